@@ -1,0 +1,149 @@
+"""ctypes front-end for the CPU oracle (oracle/vgt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: the checker for tests/, __graft_entry__.smoke() and
+bench.py's ``cpu_baseline`` leg.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_f32 = ctypes.c_float
+_f64 = ctypes.c_double
+_p = ctypes.c_void_p
+
+
+def build(march="x86-64-v3", out=None):
+    """Compile the oracle with the committed Makefile; returns the .so path."""
+    out = out or os.path.join(_HERE, "libvgt_oracle.so")
+    subprocess.check_call(
+        ["make", "-s", "-C", _HERE, "MARCH=" + march, "OUT=" + out],
+        stdout=subprocess.DEVNULL)
+    return out
+
+
+def load(path=None):
+    global _LIB
+    if path is None and _LIB is not None:
+        return _LIB
+    so = path or os.path.join(_HERE, "libvgt_oracle.so")
+    src = os.path.join(_HERE, "vgt_oracle.c")
+    if path is None and (not os.path.exists(so)
+                         or os.path.getmtime(so) < os.path.getmtime(src)):
+        build()
+    lib = ctypes.CDLL(so)
+    lib.vgt_oracle_max_threads.restype = ctypes.c_int
+    lib.vgt_oracle_edt3d_inplace.argtypes = [_p, _i64, _i64, _i64, ctypes.c_int]
+    lib.vgt_oracle_edt1d_inplace.argtypes = [_p, _i64, _i64]
+    lib.vgt_oracle_sdf_from_mask.argtypes = [_p, _i64, _i64, _i64, _f64, _p, ctypes.c_int]
+    lib.vgt_oracle_sdf_from_mask.restype = ctypes.c_int
+    lib.vgt_oracle_sdf_from_occupancy.argtypes = [
+        _p, _i64, _i64, _i64, _f64, ctypes.c_int, ctypes.c_int, _p, _p, _p, ctypes.c_int]
+    lib.vgt_oracle_sdf_from_occupancy.restype = ctypes.c_int
+    lib.vgt_oracle_raycast_f32.argtypes = [
+        _p, _i64, _f32, _p, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _i32, _p, ctypes.c_int]
+    lib.vgt_oracle_raycast_f64.argtypes = [
+        _p, _i64, _f64, _p, _f64, _f64, _f64, _f64, _f64, _i64, _i64, _i64, _p, ctypes.c_int]
+    lib.vgt_oracle_filter.argtypes = [
+        _p, _i64, _i32, _f64, _i32, _i32, ctypes.c_int, _p, ctypes.c_int]
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def max_threads():
+    return int(load().vgt_oracle_max_threads())
+
+
+def edt3d(field, threads=0):
+    """Squared EDT of a (nx,ny,nz) float64 array holding 0 at sites, +inf elsewhere."""
+    f = np.ascontiguousarray(field, dtype=np.float64).copy()
+    nx, ny, nz = f.shape
+    load().vgt_oracle_edt3d_inplace(_ptr(f), nx, ny, nz, threads)
+    return f
+
+
+def edt1d(line):
+    f = np.ascontiguousarray(line, dtype=np.float64).copy()
+    load().vgt_oracle_edt1d_inplace(_ptr(f), f.shape[0], 1)
+    return f
+
+
+def sdf_from_mask(filled, resolution, threads=0):
+    m = np.ascontiguousarray(filled, dtype=np.uint8)
+    nx, ny, nz = m.shape
+    out = np.empty((nx, ny, nz), dtype=np.float32)
+    rc = load().vgt_oracle_sdf_from_mask(_ptr(m), nx, ny, nz, float(resolution), _ptr(out), threads)
+    if rc != 0:
+        raise RuntimeError("vgt_oracle_sdf_from_mask failed rc=%d" % rc)
+    return out
+
+
+def sdf_from_occupancy(occupancy, resolution, unknown_is_filled=True,
+                       add_virtual_border=False, threads=0, lib=None):
+    """ExtractSignedDistanceField<float>; returns (sdf, min, max)."""
+    occ = np.ascontiguousarray(occupancy, dtype=np.float32)
+    nx, ny, nz = occ.shape
+    out = np.empty((nx, ny, nz), dtype=np.float32)
+    lo = ctypes.c_float()
+    hi = ctypes.c_float()
+    rc = (lib or load()).vgt_oracle_sdf_from_occupancy(
+        _ptr(occ), nx, ny, nz, float(resolution), int(bool(unknown_is_filled)),
+        int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo), ctypes.byref(hi), threads)
+    if rc != 0:
+        raise RuntimeError("vgt_oracle_sdf_from_occupancy failed rc=%d" % rc)
+    return out, float(lo.value), float(hi.value)
+
+
+def raycast_f32(points, max_range, xform, voxel_size, inverse_voxel_size,
+                grid_sizes, counts, tracking=None, threads=0, lib=None):
+    """Float32 DDA; returns int32 tracking grid of shape (nx,ny,nz,2) = (free, filled)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    T = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+    nx, ny, nz = (int(c) for c in counts)
+    if tracking is None:
+        tracking = np.zeros((nx, ny, nz, 2), dtype=np.int32)
+    (lib or load()).vgt_oracle_raycast_f32(
+        _ptr(pts), pts.shape[0], float(max_range), _ptr(T), float(voxel_size),
+        float(inverse_voxel_size), float(grid_sizes[0]), float(grid_sizes[1]),
+        float(grid_sizes[2]), nx, ny, nz, _ptr(tracking), threads)
+    return tracking
+
+
+def raycast_f64(points, max_range, xform, voxel_size, inverse_voxel_size,
+                grid_sizes, counts, tracking=None, threads=0):
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    T = np.ascontiguousarray(xform, dtype=np.float64).reshape(16)
+    nx, ny, nz = (int(c) for c in counts)
+    if tracking is None:
+        tracking = np.zeros((nx, ny, nz, 2), dtype=np.int32)
+    load().vgt_oracle_raycast_f64(
+        _ptr(pts), pts.shape[0], float(max_range), _ptr(T), float(voxel_size),
+        float(inverse_voxel_size), float(grid_sizes[0]), float(grid_sizes[1]),
+        float(grid_sizes[2]), nx, ny, nz, _ptr(tracking), threads)
+    return tracking
+
+
+def filter_grids(tracking_grids, occupancy, percent_seen_free=1.0,
+                 outlier_points_threshold=1, num_cameras_seen_free=1,
+                 ratio_in_double=False, threads=0):
+    """tracking_grids: (G,nx,ny,nz,2) int32; occupancy (nx,ny,nz) float32 -> filtered copy."""
+    tg = np.ascontiguousarray(tracking_grids, dtype=np.int32)
+    occ = np.ascontiguousarray(occupancy, dtype=np.float32).copy()
+    g = tg.shape[0]
+    cells = occ.size
+    assert tg.size == g * cells * 2
+    load().vgt_oracle_filter(_ptr(tg), cells, g, float(percent_seen_free),
+                             int(outlier_points_threshold), int(num_cameras_seen_free),
+                             int(bool(ratio_in_double)), _ptr(occ), threads)
+    return occ

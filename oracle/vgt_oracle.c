@@ -1,0 +1,694 @@
+/*
+ * vgt_oracle.c -- CPU oracle (see vgt_oracle.h: TEST INFRASTRUCTURE ONLY).
+ *
+ * Every function cites the reference file:line it restates.  Paths are relative
+ * to the reference checkout: S/ = src/voxelized_geometry_tools/,
+ * I/ = include/voxelized_geometry_tools/.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -march=native -fopenmp -ffp-contract=off).
+ * -ffp-contract=off keeps the float DDA free of FMA contraction so that it is
+ * the canonical scalar left-to-right evaluation the HIP kernel is compared to.
+ */
+#include "vgt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int vgt_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static int resolve_threads(int threads)
+{
+  if (threads > 0) return threads;
+  return vgt_oracle_max_threads();
+}
+
+/* ------------------------------------------------------------------------- */
+/* 1-D squared distance transform                                            */
+/* ------------------------------------------------------------------------- */
+
+#define EDT_AT(line, stride, i) ((line)[(i) * (stride)])
+
+static double sq_i64(int64_t v) { return (double)(v * v); }
+
+/* S/signed_distance_field_generation.cpp:85-122 -- O(n^2) for short lines. */
+static void edt1d_bruteforce(double* line, int64_t n, int64_t stride,
+                             double* d)
+{
+  for (int64_t q = 0; q < n; q++) d[q] = INFINITY;
+  for (int64_t q = 0; q < n; q++)
+  {
+    for (int64_t o = 0; o < n; o++)
+    {
+      const double cand = sq_i64(q - o) + EDT_AT(line, stride, o);
+      if (cand < d[q]) d[q] = cand;
+    }
+  }
+  for (int64_t q = 0; q < n; q++) EDT_AT(line, stride, q) = d[q];
+}
+
+/* S/signed_distance_field_generation.cpp:153-172 -- inf-safe subtraction. */
+static double inf_safe_sub(double a, double b)
+{
+  if (a == INFINITY && b == INFINITY) return 0.0;
+  if (a == INFINITY) return INFINITY;
+  if (b == INFINITY) return -INFINITY;
+  return a - b;
+}
+
+/* S/signed_distance_field_generation.cpp:175-184 -- parabola intersection. */
+static double edt_intersection(const double* line, int64_t stride, int64_t q,
+                               int64_t vk)
+{
+  const double fq = EDT_AT(line, stride, q);
+  const double fv = EDT_AT(line, stride, vk);
+  const double top = inf_safe_sub(fq + sq_i64(q), fv + sq_i64(vk));
+  const double bottom = (double)((2 * q) - (2 * vk));
+  return top / bottom;
+}
+
+/* S/signed_distance_field_generation.cpp:124-226 -- Felzenszwalb-Huttenlocher
+ * lower envelope; z has n+1 entries, v and d have n. */
+static void edt1d_linear(double* line, int64_t n, int64_t stride, double* z,
+                         int64_t* v, double* d)
+{
+  memset(z, 0, sizeof(double) * (size_t)(n + 1));
+  memset(v, 0, sizeof(int64_t) * (size_t)n);
+  memset(d, 0, sizeof(double) * (size_t)n);
+  z[0] = -INFINITY;
+  z[1] = INFINITY;
+
+  /* phase 1 (:187-204) */
+  int64_t k = 0;
+  for (int64_t q = 1; q < n; q++)
+  {
+    double s = edt_intersection(line, stride, q, v[k]);
+    while (k > 0 && s <= z[k])
+    {
+      k--;
+      s = edt_intersection(line, stride, q, v[k]);
+    }
+    k++;
+    v[k] = q;
+    z[k] = s;
+    z[k + 1] = INFINITY;
+  }
+
+  /* phase 2 (:207-225) */
+  k = 0;
+  for (int64_t q = 0; q < n; q++)
+  {
+    while (z[k + 1] < (double)q) k++;
+    const int64_t vk = v[k];
+    d[q] = sq_i64(q - vk) + EDT_AT(line, stride, vk);
+  }
+  for (int64_t q = 0; q < n; q++) EDT_AT(line, stride, q) = d[q];
+}
+
+/* S/signed_distance_field_generation.cpp:229-248 -- strategy threshold 8. */
+static void edt1d_dispatch(double* line, int64_t n, int64_t stride, double* z,
+                           int64_t* v, double* d)
+{
+  if (n > 8)
+    edt1d_linear(line, n, stride, z, v, d);
+  else
+    edt1d_bruteforce(line, n, stride, d);
+}
+
+void vgt_oracle_edt1d_inplace(double* line, int64_t n, int64_t stride)
+{
+  double* z = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+  int64_t* v = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+  double* d = (double*)malloc(sizeof(double) * (size_t)n);
+  edt1d_dispatch(line, n, stride, z, v, d);
+  free(z);
+  free(v);
+  free(d);
+}
+
+/* One axis sweep over `count` independent lines; line i starts at
+ * field + (i / step) * outer + (i % step) * inner  (:265-271 index split).
+ * Static contiguous ranges per thread with per-thread scratch, like
+ * StaticParallelForRangeLoop at :286-311. */
+static void edt_axis_sweep(double* field, int64_t n, int64_t stride,
+                           int64_t count, int64_t step, int64_t outer,
+                           int64_t inner, int threads)
+{
+#pragma omp parallel num_threads(threads)
+  {
+    double* z = (double*)malloc(sizeof(double) * (size_t)(n + 1));
+    int64_t* v = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    double* d = (double*)malloc(sizeof(double) * (size_t)n);
+#pragma omp for schedule(static)
+    for (int64_t it = 0; it < count; it++)
+    {
+      const int64_t first = it / step;
+      const int64_t second = it % step;
+      edt1d_dispatch(field + first * outer + second * inner, n, stride, z, v,
+                     d);
+    }
+    free(z);
+    free(v);
+    free(d);
+  }
+}
+
+/* S/signed_distance_field_generation.cpp:258-391. */
+void vgt_oracle_edt3d_inplace(double* field, int64_t nx, int64_t ny,
+                              int64_t nz, int threads)
+{
+  threads = resolve_threads(threads);
+  const int64_t sx = ny * nz, sy = nz, sz = 1;
+  if (nx > 1) /* X lines, iteration -> (y, z) by / and % nz (:275-312) */
+    edt_axis_sweep(field, nx, sx, ny * nz, nz, sy, sz, threads);
+  if (ny > 1) /* Y lines, iteration -> (x, z) (:314-351) */
+    edt_axis_sweep(field, ny, sy, nx * nz, nz, sx, sz, threads);
+  if (nz > 1) /* Z lines, iteration -> (x, y) by / and % ny (:353-390) */
+    edt_axis_sweep(field, nz, sz, nx * ny, ny, sx, sy, threads);
+}
+
+/* ------------------------------------------------------------------------- */
+/* SDF assembly                                                              */
+/* ------------------------------------------------------------------------- */
+
+/* I/signed_distance_field_generation.hpp:39-113. */
+int vgt_oracle_sdf_from_mask(const uint8_t* filled, int64_t nx, int64_t ny,
+                             int64_t nz, double resolution, float* sdf_out,
+                             int threads)
+{
+  const int64_t n = nx * ny * nz;
+  if (n <= 0) return 1;
+  double* to_filled = (double*)malloc(sizeof(double) * (size_t)n);
+  double* to_free = (double*)malloc(sizeof(double) * (size_t)n);
+  if (!to_filled || !to_free)
+  {
+    free(to_filled);
+    free(to_free);
+    return 2;
+  }
+  /* :47-74 -- both fields start at +inf, marked cells get 0 (serial loop) */
+  for (int64_t i = 0; i < n; i++)
+  {
+    to_filled[i] = INFINITY;
+    to_free[i] = INFINITY;
+  }
+  for (int64_t i = 0; i < n; i++)
+  {
+    if (filled[i])
+      to_filled[i] = 0.0;
+    else
+      to_free[i] = 0.0;
+  }
+  /* :77-80 */
+  vgt_oracle_edt3d_inplace(to_filled, nx, ny, nz, threads);
+  vgt_oracle_edt3d_inplace(to_free, nx, ny, nz, threads);
+  /* :85-108 (serial loop) */
+  for (int64_t i = 0; i < n; i++)
+  {
+    const double distance1 = sqrt(to_filled[i]) * resolution;
+    const double distance2 = sqrt(to_free[i]) * resolution;
+    const double distance = distance1 - distance2;
+    sdf_out[i] = (float)distance;
+  }
+  free(to_filled);
+  free(to_free);
+  return 0;
+}
+
+/* I/occupancy_map.hpp:181-205 -- the is_filled predicate. */
+static int occupancy_is_filled(float occupancy, int unknown_is_filled)
+{
+  if (occupancy > 0.5) return 1;
+  if (unknown_is_filled && (occupancy == 0.5)) return 1;
+  return 0;
+}
+
+int vgt_oracle_sdf_from_occupancy(const float* occupancy, int64_t nx,
+                                  int64_t ny, int64_t nz, double resolution,
+                                  int unknown_is_filled, int add_virtual_border,
+                                  float* sdf_out, float* out_min,
+                                  float* out_max, int threads)
+{
+  const int64_t n = nx * ny * nz;
+  if (n <= 0 || nx <= 0 || ny <= 0 || nz <= 0) return 1;
+  int rc = 0;
+  if (!add_virtual_border)
+  {
+    /* I/signed_distance_field_generation.hpp:127-133 */
+    uint8_t* mask = (uint8_t*)malloc((size_t)n);
+    if (!mask) return 2;
+    for (int64_t i = 0; i < n; i++)
+      mask[i] = (uint8_t)occupancy_is_filled(occupancy[i], unknown_is_filled);
+    rc = vgt_oracle_sdf_from_mask(mask, nx, ny, nz, resolution, sdf_out,
+                                  threads);
+    free(mask);
+  }
+  else
+  {
+    /* I/signed_distance_field_generation.hpp:134-284 -- pad every axis that
+     * has more than one voxel by one cell on each side, build one SDF with
+     * the border filled and one with the border empty, combine. */
+    const int64_t ox = (nx > 1) ? 1 : 0, oy = (ny > 1) ? 1 : 0,
+                  oz = (nz > 1) ? 1 : 0;
+    const int64_t px = nx + 2 * ox, py = ny + 2 * oy, pz = nz + 2 * oz;
+    const int64_t pn = px * py * pz;
+    uint8_t* border_filled = (uint8_t*)malloc((size_t)pn);
+    uint8_t* border_empty = (uint8_t*)malloc((size_t)pn);
+    float* sdf_free = (float*)malloc(sizeof(float) * (size_t)pn);
+    float* sdf_filled = (float*)malloc(sizeof(float) * (size_t)pn);
+    if (!border_filled || !border_empty || !sdf_free || !sdf_filled)
+    {
+      free(border_filled);
+      free(border_empty);
+      free(sdf_free);
+      free(sdf_filled);
+      return 2;
+    }
+    for (int64_t x = 0; x < px; x++)
+      for (int64_t y = 0; y < py; y++)
+        for (int64_t z = 0; z < pz; z++)
+        {
+          const int on_border = (ox && (x == 0 || x == px - 1)) ||
+                                (oy && (y == 0 || y == py - 1)) ||
+                                (oz && (z == 0 || z == pz - 1));
+          const int64_t pi = (x * py + y) * pz + z;
+          if (on_border)
+          {
+            border_filled[pi] = 1; /* :156-194 */
+            border_empty[pi] = 0;  /* :197-235 */
+          }
+          else
+          {
+            const int64_t ri = ((x - ox) * ny + (y - oy)) * nz + (z - oz);
+            const uint8_t f = (uint8_t)occupancy_is_filled(occupancy[ri],
+                                                           unknown_is_filled);
+            border_filled[pi] = f;
+            border_empty[pi] = f;
+          }
+        }
+    rc = vgt_oracle_sdf_from_mask(border_filled, px, py, pz, resolution,
+                                  sdf_free, threads);
+    if (rc == 0)
+      rc = vgt_oracle_sdf_from_mask(border_empty, px, py, pz, resolution,
+                                    sdf_filled, threads);
+    if (rc == 0)
+    {
+      /* :247-279 */
+      for (int64_t x = 0; x < nx; x++)
+        for (int64_t y = 0; y < ny; y++)
+          for (int64_t z = 0; z < nz; z++)
+          {
+            const int64_t pi = ((x + ox) * py + (y + oy)) * pz + (z + oz);
+            const float free_value = sdf_free[pi];
+            const float filled_value = sdf_filled[pi];
+            float out;
+            if (free_value >= 0.0)
+              out = free_value;
+            else if (filled_value <= -0.0)
+              out = filled_value;
+            else
+              out = 0.0f;
+            sdf_out[(x * ny + y) * nz + z] = out;
+          }
+    }
+    free(border_filled);
+    free(border_empty);
+    free(sdf_free);
+    free(sdf_filled);
+  }
+  if (rc != 0) return rc;
+  /* I/signed_distance_field.hpp:765-787 -- Lock(): serial minmax scan */
+  float lo = sdf_out[0], hi = sdf_out[0];
+  for (int64_t i = 1; i < n; i++)
+  {
+    if (sdf_out[i] < lo) lo = sdf_out[i];
+    if (hi < sdf_out[i]) hi = sdf_out[i];
+  }
+  if (out_min) *out_min = lo;
+  if (out_max) *out_max = hi;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Raycast DDA -- float32 (device kernel restatement)                        */
+/* ------------------------------------------------------------------------- */
+
+static int32_t step_from_diff_i32(int32_t diff)
+{
+  return (diff > 0) ? 1 : ((diff < 0) ? -1 : 0); /* S/cuda...cu:35-50 */
+}
+
+/* S/cuda_voxelization_helpers.cu:52-71 */
+static float axis_t_f32(float point_axis, float ray_axis, float vmin,
+                        float vmax)
+{
+  if (ray_axis > 0.0f) return fabsf((vmax - point_axis) / ray_axis);
+  if (ray_axis < -0.0f) return fabsf((point_axis - vmin) / ray_axis);
+  return INFINITY;
+}
+
+static void atomic_inc_i32(int32_t* p)
+{
+#pragma omp atomic
+  (*p)++;
+}
+
+/* S/cuda_voxelization_helpers.cu:73-356, one point. */
+static void raycast_one_f32(const float* pt, float max_range, const float* T,
+                            float vs, float ivs, const float gs[3], int32_t nx,
+                            int32_t ny, int32_t nz, int32_t* grid)
+{
+  const float px = pt[0], py = pt[1], pz = pt[2];
+  if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) return; /* :97-100 */
+
+  /* :103-114 */
+  const float gx = T[0] * px + T[4] * py + T[8] * pz + T[12];
+  const float gy = T[1] * px + T[5] * py + T[9] * pz + T[13];
+  const float gz = T[2] * px + T[6] * py + T[10] * pz + T[14];
+  /* :117-119 */
+  const float o[3] = {T[12], T[13], T[14]};
+  /* :122-136 */
+  const float ray[3] = {gx - o[0], gy - o[1], gz - o[2]};
+  const float len = sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+  const int clipped = len > max_range;
+  float fin[3] = {gx, gy, gz};
+  if (clipped)
+  {
+    fin[0] = o[0] + (ray[0] * (max_range / len));
+    fin[1] = o[1] + (ray[1] * (max_range / len));
+    fin[2] = o[2] + (ray[2] * (max_range / len));
+  }
+  /* :139-149 */
+  const int32_t oi[3] = {(int32_t)floorf(o[0] * ivs), (int32_t)floorf(o[1] * ivs),
+                         (int32_t)floorf(o[2] * ivs)};
+  const int32_t dims[3] = {nx, ny, nz};
+  const int origin_in_grid = oi[0] >= 0 && oi[0] < nx && oi[1] >= 0 &&
+                             oi[1] < ny && oi[2] >= 0 && oi[2] < nz;
+  float start[3] = {o[0], o[1], o[2]};
+  if (!origin_in_grid) /* :154-225 */
+  {
+    float tmin = 0.0f, tmax = max_range;
+    const float dir[3] = {ray[0] / len, ray[1] / len, ray[2] / len};
+    const float flat_threshold = 1e-10f;
+    for (int a = 0; a < 3; a++)
+    {
+      if (fabsf(dir[a]) < flat_threshold)
+      {
+        const int in_slab = o[a] >= 0.0f && o[a] < gs[a];
+        if (!in_slab) return;
+      }
+      else
+      {
+        const float ood = 1.0f / dir[a];
+        const float tlow = (0.0f - o[a]) * ood;
+        const float thigh = (gs[a] - o[a]) * ood;
+        const float t1 = (tlow <= thigh) ? tlow : thigh;
+        const float t2 = (tlow <= thigh) ? thigh : tlow;
+        if (t1 > tmin) tmin = t1;
+        if (t2 > tmax) tmax = t2; /* sic: reference quirk, :206-209 */
+        if (tmin > tmax) return;
+      }
+    }
+    const float nudge = 1e-10f;
+    start[0] = o[0] + (dir[0] * (tmin + nudge));
+    start[1] = o[1] + (dir[1] * (tmin + nudge));
+    start[2] = o[2] + (dir[2] * (tmin + nudge));
+  }
+  /* :228-245 */
+  int32_t si[3], fi[3], step[3];
+  for (int a = 0; a < 3; a++)
+  {
+    si[a] = (int32_t)floorf(start[a] * ivs);
+    fi[a] = (int32_t)floorf(fin[a] * ivs);
+    step[a] = step_from_diff_i32(fi[a] - si[a]);
+  }
+  /* :248-274 */
+  const float half = vs * 0.5f;
+  float t[3], dt[3];
+  for (int a = 0; a < 3; a++)
+  {
+    const float centre = ((float)si[a] + 0.5f) * vs;
+    const float lo = centre - half, hi = centre + half;
+    t[a] = axis_t_f32(start[a], ray[a], lo, hi);
+    dt[a] = fabsf(vs / ray[a]);
+  }
+  const int32_t stride1 = ny * nz, stride2 = nz; /* :683-684 */
+  /* :277-293 -- the final voxel is marked first */
+  if (fi[0] >= 0 && fi[0] < nx && fi[1] >= 0 && fi[1] < ny && fi[2] >= 0 &&
+      fi[2] < nz)
+  {
+    const int32_t di = (fi[0] * stride1) + (fi[1] * stride2) + fi[2];
+    atomic_inc_i32(&grid[(di * 2) + (clipped ? 0 : 1)]);
+  }
+  /* :295-355 */
+  int32_t c[3] = {si[0], si[1], si[2]};
+  while (c[0] != fi[0] || c[1] != fi[1] || c[2] != fi[2])
+  {
+    if (c[0] >= 0 && c[0] < dims[0] && c[1] >= 0 && c[1] < dims[1] &&
+        c[2] >= 0 && c[2] < dims[2])
+    {
+      const int32_t di = (c[0] * stride1) + (c[1] * stride2) + c[2];
+      atomic_inc_i32(&grid[(di * 2) + 0]);
+    }
+    else
+      break;
+    int a;
+    if (t[0] <= t[1] && t[0] <= t[2])
+      a = 0;
+    else if (t[1] <= t[0] && t[1] <= t[2])
+      a = 1;
+    else
+      a = 2;
+    if (c[a] == fi[a]) break;
+    c[a] += step[a];
+    t[a] += dt[a];
+  }
+}
+
+void vgt_oracle_raycast_f32(const float* points, int64_t num_points,
+                            float max_range, const float* xform,
+                            float voxel_size, float inverse_voxel_size,
+                            float grid_x_size, float grid_y_size,
+                            float grid_z_size, int32_t nx, int32_t ny,
+                            int32_t nz, int32_t* tracking, int threads)
+{
+  threads = resolve_threads(threads);
+  const float gs[3] = {grid_x_size, grid_y_size, grid_z_size};
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (int64_t i = 0; i < num_points; i++)
+    raycast_one_f32(points + 3 * i, max_range, xform, voxel_size,
+                    inverse_voxel_size, gs, nx, ny, nz, tracking);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Raycast DDA -- float64 (CPU path restatement)                             */
+/* ------------------------------------------------------------------------- */
+
+static double axis_t_f64(double point_axis, double ray_axis, double vmin,
+                         double vmax) /* S/cpu...cpp:336-353 */
+{
+  if (ray_axis > 0.0) return fabs((vmax - point_axis) / ray_axis);
+  if (ray_axis < -0.0) return fabs((point_axis - vmin) / ray_axis);
+  return INFINITY;
+}
+
+/* S/cpu_pointcloud_voxelization.cpp:208-436, one point already in grid frame
+ * (o = p_GCo, g = p_GP). */
+static void raycast_one_f64(const double o[3], const int64_t oi[3],
+                            const double g[3], double max_range, double vs,
+                            double ivs, const double gs[3], int64_t nx,
+                            int64_t ny, int64_t nz, int32_t* grid)
+{
+  const int64_t dims[3] = {nx, ny, nz};
+  /* :217-228 (Vector4d with w = 0: norm == sqrt(x^2+y^2+z^2+0)) */
+  const double ray[3] = {g[0] - o[0], g[1] - o[1], g[2] - o[2]};
+  const double len =
+      sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2] + 0.0);
+  const int clipped = len > max_range;
+  double fin[3] = {g[0], g[1], g[2]};
+  if (clipped)
+  {
+    const double scale = max_range / len;
+    fin[0] = o[0] + (ray[0] * scale);
+    fin[1] = o[1] + (ray[1] * scale);
+    fin[2] = o[2] + (ray[2] * scale);
+  }
+  /* :231-290 */
+  const int origin_in_grid = oi[0] >= 0 && oi[0] < nx && oi[1] >= 0 &&
+                             oi[1] < ny && oi[2] >= 0 && oi[2] < nz;
+  double start[3] = {o[0], o[1], o[2]};
+  if (!origin_in_grid)
+  {
+    double tmin = 0.0, tmax = max_range;
+    const double dir[3] = {ray[0] / len, ray[1] / len, ray[2] / len};
+    const double flat_threshold = 1e-10;
+    for (int a = 0; a < 3; a++)
+    {
+      if (fabs(dir[a]) < flat_threshold)
+      {
+        const int in_slab = o[a] >= 0.0 && o[a] < gs[a];
+        if (!in_slab) return;
+      }
+      else
+      {
+        const double ood = 1.0 / dir[a];
+        const double tlow = (0.0 - o[a]) * ood;
+        const double thigh = (gs[a] - o[a]) * ood;
+        const double t1 = (tlow <= thigh) ? tlow : thigh;
+        const double t2 = (tlow <= thigh) ? thigh : tlow;
+        if (t1 > tmin) tmin = t1;
+        if (t2 > tmax) tmax = t2; /* sic, :274-277 */
+        if (tmin > tmax) return;
+      }
+    }
+    const double nudge = 1e-10;
+    start[0] = o[0] + (dir[0] * (tmin + nudge));
+    start[1] = o[1] + (dir[1] * (tmin + nudge));
+    start[2] = o[2] + (dir[2] * (tmin + nudge));
+  }
+  /* :293-321 */
+  int64_t si[3], fi[3], step[3];
+  for (int a = 0; a < 3; a++)
+  {
+    si[a] = (int64_t)floor(start[a] * ivs);
+    fi[a] = (int64_t)floor(fin[a] * ivs);
+    const int64_t diff = fi[a] - si[a];
+    step[a] = (diff > 0) ? 1 : ((diff < 0) ? -1 : 0);
+  }
+  /* :324-364 */
+  const double half = vs * 0.5;
+  double t[3], dt[3];
+  for (int a = 0; a < 3; a++)
+  {
+    const double centre = ((double)si[a] + 0.5) * vs;
+    const double lo = centre - half, hi = centre + half;
+    t[a] = axis_t_f64(start[a], ray[a], lo, hi);
+    dt[a] = fabs(vs / ray[a]);
+  }
+  const int64_t stride1 = ny * nz, stride2 = nz;
+  /* :367-381 */
+  if (fi[0] >= 0 && fi[0] < nx && fi[1] >= 0 && fi[1] < ny && fi[2] >= 0 &&
+      fi[2] < nz)
+  {
+    const int64_t di = (fi[0] * stride1) + (fi[1] * stride2) + fi[2];
+    atomic_inc_i32(&grid[(di * 2) + (clipped ? 0 : 1)]);
+  }
+  /* :384-435 */
+  int64_t c[3] = {si[0], si[1], si[2]};
+  while (c[0] != fi[0] || c[1] != fi[1] || c[2] != fi[2])
+  {
+    if (c[0] >= 0 && c[0] < dims[0] && c[1] >= 0 && c[1] < dims[1] &&
+        c[2] >= 0 && c[2] < dims[2])
+    {
+      const int64_t di = (c[0] * stride1) + (c[1] * stride2) + c[2];
+      atomic_inc_i32(&grid[(di * 2) + 0]);
+    }
+    else
+      break;
+    int a;
+    if (t[0] <= t[1] && t[0] <= t[2])
+      a = 0;
+    else if (t[1] <= t[0] && t[1] <= t[2])
+      a = 1;
+    else
+      a = 2;
+    if (c[a] == fi[a]) break;
+    c[a] += step[a];
+    t[a] += dt[a];
+  }
+}
+
+/* S/cpu_pointcloud_voxelization.cpp:167-206 -- per-cloud driver.  xform is
+ * X_GC (16 doubles, column-major); p_GP = X_GC * p_CP evaluated per row as
+ * ((m0*x + m4*y) + m8*z) + m12, the canonical scalar order. */
+void vgt_oracle_raycast_f64(const double* points, int64_t num_points,
+                            double max_range, const double* T,
+                            double voxel_size, double inverse_voxel_size,
+                            double grid_x_size, double grid_y_size,
+                            double grid_z_size, int64_t nx, int64_t ny,
+                            int64_t nz, int32_t* tracking, int threads)
+{
+  threads = resolve_threads(threads);
+  const double gs[3] = {grid_x_size, grid_y_size, grid_z_size};
+  const double o[3] = {T[12], T[13], T[14]}; /* :178 */
+  const int64_t oi[3] = {(int64_t)floor(o[0] * inverse_voxel_size),
+                         (int64_t)floor(o[1] * inverse_voxel_size),
+                         (int64_t)floor(o[2] * inverse_voxel_size)}; /* :180 */
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (int64_t i = 0; i < num_points; i++)
+  {
+    const double px = points[3 * i + 0], py = points[3 * i + 1],
+                 pz = points[3 * i + 2];
+    if (!(isfinite(px) && isfinite(py) && isfinite(pz))) continue; /* :191 */
+    const double g[3] = {T[0] * px + T[4] * py + T[8] * pz + T[12],
+                         T[1] * px + T[5] * py + T[9] * pz + T[13],
+                         T[2] * px + T[6] * py + T[10] * pz + T[14]};
+    raycast_one_f64(o, oi, g, max_range, voxel_size, inverse_voxel_size, gs,
+                    nx, ny, nz, tracking);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Combine + filter                                                          */
+/* ------------------------------------------------------------------------- */
+
+void vgt_oracle_filter(const int32_t* tracking, int64_t num_cells,
+                       int32_t num_grids, double percent_seen_free,
+                       int32_t outlier_points_threshold,
+                       int32_t num_cameras_seen_free, int ratio_in_double,
+                       float* occupancy, int threads)
+{
+  threads = resolve_threads(threads);
+  const float pct_f32 = (float)percent_seen_free; /* S/device...cpp:155-156 */
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (int64_t cell = 0; cell < num_cells; cell++)
+  {
+    /* S/cuda...cu:368-371 / S/cpu...cpp:451-453: filled cells stay filled */
+    if (!(occupancy[cell] <= 0.5f)) continue;
+    int32_t seen_filled = 0, seen_free = 0;
+    for (int32_t g = 0; g < num_grids; g++)
+    {
+      const int32_t* tc = tracking + ((int64_t)g * num_cells + cell) * 2;
+      const int32_t free_count = tc[0];
+      const int32_t filled_count = tc[1];
+      const int32_t filtered_filled =
+          (filled_count >= outlier_points_threshold) ? filled_count : 0;
+      if (free_count > 0 && filtered_filled > 0)
+      {
+        int is_free;
+        if (ratio_in_double) /* I/pointcloud_voxelization_interface.hpp:60-73 */
+          is_free = ((double)free_count /
+                     (double)(free_count + filtered_filled)) >=
+                    percent_seen_free;
+        else /* S/cuda...cu:386-399 */
+          is_free = ((float)free_count /
+                     (float)(free_count + filtered_filled)) >= pct_f32;
+        if (is_free)
+          seen_free += 1;
+        else
+          seen_filled += 1;
+      }
+      else if (free_count > 0)
+        seen_free += 1;
+      else if (filtered_filled > 0)
+        seen_filled += 1;
+    }
+    if (seen_filled > 0)
+      occupancy[cell] = 1.0f;
+    else if (seen_free >= num_cameras_seen_free)
+      occupancy[cell] = 0.0f;
+    else
+      occupancy[cell] = 0.5f;
+  }
+}

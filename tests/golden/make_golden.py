@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/.
+
+Run in the BUILD container only (needs scipy; compiles gen_raycast_rays.cpp with g++):
+
+    python tests/golden/make_golden.py
+
+Outputs
+  sdf_scipy.npz            random / structured occupancy grids with the expected float SDF
+                           computed by an INDEPENDENT exact EDT
+                           (scipy.ndimage.distance_transform_edt),
+                           with and without the virtual border (border variant by explicit
+                           padding, the literal construction of
+                           include/voxelized_geometry_tools/signed_distance_field_generation.hpp:134-284).
+  voxelization_scene.npz   the scene of the reference's test/pointcloud_voxelization_test.cpp:166-246
+                           (static grid, two 129x129 lattice clouds, grid<-cloud transforms).
+  raycast_rays.npy         the 1000 seeded (origin, point) pairs of test/voxel_raycasting_test.cpp.
+None of these contain reference source text; they are inputs and expected outputs only.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from voxelized_geometry_tools_amd import synthetic  # noqa: E402
+
+
+def is_filled(occ, unknown_is_filled=True):
+    f = occ > 0.5
+    if unknown_is_filled:
+        f |= (occ == 0.5)
+    return f
+
+
+def scipy_sdf(filled, res):
+    """float32(sqrt(d2_filled)*res - sqrt(d2_free)*res) with exact integer d2."""
+    from scipy import ndimage
+    filled = np.asarray(filled, dtype=bool)
+    if filled.any():
+        d_f = ndimage.distance_transform_edt(~filled)
+        d2_f = np.rint(d_f * d_f)
+    else:
+        d2_f = np.full(filled.shape, np.inf)
+    if (~filled).any():
+        d_e = ndimage.distance_transform_edt(filled)
+        d2_e = np.rint(d_e * d_e)
+    else:
+        d2_e = np.full(filled.shape, np.inf)
+    return np.float32(np.sqrt(d2_f) * res - np.sqrt(d2_e) * res)
+
+
+def scipy_sdf_virtual_border(filled, res):
+    """Literal padded construction: SDF#1 border filled, SDF#2 border empty, combine."""
+    filled = np.asarray(filled, dtype=bool)
+    pad = [(1, 1) if n > 1 else (0, 0) for n in filled.shape]
+    inner = tuple(slice(1, -1) if n > 1 else slice(None) for n in filled.shape)
+    free_sdf = scipy_sdf(np.pad(filled, pad, constant_values=True), res)[inner]
+    filled_sdf = scipy_sdf(np.pad(filled, pad, constant_values=False), res)[inner]
+    out = np.zeros(filled.shape, dtype=np.float32)
+    pick_free = free_sdf >= 0.0
+    pick_filled = (~pick_free) & (filled_sdf <= -0.0)
+    out[pick_free] = free_sdf[pick_free]
+    out[pick_filled] = filled_sdf[pick_filled]
+    return out
+
+
+def make_sdf_fixture():
+    cases = {}
+    rng = np.random.default_rng(20240807)
+
+    def add(name, occ, res, uif=True):
+        occ = np.ascontiguousarray(occ, dtype=np.float32)
+        f = is_filled(occ, uif)
+        cases[name + "__occ"] = occ
+        cases[name + "__res"] = np.float64(res)
+        cases[name + "__uif"] = np.int32(uif)
+        cases[name + "__sdf"] = scipy_sdf(f, res)
+        cases[name + "__sdf_vb"] = scipy_sdf_virtual_border(f, res)
+
+    add("rand_12x10x16_p05", (rng.random((12, 10, 16)) < 0.05), 0.37)
+    add("rand_9x17x11_p50", (rng.random((9, 17, 11)) < 0.5), 0.37)
+    add("rand_16c_p001", (rng.random((16, 16, 16)) < 0.001), 0.37)
+    add("rand_20x3x9_p30", (rng.random((20, 3, 9)) < 0.3), 0.37)
+    add("plane_1x14x9", (rng.random((1, 14, 9)) < 0.2), 0.125)
+    add("line_1x1x37", (rng.random((1, 1, 37)) < 0.2), 0.5)
+    add("line_41x1x1", (rng.random((41, 1, 1)) < 0.2), 0.5)
+    add("col_1x33x1", (rng.random((1, 33, 1)) < 0.2), 0.5)
+    add("single_1x1x1_free", np.zeros((1, 1, 1)), 1.0)
+    add("single_1x1x1_filled", np.ones((1, 1, 1)), 1.0)
+    add("empty_10c", np.zeros((10, 10, 10)), 0.1)
+    add("full_10c", np.ones((10, 10, 10)), 0.1)
+    occ = rng.choice(np.array([0.0, 0.25, 0.5, 0.75, 1.0], dtype=np.float32), size=(13, 9, 21),
+                     p=[0.7, 0.05, 0.1, 0.05, 0.1])
+    add("unknown_mix_13x9x21_uif1", occ, 0.02, True)
+    add("unknown_mix_13x9x21_uif0", occ, 0.02, False)
+    add("odd_33x65x31_p02", (rng.random((33, 65, 31)) < 0.02), 0.01)
+    # BASELINE config C1: 64^3, distributions D1/D2/D3, seed 42, res 0.01
+    add("c1_64c_spheres", synthetic.occupancy_spheres((64, 64, 64), 42), 0.01)
+    add("c1_64c_salt", synthetic.occupancy_salt((64, 64, 64), 42), 0.01)
+    add("c1_64c_unknown_mix", synthetic.occupancy_unknown_mix((64, 64, 64), 42), 0.01)
+    add("c1_64c_single", synthetic.occupancy_degenerate((64, 64, 64), "single"), 0.01)
+    np.savez_compressed(os.path.join(HERE, "sdf_scipy.npz"), **cases)
+    print("sdf_scipy.npz:", len(cases) // 5, "cases")
+
+
+# ---- Eigen-equivalent rigid transform construction (documented in DESIGN.md) ----
+def quat_from_angle_axis(angle, axis):
+    s = np.sin(angle / 2.0)
+    return np.array([np.cos(angle / 2.0), axis[0] * s, axis[1] * s, axis[2] * s])  # w,x,y,z
+
+
+def quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx])
+
+
+def quat_to_matrix(q):
+    w, x, y, z = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+def isometry(translation, rot=None):
+    m = np.eye(4)
+    if rot is not None:
+        m[:3, :3] = rot
+    m[:3, 3] = translation
+    return m
+
+
+def iso_mul(a, b):
+    m = np.eye(4)
+    m[:3, :3] = a[:3, :3] @ b[:3, :3]
+    m[:3, 3] = a[:3, :3] @ b[:3, 3] + a[:3, 3]
+    return m
+
+
+def make_voxelization_scene():
+    ux, uz = np.array([1.0, 0, 0]), np.array([0, 0, 1.0])
+    # X_CO: physical -> optical frame (test/pointcloud_voxelization_test.cpp:192-194)
+    q_co = quat_mul(quat_from_angle_axis(-np.pi / 2, uz), quat_from_angle_axis(-np.pi / 2, ux))
+    x_co = isometry([0, 0, 0], quat_to_matrix(q_co))
+    x_wc1o = iso_mul(isometry([-2.0, 0, 0]), x_co)                                   # :197-198
+    x_wc2 = isometry([0, -2.0, 0], quat_to_matrix(quat_from_angle_axis(np.pi / 2, uz)))  # :213-214
+    x_wc2o = iso_mul(x_wc2, x_co)
+    x_gw = isometry([1.0, 1.0, 1.0])   # inverse of X_WG = Translation(-1,-1,-1) (:169)
+    lattice = np.arange(129) * 0.03125 - 2.0   # x += 0.03125 from -2 to 2 inclusive (:202-204)
+    gx, gy = np.meshgrid(lattice, lattice, indexing="ij")
+
+    def cloud(near_mask):
+        z = np.where(near_mask, 2.125, 4.0)
+        return np.stack([gx.ravel(), gy.ravel(), z.ravel()], axis=1)
+
+    cam1 = cloud(gx <= 0.0)    # :206
+    cam2 = cloud(gx >= 0.0)    # :223
+    occ = np.zeros((8, 8, 8), dtype=np.float32)
+    occ[:, :, 0] = 1.0         # :181-188
+    out = {
+        "static_occupancy": occ,
+        "voxel_size": np.float64(0.25),
+        "cam1_points": cam1, "cam2_points": cam2,
+        "cam1_X_GC_colmajor": iso_mul(x_gw, x_wc1o).T.reshape(16).copy(),
+        "cam2_X_GC_colmajor": iso_mul(x_gw, x_wc2o).T.reshape(16).copy(),
+        "cam3_X_GC_colmajor": iso_mul(x_gw, iso_mul(isometry([0, 0, 0]), x_co)).T.reshape(16).copy(),
+        "max_range": np.float64(np.inf),
+        "filter": np.array([1.0, 1, 1]),
+    }
+    np.savez_compressed(os.path.join(HERE, "voxelization_scene.npz"), **out)
+    print("voxelization_scene.npz: 2 clouds x", cam1.shape[0], "points")
+
+
+def make_raycast_rays():
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "gen")
+        raw = os.path.join(td, "rays.bin")
+        subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(HERE, "gen_raycast_rays.cpp")])
+        subprocess.check_call([exe, raw])
+        rays = np.fromfile(raw, dtype="<f8").reshape(1000, 6)
+    np.save(os.path.join(HERE, "raycast_rays.npy"), rays)
+    print("raycast_rays.npy:", rays.shape, "first", rays[0])
+
+
+if __name__ == "__main__":
+    make_sdf_fixture()
+    make_voxelization_scene()
+    make_raycast_rays()
