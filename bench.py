@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvoxels/s of a float SDF extraction (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--dist spheres]
+
+One "step" = one full ExtractSignedDistanceField<float> pass (Z scan, Y pass, X pass +
+finalize + min/max) over a synthetic occupancy grid that is already resident in HBM; the
+SDF is left in HBM.  N = 1 runs BASELINE config 4 (1024^3, distribution D1 "spheres", seed
+42, resolution 0.01).  N > 1 runs BASELINE config 5 (2048 x 2048 x 1024) partitioned into
+Z slabs, one process per GPU, with one RCCL exchange of per-line boundary summaries
+(voxelized_geometry_tools_amd/multi_gpu.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_VOXEL_PASS = 8.0  # 3 passes x (4 B read + 4 B write) = 24 B/voxel
+KERNEL_NAMES = ["ScanZ", "PassY", "PassXFinalize"]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=0, help="cube edge for N=1 (default 1024)")
+    ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
+    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default, 1 pruned search)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=None):
+    """Synthetic occupancy built directly in HBM; identical to synthetic.make_occupancy."""
+    from voxelized_geometry_tools_amd import synthetic
+    full_shape = full_shape or shape
+    nx, ny, nz = shape
+    occ = torch.zeros(shape, dtype=torch.float32, device=device)
+    if dist in ("spheres", "unknown_mix"):
+        centres, r2 = synthetic.sphere_list(full_shape, seed)
+        for (cx, cy, cz), rr in zip(centres, r2):
+            cz = int(cz) - z_offset
+            r = int(np.ceil(np.sqrt(rr)))
+            x0, x1 = max(int(cx) - r, 0), min(int(cx) + r + 1, nx)
+            y0, y1 = max(int(cy) - r, 0), min(int(cy) + r + 1, ny)
+            z0, z1 = max(cz - r, 0), min(cz + r + 1, nz)
+            if x0 >= x1 or y0 >= y1 or z0 >= z1:
+                continue
+            dx = (torch.arange(x0, x1, device=device, dtype=torch.int64) - int(cx)) ** 2
+            dy = (torch.arange(y0, y1, device=device, dtype=torch.int64) - int(cy)) ** 2
+            dz = (torch.arange(z0, z1, device=device, dtype=torch.int64) - cz) ** 2
+            d2 = dx[:, None, None] + dy[None, :, None] + dz[None, None, :]
+            occ[x0:x1, y0:y1, z0:z1][d2.to(torch.float64) <= float(rr)] = 1.0
+        if dist == "unknown_mix":
+            g = torch.Generator(device=device)
+            g.manual_seed(seed + 1)
+            occ[torch.rand(shape, device=device, generator=g) < 0.01] = 0.5
+    elif dist == "salt":
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        occ = (torch.rand(shape, device=device, generator=g) < 0.01).to(torch.float32)
+    elif dist == "single":
+        if z_offset == 0:
+            occ[0, 0, 0] = 1.0
+    return occ
+
+
+def cpu_baseline(budget_s):
+    """Times the CPU oracle (a port of the reference's OpenMP CPU path, NOT the reference
+    binary -- unbuildable here) on a bounded sample of the same distribution."""
+    import tempfile
+    from oracle import oracle as O
+    from voxelized_geometry_tools_amd import synthetic
+    lib = None
+    try:  # rebuild with -march=native for this host, like the reference's CMake does
+        out = os.path.join(tempfile.mkdtemp(prefix="vgt_oracle_"), "libvgt_oracle_native.so")
+        lib = O.load(O.build(march="native", out=out))
+    except Exception:
+        lib = O.load()
+    cores = int(lib.vgt_oracle_max_threads())
+    edge, rate = 96, None
+    while True:
+        occ = synthetic.occupancy_spheres((edge,) * 3, 42)
+        t0 = time.perf_counter()
+        O.sdf_from_occupancy(occ, 0.01, True, False, 0, lib=lib)
+        dt = time.perf_counter() - t0
+        rate = occ.size / dt / 1e6
+        nxt = int(edge * 1.5) // 32 * 32
+        # EDT cost is ~linear in voxels; stop once the next size would blow the budget
+        if dt * (nxt / edge) ** 3 > budget_s or nxt > 640:
+            break
+        edge = nxt
+    return {"value": round(rate, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": "%d^3 D1 spheres seed 42, res 0.01, %.2f s on %d OpenMP threads "
+                      "(oracle/vgt_oracle.c, -O3 -march=native)" % (edge, dt, cores)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    from voxelized_geometry_tools_amd import capi
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    res = 0.01
+    if world == 1:
+        edge = args.size or 1024
+        full_shape = (edge, edge, edge)
+        local_shape = full_shape
+        z_offset = 0
+        workload = "%d^3 float SDF, D1 %s seed 42, res 0.01, device-resident" % (edge, args.dist)
+        parallelism = "single GPU"
+    else:
+        from voxelized_geometry_tools_amd import multi_gpu
+        full_shape = (2048, 2048, 1024) if not args.size else (args.size,) * 3
+        local_shape, z_offset = multi_gpu.slab_of(full_shape, rank, world)
+        workload = "%dx%dx%d float SDF, D1 %s seed 42, res 0.01, Z-slab x%d, device-resident" % (
+            full_shape + (args.dist, world))
+        parallelism = "zslab%d" % world
+
+    occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape)
+    sdf = torch.empty(local_shape, dtype=torch.float32, device=device)
+    ws_bytes = capi.sdf_workspace_bytes(local_shape)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    minmax = torch.zeros(2, dtype=torch.float32, device=device)
+    ctx = capi.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_edt_variant(args.variant)
+    if world > 1:
+        runner = multi_gpu.SlabSdf(ctx, torch, dist, full_shape, rank, world, device)
+
+    kernel_ms = np.zeros(3, dtype=np.float32)
+    kernel_sum = np.zeros(3, dtype=np.float64)
+
+    def step(timed):
+        if world == 1:
+            ctx.sdf_dev(occ.data_ptr(), local_shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes,
+                        minmax.data_ptr(), kernel_ms=kernel_ms if timed else None)
+        else:
+            runner.run(occ, sdf, ws, minmax, res, kernel_ms if timed else None)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        kernel_sum += kernel_ms
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_vox = float(np.prod(full_shape))
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_vox / (elapsed / args.steps) / 1e6
+    avg_ms = kernel_sum / max(args.steps, 1)
+    dom = int(np.argmax(avg_ms))
+    local_vox = float(np.prod(local_shape))
+    achieved = ALG_BYTES_PER_VOXEL_PASS * local_vox / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+    whole = 3 * ALG_BYTES_PER_VOXEL_PASS * local_vox / (avg_ms.sum() * 1e-3) / 1e9 if avg_ms.sum() > 0 else 0.0
+    mm = minmax.cpu().numpy()
+
+    if rank == 0:
+        line = {
+            "metric": "Mvoxels/s for 1024^3 float SDF extract @1 GPU; % HBM roofline",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "shape": list(full_shape), "parallelism": parallelism,
+                       "edt_variant": args.variant, "sdf_min_max": [float(mm[0]), float(mm[1])]},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom],
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNEL_NAMES, avg_ms)},
+                         "whole_sdf_achieved": round(whole, 1),
+                         "whole_sdf_frac": round(whole / HBM_PEAK_GBPS, 4),
+                         "algorithmic_bytes_per_voxel": {"per_pass": 8, "whole_sdf": 24}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+/*
+ * vgt_hip.h -- C ABI of libvgt_hip.so, the MI355X (gfx950) backend for the SDF/EDT and
+ * pointcloud-raycast-voxelization hot path of calderpg/voxelized_geometry_tools.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Each entry point names the reference interface it stands in for (paths relative to
+ * the reference checkout; I/ = include/voxelized_geometry_tools/,
+ * S/ = src/voxelized_geometry_tools/).  The reference-side binding a maintainer would
+ * add is shown in INTEGRATION.md; include/vgt_hip/ holds the C++ glue that implements
+ * the reference's DeviceVoxelizationHelperInterface on top of these calls.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is then
+ *     available from vgt_hip_last_error() (thread-local).  No exception crosses the ABI.
+ *   - dense grids are X-major / Z fastest: index = x*(ny*nz) + y*nz + z
+ *     (S/cuda_voxelization_helpers.cu:683-684).
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory
+ *     on the context's device.  The caller owns every buffer it passes in; the library
+ *     owns what it hands out behind the opaque handles.
+ *   - there is no CPU fallback: without a usable HIP device vgt_hip_create() fails.
+ */
+#ifndef VGT_HIP_H_
+#define VGT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGT_HIP_ABI_VERSION 1
+
+typedef struct vgt_hip_ctx vgt_hip_ctx;       /* one context <-> one device + one stream */
+typedef struct vgt_hip_grids vgt_hip_grids;   /* tracking grids (TrackingGridsHandle)    */
+typedef struct vgt_hip_filter vgt_hip_filter; /* filter grid (FilterGridHandle)          */
+
+/* Error codes (also the return values). */
+enum {
+  VGT_HIP_OK = 0,
+  VGT_HIP_ERR_INVALID_ARGUMENT = 1, /* maps to std::invalid_argument in the C++ glue */
+  VGT_HIP_ERR_RUNTIME = 2,          /* HIP error; maps to std::runtime_error          */
+  VGT_HIP_ERR_UNAVAILABLE = 3       /* no device / device index out of range           */
+};
+
+int vgt_hip_abi_version(void);
+const char* vgt_hip_last_error(void);
+
+/* ---- device enumeration: hip_helpers::GetAvailableDevices()
+ *      (sibling of cuda_helpers::GetAvailableDevices, S/cuda_voxelization_helpers.cu:791-821) */
+int vgt_hip_device_count(int* count);
+int vgt_hip_device_name(int device, char* buffer, size_t buffer_size);
+
+/* ---- context: the state behind hip_helpers::MakeHipVoxelizationHelper(options, log)
+ *      (I/cuda_voxelization_helpers.h:19-24; ctor S/cuda_voxelization_helpers.cu:562-639).
+ *      threads_per_block <= 0 selects the default (256).  Options HIP_DEVICE /
+ *      HIP_THREADS_PER_BLOCK of the C++ glue land here. */
+int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx);
+void vgt_hip_destroy(vgt_hip_ctx* ctx);
+/* Run all work of this context on an externally owned hipStream_t (e.g. the caller's
+ * framework stream); pass NULL to go back to the context's own stream. */
+int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream);
+int vgt_hip_synchronize(vgt_hip_ctx* ctx);
+int vgt_hip_device_of(const vgt_hip_ctx* ctx);
+
+/* =====================  pointcloud raycast voxelization  ===================== */
+
+/* DeviceVoxelizationHelperInterface::PrepareTrackingGrids
+ * (I/device_voxelization_interface.hpp:148-149; S/cuda_voxelization_helpers.cu:641-658):
+ * num_grids zeroed grids of int32[2*num_cells] = (seen_free, seen_filled) per cell,
+ * grid g starting at element offset g*num_cells*2. */
+int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t num_grids,
+                                  vgt_hip_grids** out_grids);
+void vgt_hip_tracking_grids_destroy(vgt_hip_grids* grids);
+int64_t vgt_hip_tracking_grids_num_cells(const vgt_hip_grids* grids);
+int32_t vgt_hip_tracking_grids_num_grids(const vgt_hip_grids* grids);
+int64_t vgt_hip_tracking_grids_offset(const vgt_hip_grids* grids, size_t grid_index);
+void* vgt_hip_tracking_grids_dev_ptr(const vgt_hip_grids* grids, size_t grid_index);
+int vgt_hip_tracking_grids_clear(vgt_hip_ctx* ctx, vgt_hip_grids* grids);
+
+/* DeviceVoxelizationHelperInterface::RaycastPoints
+ * (I/device_voxelization_interface.hpp:151-158; kernel S/cuda_voxelization_helpers.cu:73-356):
+ * float32 DDA of num_points xyz points (AoS, cloud frame) through the grid, transform =
+ * 16 floats column-major (grid <- cloud).  Safe to call concurrently from several host
+ * threads on one context with distinct grid_index
+ * (S/device_pointcloud_voxelization.cpp:147-149).  Returns after the kernel has been
+ * enqueued AND the host point buffer has been consumed. */
+int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                               const float* points_xyz_host, int64_t num_points,
+                               float max_range, const float* grid_pointcloud_transform,
+                               float voxel_size, float inverse_voxel_size,
+                               float grid_x_size, float grid_y_size, float grid_z_size,
+                               int32_t num_x_voxels, int32_t num_y_voxels,
+                               int32_t num_z_voxels);
+/* Same, points already resident on the device (bench / device-resident pipelines). */
+int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                   const float* points_xyz_dev, int64_t num_points,
+                                   float max_range, const float* grid_pointcloud_transform,
+                                   float voxel_size, float inverse_voxel_size,
+                                   float grid_x_size, float grid_y_size, float grid_z_size,
+                                   int32_t num_x_voxels, int32_t num_y_voxels,
+                                   int32_t num_z_voxels);
+/* HIP_EXACT_FP64 mode: float64 DDA with the arithmetic of the reference's CPU voxelizer
+ * (CpuPointCloudVoxelizer::DoRaycastSinglePoint, S/cpu_pointcloud_voxelization.cpp:208-436);
+ * points and transform are doubles. */
+int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                               const double* points_xyz_host, int64_t num_points,
+                               double max_range, const double* grid_pointcloud_transform,
+                               double voxel_size, double inverse_voxel_size,
+                               double grid_x_size, double grid_y_size, double grid_z_size,
+                               int32_t num_x_voxels, int32_t num_y_voxels,
+                               int32_t num_z_voxels);
+
+/* DeviceVoxelizationHelperInterface::PrepareFilterGrid
+ * (I/device_voxelization_interface.hpp:160-161; S/cuda_voxelization_helpers.cu:701-708):
+ * device copy of the static environment's float occupancy. */
+int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells,
+                               const float* occupancy_host, vgt_hip_filter** out_filter);
+void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter);
+int64_t vgt_hip_filter_grid_num_cells(const vgt_hip_filter* filter);
+void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter);
+
+/* DeviceVoxelizationHelperInterface::FilterTrackingGrids
+ * (I/device_voxelization_interface.hpp:163-166; kernel S/cuda_voxelization_helpers.cu:358-426).
+ * ratio_in_double = 0: float ratio as the reference device kernels; 1: double ratio as
+ * PointCloudVoxelizationFilterOptions::CountsSeenAs (I/pointcloud_voxelization_interface.hpp:55-86). */
+int vgt_hip_filter_tracking_grids(vgt_hip_ctx* ctx, const vgt_hip_grids* grids,
+                                  float percent_seen_free, int32_t outlier_points_threshold,
+                                  int32_t num_cameras_seen_free, vgt_hip_filter* filter);
+int vgt_hip_filter_tracking_grids_f64(vgt_hip_ctx* ctx, const vgt_hip_grids* grids,
+                                      double percent_seen_free,
+                                      int32_t outlier_points_threshold,
+                                      int32_t num_cameras_seen_free, vgt_hip_filter* filter);
+
+/* DeviceVoxelizationHelperInterface::RetrieveTrackingGrid / RetrieveFilteredGrid
+ * (I/device_voxelization_interface.hpp:168-173; S/cuda_voxelization_helpers.cu:734-767):
+ * blocking copies of num_cells*8 / num_cells*4 bytes; all earlier work of the context
+ * has finished when they return. */
+int vgt_hip_retrieve_tracking_grid(vgt_hip_ctx* ctx, const vgt_hip_grids* grids,
+                                   size_t grid_index, void* host_out);
+int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filter,
+                                   void* host_out);
+
+/* ==========================  signed distance field  ========================== */
+
+/* OccupancyMap::ExtractSignedDistanceField<float>(params)
+ * (I/occupancy_map.hpp:174-210 -> I/signed_distance_field_generation.hpp:39-285 ->
+ *  S/signed_distance_field_generation.cpp:258-391).  occupancy_host / sdf_host are
+ * float[nx*ny*nz]; out_min / out_max receive what SignedDistanceField::Lock() caches
+ * (I/signed_distance_field.hpp:765-787) and may be NULL. */
+int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host,
+                                   int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                   int unknown_is_filled, int add_virtual_border,
+                                   float* sdf_host, float* out_min, float* out_max);
+/* Same for the map types whose predicate is not a pure occupancy threshold
+ * (I/occupancy_component_map.hpp:270-306, I/tagged_object_occupancy_map.hpp:199-247):
+ * the caller evaluates is_filled on the host into one byte per voxel. */
+int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, int64_t nx,
+                             int64_t ny, int64_t nz, double resolution,
+                             int add_virtual_border, float* sdf_host, float* out_min,
+                             float* out_max);
+
+/* Device-resident form (bench, device pipelines): input and output stay
+ * in HBM, the caller provides the scratch workspace.  minmax_dev, if non-NULL, receives
+ * {min, max} as two floats on the device after the call (stream-ordered). */
+size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
+int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
+                    int64_t nz, double resolution, int unknown_is_filled,
+                    int add_virtual_border, float* sdf_dev, void* workspace_dev,
+                    size_t workspace_bytes, float* minmax_dev);
+/* As vgt_hip_sdf_dev, bracketing each kernel with HIP events on the context's stream.
+ * kernel_ms[0..2] = Z-scan, Y-pass, X-pass(+finalize) durations of this call. Blocking. */
+int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx,
+                          int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
+                          int add_virtual_border, float* sdf_dev, void* workspace_dev,
+                          size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
+/* Selects the EDT line-pass implementation: 0 = default (fastest exact path),
+ * 1 = pruned brute force (simple reference kernel, any size). Testing knob. */
+int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGT_HIP_H_ */

@@ -1,0 +1,52 @@
+"""(not gpu) The C-ABI library loads and exports every symbol include/vgt_hip.h declares.
+No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from voxelized_geometry_tools_amd import capi
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vgt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vgt_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return capi.load()
+
+
+def test_header_and_binding_agree(lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    assert sorted(capi.SIGNATURES) == declared
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(raw, name), name
+
+
+def test_abi_version_and_workspace_size(lib):
+    assert lib.vgt_hip_abi_version() == 1
+    # int16 + int32 intermediates + a small min/max block, 256-byte aligned pieces
+    n = 64 * 64 * 64
+    assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256
+    assert capi.sdf_workspace_bytes((0, 4, 4)) == 0
+
+
+def test_argument_errors_without_device(lib):
+    """Null / invalid arguments are rejected before any HIP call."""
+    assert lib.vgt_hip_create(0, -1, None) == 1
+    assert b"null" in lib.vgt_hip_last_error()
+    assert lib.vgt_hip_device_count(None) == 1
+    assert lib.vgt_hip_tracking_grids_create(None, 10, 1, None) == 1

@@ -1,0 +1,147 @@
+"""(gpu) SDF parity: the HIP path through the C ABI vs the CPU oracle, the reference's
+known answers and the committed independent-EDT fixtures.  Bar: bit-exact float32."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, kat_occupancy
+from voxelized_geometry_tools_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+VARIANTS = [0, 1]  # default (fast) path and the pruned-search reference kernels
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_known_answers(ctx, sdf_kats, variant):
+    """test/sdf_generation_test.cpp extrema + exact cases through the HIP path."""
+    ctx.set_edt_variant(variant)
+    tol = sdf_kats["extrema_tolerance"]
+    for case in sdf_kats["extrema_cases"]:
+        occ = kat_occupancy(case)
+        sdf, lo, hi = ctx.sdf_from_occupancy(occ, case["resolution"])
+        exp_lo, exp_hi = float(case["min"]), float(case["max"])
+        assert lo == exp_lo or abs(lo - exp_lo) <= tol, case["name"]
+        assert hi == exp_hi or abs(hi - exp_hi) <= tol, case["name"]
+        assert np.all(sdf[occ >= 0.5] < 0) and np.all(sdf[occ < 0.5] > 0), case["name"]
+    for case in sdf_kats["exact_cases"]:
+        occ = kat_occupancy(case)
+        sdf, _, _ = ctx.sdf_from_occupancy(occ, case["resolution"])
+        sq = np.array(case["expected_sq"], dtype=np.float32)
+        expected = (np.sign(sq) * np.sqrt(np.abs(sq))).astype(np.float32).reshape(case["shape"])
+        assert bits_equal(sdf, expected), case["name"]
+    ctx.set_edt_variant(0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_independent_edt_fixtures(ctx, sdf_scipy_cases, variant):
+    ctx.set_edt_variant(variant)
+    for name, c in sdf_scipy_cases.items():
+        sdf, lo, hi = ctx.sdf_from_occupancy(c["occ"], float(c["res"]), bool(c["uif"]), False)
+        assert bits_equal(sdf, c["sdf"]), name
+        assert lo == c["sdf"].min() and hi == c["sdf"].max(), name
+        vb, lo, hi = ctx.sdf_from_occupancy(c["occ"], float(c["res"]), bool(c["uif"]), True)
+        assert bits_equal(vb, c["sdf_vb"]), name + " (virtual border)"
+        assert lo == c["sdf_vb"].min() and hi == c["sdf_vb"].max(), name
+    ctx.set_edt_variant(0)
+
+
+SHAPES = [(1, 1, 1), (1, 1, 2), (2, 1, 1), (1, 70, 1), (3, 5, 64), (3, 5, 65), (7, 9, 130),
+          (40, 33, 17), (64, 64, 64), (31, 130, 67), (130, 31, 67), (96, 80, 200)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_random_grids_vs_oracle(ctx, oracle, shape):
+    rng = np.random.default_rng(abs(hash(shape)) % (2 ** 31))
+    for p in (0.002, 0.05, 0.5, 0.97):
+        occ = (rng.random(shape) < p).astype(np.float32)
+        occ[rng.random(shape) < 0.02] = 0.5
+        for uif in (True, False):
+            got, lo, hi = ctx.sdf_from_occupancy(occ, 0.013, uif, False)
+            want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.013, uif, False)
+            assert bits_equal(got, want), (shape, p, uif)
+            assert (lo, hi) == (wlo, whi)
+
+
+def test_degenerate_grids(ctx, oracle):
+    for kind in ("empty", "full", "single"):
+        occ = synthetic.occupancy_degenerate((48, 20, 70), kind)
+        for vb in (False, True):
+            got, lo, hi = ctx.sdf_from_occupancy(occ, 0.01, True, vb)
+            want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.01, True, vb)
+            assert bits_equal(got, want), (kind, vb)
+            assert (lo, hi) == (wlo, whi)
+    got, lo, hi = ctx.sdf_from_occupancy(np.zeros((5, 6, 7), np.float32), 0.25)
+    assert np.all(np.isposinf(got)) and np.isposinf(lo) and np.isposinf(hi)
+    got, lo, hi = ctx.sdf_from_occupancy(np.ones((5, 6, 7), np.float32), 0.25)
+    assert np.all(np.isneginf(got)) and np.isneginf(lo) and np.isneginf(hi)
+
+
+def test_variants_agree_on_synthetic_distributions(ctx, oracle):
+    shape = (72, 96, 160)
+    for dist in ("spheres", "salt", "unknown_mix"):
+        occ = synthetic.make_occupancy(shape, dist, seed=42)
+        want, _, _ = oracle.sdf_from_occupancy(occ, 0.01)
+        for variant in VARIANTS:
+            ctx.set_edt_variant(variant)
+            got, _, _ = ctx.sdf_from_occupancy(occ, 0.01)
+            assert bits_equal(got, want), (dist, variant)
+    ctx.set_edt_variant(0)
+
+
+def test_mask_entry_point(ctx, oracle):
+    """vgt_hip_sdf_from_mask_u8: the path for map types whose predicate is evaluated on the host."""
+    rng = np.random.default_rng(11)
+    mask = (rng.random((21, 34, 55)) < 0.1).astype(np.uint8)
+    got, lo, hi = ctx.sdf_from_mask(mask, 0.05)
+    want = oracle.sdf_from_mask(mask, 0.05)
+    assert bits_equal(got, want)
+    assert lo == want.min() and hi == want.max()
+
+
+def test_argument_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.sdf_from_occupancy(np.zeros((4, 4, 4), np.float32), 0.0)      # non-positive resolution
+    with pytest.raises(ValueError):
+        ctx.sdf_from_occupancy(np.zeros((4, 4, 4), np.float32), float("nan"))
+    with pytest.raises(ValueError):
+        ctx.sdf_from_occupancy(np.zeros((0, 4, 4), np.float32), 0.1)      # empty grid
+
+
+def test_full_size_properties(ctx):
+    """512^3 (BASELINE config C2) through the host entry point, checked by size-independent
+    properties: sign follows occupancy, |sdf| >= res, a sphere's interior/exterior distances
+    are analytic, and translating the scene by whole voxels translates the field."""
+    n = 512
+    res = 0.01
+    occ = np.zeros((n, n, n), dtype=np.float32)
+    c, r = np.array([200, 260, 310]), 57.0
+    ax = np.arange(n)
+    d2 = ((ax - c[0]) ** 2)[:, None, None] + ((ax - c[1]) ** 2)[None, :, None] + ((ax - c[2]) ** 2)[None, None, :]
+    occ[d2 <= r * r] = 1.0
+    sdf, lo, hi = ctx.sdf_from_occupancy(occ, res)
+    assert np.all(sdf[occ > 0.5] < 0) and np.all(sdf[occ <= 0.5] > 0)
+    assert np.min(np.abs(sdf)) >= np.float32(res)
+    assert lo == sdf.min() and hi == sdf.max()
+    # exact EDT of a digital ball is within one voxel diagonal of the analytic distance
+    analytic = (np.sqrt(d2) - r) * res
+    assert np.max(np.abs(sdf - analytic)) <= 1.8 * res
+    # translation by (8, -16, 24) voxels: interior region away from the borders must match
+    occ2 = np.roll(occ, (8, -16, 24), axis=(0, 1, 2))
+    sdf2, _, _ = ctx.sdf_from_occupancy(occ2, res)
+    core = (slice(120, 300), slice(180, 340), slice(230, 390))
+    moved = np.roll(sdf2, (-8, 16, -24), axis=(0, 1, 2))
+    assert bits_equal(sdf[core], moved[core])

@@ -1,0 +1,186 @@
+"""(gpu) Raycast voxelizer parity through the C ABI: tracking counts bit-exact against the
+oracle of the same precision, the reference test scene's predicates, and the edge cases the
+reference exercises (empty cloud list, empty cloud, NaN points, origin outside the grid)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import check_empty_voxelization, check_voxelization, scene_clouds
+from voxelized_geometry_tools_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _scene_grid(scene):
+    occ = scene["static_occupancy"]
+    vs = float(scene["voxel_size"])
+    counts = occ.shape
+    return occ, vs, counts
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_reference_scene(ctx, oracle, voxelization_scene, precision):
+    """test/pointcloud_voxelization_test.cpp: three clouds (third empty), filter (1.0, 1, 1)."""
+    occ, vs, counts = _scene_grid(voxelization_scene)
+    grids = ctx.tracking_grids(occ.size, 3)
+    want = []
+    if precision == "f32":
+        vs32, ivs32 = np.float32(vs), np.float32(1.0 / vs)
+        sizes = [np.float32(c * vs) for c in counts]
+        for i, (pts, xf) in enumerate(scene_clouds(voxelization_scene, np.float32)):
+            grids.raycast_f32(i, pts, np.float32(np.inf), xf, vs32, ivs32, sizes, counts)
+            want.append(oracle.raycast_f32(pts, np.float32(np.inf), xf, vs32, ivs32, sizes, counts))
+    else:
+        sizes = [c * vs for c in counts]
+        for i, (pts, xf) in enumerate(scene_clouds(voxelization_scene, np.float64)):
+            grids.raycast_f64(i, pts, np.inf, xf, vs, 1.0 / vs, sizes, counts)
+            want.append(oracle.raycast_f64(pts, np.inf, xf, vs, 1.0 / vs, sizes, counts))
+    for i in range(2):
+        assert np.array_equal(grids.retrieve(i, counts), want[i]), "tracking counts cloud %d" % i
+    assert not grids.retrieve(2).any()
+    fg = ctx.filter_grid(occ)
+    fg.filter(grids, 1.0, 1, 1, ratio_in_double=(precision == "f64"))
+    out = fg.retrieve()
+    check_voxelization(out)
+    want.append(np.zeros_like(want[0]))
+    assert np.array_equal(out, oracle.filter_grids(np.stack(want), occ, 1.0, 1, 1, precision == "f64"))
+
+
+def test_empty_voxelization(ctx, voxelization_scene):
+    """No clouds: one zeroed grid is still filtered (device_pointcloud_voxelization.cpp:79-80)."""
+    occ, _, _ = _scene_grid(voxelization_scene)
+    grids = ctx.tracking_grids(occ.size, 1)
+    fg = ctx.filter_grid(occ)
+    fg.filter(grids, 1.0, 1, 1)
+    check_empty_voxelization(fg.retrieve())
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_raycasting_invariants(ctx, raycast_rays, precision):
+    """test/voxel_raycasting_test.cpp: per ray, every count is 0/1 and never free and filled."""
+    counts = (40, 40, 40)
+    vs = 0.125
+    grids = ctx.tracking_grids(40 ** 3, 1)
+    for ray in raycast_rays[:250]:
+        grids.clear()
+        origin, point = ray[:3], ray[3:]
+        xf = synthetic.translation_xform(*origin)
+        local = (point - origin).reshape(1, 3)
+        if precision == "f32":
+            grids.raycast_f32(0, local, 10.0, xf, vs, 1.0 / vs, [5.0] * 3, counts)
+        else:
+            grids.raycast_f64(0, local, 10.0, xf, vs, 1.0 / vs, [5.0] * 3, counts)
+        g = grids.retrieve(0, counts)
+        assert g.min() >= 0 and g.max() <= 1
+        assert not np.any((g[..., 0] > 0) & (g[..., 1] > 0))
+
+
+@pytest.mark.parametrize("sensor", [(2.56, 2.56, 2.56), (-1.0, 2.56, 2.56)])
+def test_synthetic_cloud_counts_bit_exact(ctx, oracle, sensor):
+    """BASELINE config C3 shape at reduced size: 128^3 grid, 200k points, 1 % NaN, clipped and
+    unclipped rays, sensor inside / outside the grid (slab-entry branch)."""
+    counts = (128, 128, 128)
+    vs = np.float32(0.04)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(200_000, seed=42)
+    xf = synthetic.translation_xform(*sensor).astype(np.float32)
+    grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+    grids.raycast_f32(0, pts, 3.0, xf, vs, ivs, sizes, counts)
+    got = grids.retrieve(0, counts)
+    want = oracle.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+    assert got.sum() == want.sum() and got.sum() > 0
+    assert np.array_equal(got, want)
+
+
+def test_concurrent_raycasts_from_host_threads(ctx, oracle):
+    """RaycastPoints is called concurrently on one helper with distinct grid indices
+    (device_pointcloud_voxelization.cpp:147-149)."""
+    counts = (64, 64, 64)
+    vs = np.float32(0.05)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    clouds = [synthetic.raycast_cloud(30_000, seed=100 + i) * np.float32(0.5) for i in range(6)]
+    xfs = [synthetic.translation_xform(1.0 + 0.2 * i, 1.5, 1.6).astype(np.float32) for i in range(6)]
+    grids = ctx.tracking_grids(64 ** 3, 6)
+    errors = []
+
+    def work(i):
+        try:
+            grids.raycast_f32(i, clouds[i], 1.5, xfs[i], vs, ivs, sizes, counts)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for i in range(6):
+        want = oracle.raycast_f32(clouds[i], 1.5, xfs[i], vs, ivs, sizes, counts)
+        assert np.array_equal(grids.retrieve(i, counts), want), i
+
+
+def _hip_memcpy_htod(dev_ptr, array):
+    """Test helper: writes a host array into library-owned device memory via the HIP runtime."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    a = np.ascontiguousarray(array)
+    rc = hip.hipMemcpy(dev_ptr, a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 1)
+    assert rc == 0, "hipMemcpy failed: %d" % rc
+
+
+def test_filter_options(ctx, oracle):
+    """CountsSeenAs / FilterGrids over random counts and every option combination."""
+    rng = np.random.default_rng(5)
+    shape = (16, 16, 16)
+    cells = 4096
+    tracking = np.zeros((3,) + shape + (2,), dtype=np.int32)
+    tracking[..., 0] = rng.integers(0, 6, (3,) + shape) * (rng.random((3,) + shape) < 0.5)
+    tracking[..., 1] = rng.integers(0, 4, (3,) + shape) * (rng.random((3,) + shape) < 0.4)
+    occ = rng.choice(np.array([0.0, 0.5, 1.0], dtype=np.float32), size=shape)
+    grids = ctx.tracking_grids(cells, 3)
+    ctx.synchronize()
+    for g in range(3):
+        assert grids.offset(g) == g * cells * 2
+        _hip_memcpy_htod(grids.dev_ptr(g), tracking[g])
+    for g in range(3):
+        assert np.array_equal(grids.retrieve(g, shape), tracking[g])
+    for dbl in (False, True):
+        for pct, outlier, ncam in [(1.0, 1, 1), (0.6, 2, 1), (1.0, 1, 2), (0.3, 3, 3), (0.75, 1, 1)]:
+            fg = ctx.filter_grid(occ)
+            fg.filter(grids, pct, outlier, ncam, ratio_in_double=dbl)
+            want = oracle.filter_grids(tracking, occ, pct, outlier, ncam, dbl)
+            assert np.array_equal(fg.retrieve(), want), (pct, outlier, ncam, dbl)
+
+
+def test_handle_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.tracking_grids(0, 1)                       # zero-element buffers are an error
+    with pytest.raises(ValueError):
+        ctx.tracking_grids(10, 0)
+    grids = ctx.tracking_grids(8, 1)
+    with pytest.raises(ValueError):                    # grid index out of range
+        grids.raycast_f32(3, np.zeros((1, 3)), 1.0, np.eye(4).reshape(16), 1.0, 1.0, [2, 2, 2], (2, 2, 2))
+    with pytest.raises(ValueError):                    # voxel counts do not match the handle
+        grids.raycast_f32(0, np.zeros((1, 3)), 1.0, np.eye(4).reshape(16), 1.0, 1.0, [3, 3, 3], (3, 3, 3))
+    grids.raycast_f32(0, np.zeros((0, 3)), 1.0, np.eye(4).reshape(16), 1.0, 1.0, [2, 2, 2], (2, 2, 2))
+    assert not grids.retrieve(0).any()                 # empty cloud is a no-op
+    with pytest.raises(capi.VgtHipUnavailable):
+        capi.Context(9999)                             # device index out of range

@@ -1,0 +1,326 @@
+"""ctypes binding of libvgt_hip.so (the C ABI declared in include/vgt_hip.h).
+
+This is test / bench plumbing: the product is the shared library and the C++ glue in
+include/vgt_hip/.  There is no CPU fallback here -- if the library is missing, or no HIP
+device is usable, the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvgt_hip.so")
+_LIB = None
+
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_f32 = ctypes.c_float
+_f64 = ctypes.c_double
+_p = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/vgt_hip.h one to one.
+SIGNATURES = {
+    "vgt_hip_abi_version": (_int, []),
+    "vgt_hip_last_error": (ctypes.c_char_p, []),
+    "vgt_hip_device_count": (_int, [ctypes.POINTER(_int)]),
+    "vgt_hip_device_name": (_int, [_int, ctypes.c_char_p, _sz]),
+    "vgt_hip_create": (_int, [_int, _int, ctypes.POINTER(_p)]),
+    "vgt_hip_destroy": (None, [_p]),
+    "vgt_hip_set_stream": (_int, [_p, _p]),
+    "vgt_hip_synchronize": (_int, [_p]),
+    "vgt_hip_device_of": (_int, [_p]),
+    "vgt_hip_tracking_grids_create": (_int, [_p, _i64, _i32, ctypes.POINTER(_p)]),
+    "vgt_hip_tracking_grids_destroy": (None, [_p]),
+    "vgt_hip_tracking_grids_num_cells": (_i64, [_p]),
+    "vgt_hip_tracking_grids_num_grids": (_i32, [_p]),
+    "vgt_hip_tracking_grids_offset": (_i64, [_p, _sz]),
+    "vgt_hip_tracking_grids_dev_ptr": (_p, [_p, _sz]),
+    "vgt_hip_tracking_grids_clear": (_int, [_p, _p]),
+    "vgt_hip_raycast_points_f32": (_int, [_p, _p, _sz, _p, _i64, _f32, _p, _f32, _f32, _f32, _f32,
+                                          _f32, _i32, _i32, _i32]),
+    "vgt_hip_raycast_points_f32_dev": (_int, [_p, _p, _sz, _p, _i64, _f32, _p, _f32, _f32, _f32,
+                                              _f32, _f32, _i32, _i32, _i32]),
+    "vgt_hip_raycast_points_f64": (_int, [_p, _p, _sz, _p, _i64, _f64, _p, _f64, _f64, _f64, _f64,
+                                          _f64, _i32, _i32, _i32]),
+    "vgt_hip_filter_grid_create": (_int, [_p, _i64, _p, ctypes.POINTER(_p)]),
+    "vgt_hip_filter_grid_destroy": (None, [_p]),
+    "vgt_hip_filter_grid_num_cells": (_i64, [_p]),
+    "vgt_hip_filter_grid_dev_ptr": (_p, [_p]),
+    "vgt_hip_filter_tracking_grids": (_int, [_p, _p, _f32, _i32, _i32, _p]),
+    "vgt_hip_filter_tracking_grids_f64": (_int, [_p, _p, _f64, _i32, _i32, _p]),
+    "vgt_hip_retrieve_tracking_grid": (_int, [_p, _p, _sz, _p]),
+    "vgt_hip_retrieve_filtered_grid": (_int, [_p, _p, _p]),
+    "vgt_hip_sdf_from_occupancy_f32": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
+    "vgt_hip_sdf_from_mask_u8": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _p, _p, _p]),
+    "vgt_hip_sdf_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
+    "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
+    "vgt_hip_set_edt_variant": (_int, [_p, _int]),
+}
+
+
+class VgtHipError(RuntimeError):
+    """HIP / runtime failure reported by libvgt_hip (std::runtime_error in the C++ glue)."""
+
+
+class VgtHipUnavailable(VgtHipError):
+    """No usable device (helper->IsAvailable() == false in the C++ glue)."""
+
+
+def load():
+    """Loads libvgt_hip.so once.  Raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise VgtHipError(
+            "libvgt_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C voxelized_geometry_tools_amd/csrc`" % LIB_PATH)
+    try:
+        # One HIP runtime per process: if torch is around, let it load its bundled
+        # libamdhip64 (same SONAME) first so the dynamic linker reuses it for us.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def last_error():
+    return load().vgt_hip_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == 1:
+        raise ValueError(msg)
+    if rc == 3:
+        raise VgtHipUnavailable(msg)
+    raise VgtHipError(msg)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(a))
+
+
+def device_count():
+    n = _int(0)
+    check(load().vgt_hip_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_name(device):
+    buf = ctypes.create_string_buffer(256)
+    check(load().vgt_hip_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+class Context:
+    """One device + one stream (vgt_hip_ctx)."""
+
+    def __init__(self, device=0, threads_per_block=-1):
+        self._lib = load()
+        h = _p()
+        check(self._lib.vgt_hip_create(device, threads_per_block, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.vgt_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.vgt_hip_set_stream(self.handle, _ptr(stream_ptr)))
+
+    def synchronize(self):
+        check(self._lib.vgt_hip_synchronize(self.handle))
+
+    def set_edt_variant(self, variant):
+        check(self._lib.vgt_hip_set_edt_variant(self.handle, int(variant)))
+
+    # ---- SDF ----
+    def sdf_from_occupancy(self, occupancy, resolution, unknown_is_filled=True,
+                           add_virtual_border=False):
+        occ = np.ascontiguousarray(occupancy, dtype=np.float32)
+        if occ.ndim != 3:
+            raise ValueError("occupancy must be (nx, ny, nz)")
+        nx, ny, nz = occ.shape
+        out = np.empty(occ.shape, dtype=np.float32)
+        lo, hi = _f32(), _f32()
+        check(self._lib.vgt_hip_sdf_from_occupancy_f32(
+            self.handle, _ptr(occ), nx, ny, nz, float(resolution), int(bool(unknown_is_filled)),
+            int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo), ctypes.byref(hi)))
+        return out, lo.value, hi.value
+
+    def sdf_from_mask(self, mask, resolution, add_virtual_border=False):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        nx, ny, nz = m.shape
+        out = np.empty(m.shape, dtype=np.float32)
+        lo, hi = _f32(), _f32()
+        check(self._lib.vgt_hip_sdf_from_mask_u8(
+            self.handle, _ptr(m), nx, ny, nz, float(resolution), int(bool(add_virtual_border)),
+            _ptr(out), ctypes.byref(lo), ctypes.byref(hi)))
+        return out, lo.value, hi.value
+
+    def sdf_dev(self, occ_ptr, shape, resolution, sdf_ptr, ws_ptr, ws_bytes, minmax_ptr=None,
+                unknown_is_filled=True, add_virtual_border=False, kernel_ms=None):
+        nx, ny, nz = shape
+        if kernel_ms is None:
+            check(self._lib.vgt_hip_sdf_dev(
+                self.handle, _ptr(occ_ptr), nx, ny, nz, float(resolution),
+                int(bool(unknown_is_filled)), int(bool(add_virtual_border)), _ptr(sdf_ptr),
+                _ptr(ws_ptr), ws_bytes, _ptr(minmax_ptr)))
+        else:
+            check(self._lib.vgt_hip_sdf_dev_timed(
+                self.handle, _ptr(occ_ptr), nx, ny, nz, float(resolution),
+                int(bool(unknown_is_filled)), int(bool(add_virtual_border)), _ptr(sdf_ptr),
+                _ptr(ws_ptr), ws_bytes, _ptr(minmax_ptr), _ptr(kernel_ms)))
+
+    # ---- voxelizer ----
+    def tracking_grids(self, num_cells, num_grids):
+        return TrackingGrids(self, num_cells, num_grids)
+
+    def filter_grid(self, occupancy):
+        return FilterGrid(self, occupancy)
+
+
+def sdf_workspace_bytes(shape):
+    return int(load().vgt_hip_sdf_workspace_bytes(*[int(s) for s in shape]))
+
+
+class TrackingGrids:
+    def __init__(self, ctx, num_cells, num_grids):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        h = _p()
+        check(self._lib.vgt_hip_tracking_grids_create(ctx.handle, int(num_cells), int(num_grids),
+                                                      ctypes.byref(h)))
+        self.handle = h
+        self.num_cells = int(num_cells)
+        self.num_grids = int(num_grids)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.vgt_hip_tracking_grids_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def offset(self, index):
+        return int(self._lib.vgt_hip_tracking_grids_offset(self.handle, index))
+
+    def dev_ptr(self, index):
+        return self._lib.vgt_hip_tracking_grids_dev_ptr(self.handle, index)
+
+    def clear(self):
+        check(self._lib.vgt_hip_tracking_grids_clear(self.ctx.handle, self.handle))
+
+    def raycast_f32(self, index, points, max_range, xform, voxel_size, inverse_voxel_size,
+                    grid_sizes, counts):
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1)
+        T = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+        check(self._lib.vgt_hip_raycast_points_f32(
+            self.ctx.handle, self.handle, index, _ptr(pts) if pts.size else None, pts.size // 3,
+            float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
+            float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
+            int(counts[0]), int(counts[1]), int(counts[2])))
+
+    def raycast_f32_dev(self, index, points_ptr, num_points, max_range, xform, voxel_size,
+                        inverse_voxel_size, grid_sizes, counts):
+        T = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+        check(self._lib.vgt_hip_raycast_points_f32_dev(
+            self.ctx.handle, self.handle, index, _ptr(points_ptr), int(num_points),
+            float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
+            float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
+            int(counts[0]), int(counts[1]), int(counts[2])))
+
+    def raycast_f64(self, index, points, max_range, xform, voxel_size, inverse_voxel_size,
+                    grid_sizes, counts):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1)
+        T = np.ascontiguousarray(xform, dtype=np.float64).reshape(16)
+        check(self._lib.vgt_hip_raycast_points_f64(
+            self.ctx.handle, self.handle, index, _ptr(pts) if pts.size else None, pts.size // 3,
+            float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
+            float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
+            int(counts[0]), int(counts[1]), int(counts[2])))
+
+    def retrieve(self, index, counts=None):
+        out = np.empty((self.num_cells, 2), dtype=np.int32)
+        check(self._lib.vgt_hip_retrieve_tracking_grid(self.ctx.handle, self.handle, index,
+                                                       _ptr(out)))
+        if counts is not None:
+            out = out.reshape(tuple(counts) + (2,))
+        return out
+
+
+class FilterGrid:
+    def __init__(self, ctx, occupancy):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        occ = np.ascontiguousarray(occupancy, dtype=np.float32)
+        self.shape = occ.shape
+        h = _p()
+        check(self._lib.vgt_hip_filter_grid_create(ctx.handle, occ.size,
+                                                   _ptr(occ) if occ.size else None,
+                                                   ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.vgt_hip_filter_grid_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dev_ptr(self):
+        return self._lib.vgt_hip_filter_grid_dev_ptr(self.handle)
+
+    def filter(self, grids, percent_seen_free=1.0, outlier_points_threshold=1,
+               num_cameras_seen_free=1, ratio_in_double=False):
+        if ratio_in_double:
+            check(self._lib.vgt_hip_filter_tracking_grids_f64(
+                self.ctx.handle, grids.handle, float(percent_seen_free),
+                int(outlier_points_threshold), int(num_cameras_seen_free), self.handle))
+        else:
+            check(self._lib.vgt_hip_filter_tracking_grids(
+                self.ctx.handle, grids.handle, float(percent_seen_free),
+                int(outlier_points_threshold), int(num_cameras_seen_free), self.handle))
+
+    def retrieve(self):
+        out = np.empty(self.shape, dtype=np.float32)
+        check(self._lib.vgt_hip_retrieve_filtered_grid(self.ctx.handle, self.handle, _ptr(out)))
+        return out

@@ -1,0 +1,383 @@
+// Exact signed Euclidean distance transform for gfx950 (MI355X): kernels and launchers.
+//
+// What is computed (reference: OccupancyMap::ExtractSignedDistanceField<float>,
+// include/voxelized_geometry_tools/occupancy_map.hpp:174-210 ->
+// signed_distance_field_generation.hpp:39-113 -> signed_distance_field_generation.cpp:258-391):
+// for every voxel the exact squared Euclidean distance (integer, voxel units) to the nearest
+// voxel of the OTHER class (filled vs free), turned into
+//     sdf = float( sqrt(double(d2)) * resolution ), negated on filled voxels,
+// +-inf when the other class is absent.  The reference runs two separate double-precision
+// Felzenszwalb-Huttenlocher transforms (one per class) in X,Y,Z order; the result is
+// order-independent and integral, so here both classes travel through three passes as ONE
+// signed integer field (a voxel only ever needs the distance to the other class, and a voxel of
+// the other class is a zero-valued site):
+//     pass 1  Z (contiguous axis): nearest-site scan on the binarised input, wave ballots
+//     pass 2  Y: lower envelope of parabolas over the squared pass-1 distances
+//     pass 3  X: same, fused with sqrt / resolution / sign / virtual border / min-max.
+//
+// This file currently holds the Z scan and the simple pruned-search line pass
+// (EdtVariant::kBruteForce, exact for any size); the LDS-tiled envelope pass lives in
+// edt_hull_kernels.hip.
+#include "vgt_internal.hpp"
+
+namespace vgt
+{
+namespace
+{
+constexpr int kWave = 64;
+constexpr int kScanBlock = 256;
+constexpr int kScanWaves = kScanBlock / kWave;
+constexpr int kMaxChunks = static_cast<int>(kMaxExtent / kWave);
+
+// is_filled predicate of OccupancyMap (occupancy_map.hpp:181-205).
+__device__ __forceinline__ bool IsFilled(float occupancy, int unknown_is_filled)
+{
+  return (occupancy > 0.5f) || (unknown_is_filled && (occupancy == 0.5f));
+}
+__device__ __forceinline__ bool IsFilled(uint8_t mask, int) { return mask != 0; }
+
+// ---------------------------------------------------------------------------------------------
+// Pass 1: one wave per Z line.  Each 64-voxel chunk becomes one ballot mask; a voxel's distance
+// to the nearest voxel of the other class is a clz/ffs on that mask, falling back to the nearest
+// such voxel in the chunks before / after (carried as scalars).  Input is read exactly once.
+// ---------------------------------------------------------------------------------------------
+template <typename InT>
+__global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict__ in,
+                                                         int16_t* __restrict__ out,
+                                                         int64_t num_lines, int nz,
+                                                         int unknown_is_filled)
+{
+  // [wave][chunk]: ballot of "filled", then first position >= chunk end holding a filled /
+  // free voxel (or -1).  Written and read by the same wave only.
+  __shared__ uint64_t s_filled[kScanWaves][kMaxChunks];
+  __shared__ int32_t s_next_filled[kScanWaves][kMaxChunks];
+  __shared__ int32_t s_next_free[kScanWaves][kMaxChunks];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int nchunks = (nz + kWave - 1) / kWave;
+  volatile uint64_t* filled = s_filled[wave];
+  volatile int32_t* next_filled = s_next_filled[wave];
+  volatile int32_t* next_free = s_next_free[wave];
+
+  for (int64_t line = static_cast<int64_t>(blockIdx.x) * kScanWaves + wave; line < num_lines;
+       line += static_cast<int64_t>(gridDim.x) * kScanWaves)
+  {
+    const InT* src = in + line * nz;
+    int16_t* dst = out + line * nz;
+
+    for (int c = 0; c < nchunks; c++)
+    {
+      const int z = c * kWave + lane;
+      const bool f = (z < nz) && IsFilled(src[z], unknown_is_filled);
+      const uint64_t m = __ballot(f);
+      if (lane == 0) filled[c] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // Backward sweep (uniform per wave): nearest filled / free voxel after each chunk.
+    if (lane == 0)
+    {
+      int32_t nf = -1, ne = -1;
+      for (int c = nchunks - 1; c >= 0; c--)
+      {
+        next_filled[c] = nf;
+        next_free[c] = ne;
+        const int rem = nz - c * kWave;
+        const uint64_t valid = (rem >= kWave) ? ~0ull : ((1ull << rem) - 1ull);
+        const uint64_t F = filled[c];
+        const uint64_t E = ~F & valid;
+        if (F) nf = c * kWave + (__ffsll(static_cast<long long>(F)) - 1);
+        if (E) ne = c * kWave + (__ffsll(static_cast<long long>(E)) - 1);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // Forward sweep: per-lane distances.
+    int32_t prev_filled = -1, prev_free = -1;  // last filled / free position before this chunk
+    for (int c = 0; c < nchunks; c++)
+    {
+      const int rem = nz - c * kWave;
+      const uint64_t valid = (rem >= kWave) ? ~0ull : ((1ull << rem) - 1ull);
+      const uint64_t F = filled[c];
+      const uint64_t E = ~F & valid;
+      const int z = c * kWave + lane;
+      if (z < nz)
+      {
+        const bool is_filled = (F >> lane) & 1ull;
+        const uint64_t other = is_filled ? E : F;
+        const int32_t prev_other = is_filled ? prev_free : prev_filled;
+        const int32_t next_other = is_filled ? next_free[c] : next_filled[c];
+        const uint64_t below = other & ((1ull << lane) - 1ull);
+        const uint64_t above = (lane == kWave - 1) ? 0ull : (other >> (lane + 1));
+        int32_t d_below = kInf16, d_above = kInf16;
+        if (below)
+          d_below = lane - (63 - __clzll(static_cast<long long>(below)));
+        else if (prev_other >= 0)
+          d_below = z - prev_other;
+        if (above)
+          d_above = __ffsll(static_cast<long long>(above));
+        else if (next_other >= 0)
+          d_above = next_other - z;
+        const int32_t d = min(d_below, d_above);
+        dst[z] = static_cast<int16_t>(is_filled ? -d : d);
+      }
+      if (F) prev_filled = c * kWave + (63 - __clzll(static_cast<long long>(F)));
+      if (E) prev_free = c * kWave + (63 - __clzll(static_cast<long long>(E)));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoding of the intermediate encodings into (class, squared distance so far).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void Decode(int16_t v, bool& negative, int32_t& f)
+{
+  negative = v < 0;
+  const int32_t a = negative ? -static_cast<int32_t>(v) : static_cast<int32_t>(v);
+  f = (a == kInf16) ? kInf32 : a * a;
+}
+__device__ __forceinline__ void Decode(int32_t v, bool& negative, int32_t& f)
+{
+  negative = v < 0;
+  f = negative ? -v : v;
+}
+
+// Exact 1-D lower-envelope value at position q by outward search with pruning: a site at
+// offset k can only improve the answer while k*k < best, and the first voxel of the other
+// class (a zero-valued site) ends the search on both sides.  O(sqrt(answer)) per voxel.
+template <typename InT>
+__device__ __forceinline__ int32_t LineSearch(const InT* __restrict__ centre, int64_t stride,
+                                              int q, int n, bool negative, int32_t own)
+{
+  int32_t best = own;
+  for (int k = 1; k < n; k++)
+  {
+    const int32_t kk = k * k;
+    if (kk >= best) break;
+    const bool has_lo = (q - k) >= 0;
+    const bool has_hi = (q + k) < n;
+    if (!has_lo && !has_hi) break;
+    if (has_lo)
+    {
+      bool neg;
+      int32_t f;
+      Decode(centre[-static_cast<int64_t>(k) * stride], neg, f);
+      const int32_t cand = (neg != negative) ? kk : ((f == kInf32) ? kInf32 : kk + f);
+      best = min(best, cand);
+    }
+    if (has_hi)
+    {
+      bool neg;
+      int32_t f;
+      Decode(centre[static_cast<int64_t>(k) * stride], neg, f);
+      const int32_t cand = (neg != negative) ? kk : ((f == kInf32) ? kInf32 : kk + f);
+      best = min(best, cand);
+    }
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void PassYBruteKernel(const int16_t* __restrict__ in,
+                                                       int32_t* __restrict__ out, int64_t total,
+                                                       int ny, int nz)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int y = static_cast<int>((i / nz) % ny);
+    bool negative;
+    int32_t own;
+    Decode(in[i], negative, own);
+    const int32_t best = LineSearch(in + i, static_cast<int64_t>(nz), y, ny, negative, own);
+    out[i] = negative ? -best : best;
+  }
+}
+
+// Order-preserving float <-> uint32 map so min / max can use integer atomics.
+__device__ __forceinline__ uint32_t EncodeOrdered(float v)
+{
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float DecodeOrdered(uint32_t e)
+{
+  const uint32_t b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+  return __uint_as_float(b);
+}
+
+}  // namespace
+
+// Final conversion shared by every X-pass implementation: squared voxel distance -> float SDF.
+// Matches signed_distance_field_generation.hpp:98-105 evaluated in double, and the
+// virtual-border branch (:134-284) through its closed form min(d2, b^2) with b the distance to
+// the nearest virtual border cell.
+__device__ __forceinline__ float FinalizeSdf(int32_t d2, bool negative, int x, int y, int z,
+                                             int nx, int ny, int nz, double resolution,
+                                             int add_virtual_border)
+{
+  if (add_virtual_border)
+  {
+    int32_t b = kInf32;
+    if (nx > 1) b = min(b, min(x + 1, nx - x));
+    if (ny > 1) b = min(b, min(y + 1, ny - y));
+    if (nz > 1) b = min(b, min(z + 1, nz - z));
+    if (b != kInf32) d2 = min(d2, b * b);
+  }
+  float dist;
+  if (d2 == kInf32)
+    dist = __uint_as_float(0x7f800000u);
+  else
+    dist = static_cast<float>(sqrt(static_cast<double>(d2)) * resolution);
+  return negative ? -dist : dist;
+}
+
+namespace
+{
+// Wave + block reduction of the ordered encodings, one atomic pair per block.
+__device__ __forceinline__ void BlockMinMax(uint32_t lo, uint32_t hi, uint32_t* minmax_enc)
+{
+  __shared__ uint32_t s_lo[16], s_hi[16];
+  for (int off = kWave / 2; off > 0; off >>= 1)
+  {
+    lo = min(lo, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), off)));
+    hi = max(hi, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), off)));
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  if (lane == 0)
+  {
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const int nwaves = (blockDim.x + kWave - 1) / kWave;
+    for (int w = 1; w < nwaves; w++)
+    {
+      lo = min(lo, s_lo[w]);
+      hi = max(hi, s_hi[w]);
+    }
+    atomicMin(&minmax_enc[0], lo);
+    atomicMax(&minmax_enc[1], hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void PassXBruteFinalizeKernel(
+    const int32_t* __restrict__ in, float* __restrict__ sdf, uint32_t* __restrict__ minmax_enc,
+    int64_t total, int nx, int ny, int nz, double resolution, int add_virtual_border)
+{
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  const int64_t plane = static_cast<int64_t>(ny) * nz;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int x = static_cast<int>(i / plane);
+    const int64_t r = i - static_cast<int64_t>(x) * plane;
+    const int y = static_cast<int>(r / nz);
+    const int z = static_cast<int>(r - static_cast<int64_t>(y) * nz);
+    bool negative;
+    int32_t own;
+    Decode(in[i], negative, own);
+    const int32_t best = LineSearch(in + i, plane, x, nx, negative, own);
+    const float v = FinalizeSdf(best, negative, x, y, z, nx, ny, nz, resolution,
+                                add_virtual_border);
+    sdf[i] = v;
+    const uint32_t e = EncodeOrdered(v);
+    lo = min(lo, e);
+    hi = max(hi, e);
+  }
+  BlockMinMax(lo, hi, minmax_enc);
+}
+
+__global__ void InitMinMaxKernel(uint32_t* minmax_enc)
+{
+  minmax_enc[0] = 0xffffffffu;
+  minmax_enc[1] = 0u;
+}
+__global__ void DecodeMinMaxKernel(const uint32_t* minmax_enc, float* out)
+{
+  out[0] = DecodeOrdered(minmax_enc[0]);
+  out[1] = DecodeOrdered(minmax_enc[1]);
+}
+
+int GridFor(int64_t work_items, int block)
+{
+  // Memory-bound grid-stride launches: enough blocks to fill 256 CUs several times over.
+  const int64_t blocks = (work_items + block - 1) / block;
+  const int64_t cap = 256 * 32;
+  return static_cast<int>(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+}  // namespace
+
+// Declared in edt_hull_kernels.hip.
+hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
+                           hipStream_t stream, bool* handled);
+hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                   const SdfParams& p, hipStream_t stream, bool* handled);
+
+hipError_t LaunchScanZFromOccupancy(const float* occupancy, int16_t* out16, const SdfParams& p,
+                                    hipStream_t stream)
+{
+  const int64_t lines = p.nx * p.ny;
+  const int grid = GridFor(lines, kScanWaves);
+  hipLaunchKernelGGL(ScanZKernel<float>, dim3(grid), dim3(kScanBlock), 0, stream, occupancy, out16,
+                     lines, static_cast<int>(p.nz), p.unknown_is_filled);
+  return hipGetLastError();
+}
+
+hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfParams& p,
+                               hipStream_t stream)
+{
+  const int64_t lines = p.nx * p.ny;
+  const int grid = GridFor(lines, kScanWaves);
+  hipLaunchKernelGGL(ScanZKernel<uint8_t>, dim3(grid), dim3(kScanBlock), 0, stream, mask, out16,
+                     lines, static_cast<int>(p.nz), 0);
+  return hipGetLastError();
+}
+
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
+                       hipStream_t stream)
+{
+  if (variant == EdtVariant::kDefault)
+  {
+    bool handled = false;
+    const hipError_t err = LaunchPassYHull(in16, out32, p, stream, &handled);
+    if (handled || err != hipSuccess) return err;
+  }
+  const int64_t total = p.nx * p.ny * p.nz;
+  hipLaunchKernelGGL(PassYBruteKernel, dim3(GridFor(total, 256)), dim3(256), 0, stream, in16,
+                     out32, total, static_cast<int>(p.ny), static_cast<int>(p.nz));
+  return hipGetLastError();
+}
+
+hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                               const SdfParams& p, EdtVariant variant, hipStream_t stream)
+{
+  if (variant == EdtVariant::kDefault)
+  {
+    bool handled = false;
+    const hipError_t err = LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
+    if (handled || err != hipSuccess) return err;
+  }
+  const int64_t total = p.nx * p.ny * p.nz;
+  hipLaunchKernelGGL(PassXBruteFinalizeKernel, dim3(GridFor(total, 256)), dim3(256), 0, stream,
+                     in32, sdf, minmax_enc, total, static_cast<int>(p.nx), static_cast<int>(p.ny),
+                     static_cast<int>(p.nz), p.resolution, p.add_virtual_border);
+  return hipGetLastError();
+}
+
+hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream)
+{
+  hipLaunchKernelGGL(InitMinMaxKernel, dim3(1), dim3(1), 0, stream, minmax_enc);
+  return hipGetLastError();
+}
+
+hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(DecodeMinMaxKernel, dim3(1), dim3(1), 0, stream, minmax_enc, minmax_out);
+  return hipGetLastError();
+}
+}  // namespace vgt

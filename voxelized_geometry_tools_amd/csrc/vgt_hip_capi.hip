@@ -1,0 +1,700 @@
+// extern "C" surface of libvgt_hip.so (declared in include/vgt_hip.h): contexts, handles,
+// host<->device staging and the sequencing of the kernels.  No kernel code here.
+#include "../../include/vgt_hip.h"
+
+#include "vgt_internal.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+struct vgt_hip_ctx
+{
+  int device = -1;
+  int threads_per_block = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::mutex mutex;              // serialises enqueues + the staging buffer
+  void* stage = nullptr;         // device staging for host point clouds
+  size_t stage_bytes = 0;
+  float* minmax_out = nullptr;   // 2 floats (device) for host-facing SDF calls
+  vgt::EdtVariant variant = vgt::EdtVariant::kDefault;
+};
+
+struct vgt_hip_grids
+{
+  vgt_hip_ctx* ctx = nullptr;
+  int32_t* dev = nullptr;
+  int64_t num_cells = 0;
+  int32_t num_grids = 0;
+};
+
+struct vgt_hip_filter
+{
+  vgt_hip_ctx* ctx = nullptr;
+  float* dev = nullptr;
+  int64_t num_cells = 0;
+};
+
+namespace
+{
+thread_local std::string g_last_error;
+
+int Fail(int code, const std::string& msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+int FailHip(const char* what, hipError_t err)
+{
+  g_last_error = std::string("[") + what + "] HIP error [" + hipGetErrorString(err) + "]";
+  return VGT_HIP_ERR_RUNTIME;
+}
+
+#define VGT_TRY_HIP(expr, what)                          \
+  do                                                     \
+  {                                                      \
+    const hipError_t vgt_err_ = (expr);                  \
+    if (vgt_err_ != hipSuccess) return FailHip(what, vgt_err_); \
+  } while (0)
+
+size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct SdfWorkspace
+{
+  int16_t* t16;
+  int32_t* t32;
+  uint32_t* minmax_enc;
+  size_t bytes;
+};
+
+SdfWorkspace CarveWorkspace(void* base, int64_t nvox)
+{
+  SdfWorkspace ws;
+  const size_t n = static_cast<size_t>(nvox);
+  size_t off = 0;
+  ws.t16 = reinterpret_cast<int16_t*>(static_cast<char*>(base) + off);
+  off = AlignUp(off + n * sizeof(int16_t), 256);
+  ws.t32 = reinterpret_cast<int32_t*>(static_cast<char*>(base) + off);
+  off = AlignUp(off + n * sizeof(int32_t), 256);
+  ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
+  off += 256;
+  ws.bytes = off;
+  return ws;
+}
+
+int CheckSdfShape(int64_t nx, int64_t ny, int64_t nz, double resolution)
+{
+  if (nx <= 0 || ny <= 0 || nz <= 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "grid extents must be positive");
+  if (nx > vgt::kMaxExtent || ny > vgt::kMaxExtent || nz > vgt::kMaxExtent)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "grid extent exceeds 16384 voxels on an axis");
+  if (!(resolution > 0.0) || !std::isfinite(resolution))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "Grid must have uniform, positive resolution");
+  return VGT_HIP_OK;
+}
+
+// Enqueues the three passes.  events (optional) = 4 recorded events bracketing the kernels.
+template <typename InT>
+int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams& p, float* sdf_dev,
+                   void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
+                   hipEvent_t* events)
+{
+  const int64_t nvox = p.nx * p.ny * p.nz;
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nvox);
+  if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
+  hipStream_t s = ctx->stream;
+  VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
+  if (events) VGT_TRY_HIP(hipEventRecord(events[0], s), "event record");
+  if constexpr (std::is_same<InT, float>::value)
+    VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(input_dev, ws.t16, p, s), "Z scan");
+  else
+    VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, s), "Z scan");
+  if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, p, ctx->variant, s), "Y pass");
+  if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, p, ctx->variant, s),
+              "X pass");
+  if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
+  if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
+  return VGT_HIP_OK;
+}
+
+template <typename InT>
+int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p, float* sdf_host,
+                float* out_min, float* out_max)
+{
+  if (!ctx || !input_host || !sdf_host)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(p.nx, p.ny, p.nz, p.resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
+  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes(p.nx, p.ny, p.nz);
+  InT* in_dev = nullptr;
+  float* sdf_dev = nullptr;
+  void* ws_dev = nullptr;
+  int result = VGT_HIP_OK;
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&in_dev), nvox * sizeof(InT));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&sdf_dev), nvox * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&ws_dev, ws_bytes);
+  if (err != hipSuccess)
+    result = FailHip("allocate SDF buffers", err);
+  else
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    hipStream_t s = ctx->stream;
+    err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
+    if (err != hipSuccess)
+      result = FailHip("copy occupancy to device", err);
+    else
+      result = RunSdfPipeline<InT>(ctx, in_dev, p, sdf_dev, ws_dev, ws_bytes, ctx->minmax_out,
+                                   nullptr);
+    if (result == VGT_HIP_OK)
+    {
+      float mm[2] = {0.0f, 0.0f};
+      err = hipMemcpyAsync(sdf_host, sdf_dev, nvox * sizeof(float), hipMemcpyDeviceToHost, s);
+      if (err == hipSuccess)
+        err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, s);
+      if (err == hipSuccess) err = hipStreamSynchronize(s);
+      if (err != hipSuccess)
+        result = FailHip("copy SDF to host", err);
+      else
+      {
+        if (out_min) *out_min = mm[0];
+        if (out_max) *out_max = mm[1];
+      }
+    }
+    else
+      (void)hipStreamSynchronize(s);
+  }
+  if (in_dev) (void)hipFree(in_dev);
+  if (sdf_dev) (void)hipFree(sdf_dev);
+  if (ws_dev) (void)hipFree(ws_dev);
+  return result;
+}
+
+int CheckRaycastArgs(const vgt_hip_ctx* ctx, const vgt_hip_grids* grids, size_t grid_index,
+                     const void* points, int64_t num_points, const void* xform, int32_t nx,
+                     int32_t ny, int32_t nz)
+{
+  if (!ctx || !grids || !xform) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (grids->ctx != ctx)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grids belong to another context");
+  if (grid_index >= static_cast<size_t>(grids->num_grids))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grid index out of range");
+  if (num_points < 0 || (num_points > 0 && !points))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid point buffer");
+  if (nx <= 0 || ny <= 0 || nz <= 0 ||
+      static_cast<int64_t>(nx) * ny * nz != grids->num_cells)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "voxel counts do not match the tracking grids");
+  return VGT_HIP_OK;
+}
+
+// Grows the context's staging buffer (caller holds the mutex).
+int EnsureStage(vgt_hip_ctx* ctx, size_t bytes)
+{
+  if (ctx->stage_bytes >= bytes) return VGT_HIP_OK;
+  if (ctx->stage)
+  {
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain before regrowing staging buffer");
+    VGT_TRY_HIP(hipFree(ctx->stage), "free staging buffer");
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
+  }
+  const size_t want = AlignUp(bytes + bytes / 4, 1 << 20);
+  VGT_TRY_HIP(hipMalloc(&ctx->stage, want), "allocate staging buffer");
+  ctx->stage_bytes = want;
+  return VGT_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vgt_hip_abi_version(void) { return VGT_HIP_ABI_VERSION; }
+
+const char* vgt_hip_last_error(void) { return g_last_error.c_str(); }
+
+int vgt_hip_device_count(int* count)
+{
+  if (!count) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *count = 0;
+  int n = 0;
+  const hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) return FailHip("Failed to get device count", err);
+  *count = n;
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_device_name(int device, char* buffer, size_t buffer_size)
+{
+  if (!buffer || buffer_size == 0) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  hipDeviceProp_t prop;
+  std::memset(&prop, 0, sizeof(prop));
+  VGT_TRY_HIP(hipGetDeviceProperties(&prop, device), "Failed to get device properties");
+  std::snprintf(buffer, buffer_size, "%s", prop.name);
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx)
+{
+  if (!out_ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *out_ctx = nullptr;
+  int count = 0;
+  const hipError_t cerr = hipGetDeviceCount(&count);
+  if (cerr != hipSuccess || count <= 0)
+  {
+    g_last_error = "no usable HIP device (libvgt_hip has no CPU fallback)";
+    return VGT_HIP_ERR_UNAVAILABLE;
+  }
+  if (device < 0 || device >= count)
+  {
+    g_last_error = "HIP_DEVICE = " + std::to_string(device) + " out of range for " +
+                   std::to_string(count) + " devices";
+    return VGT_HIP_ERR_UNAVAILABLE;
+  }
+  if (threads_per_block <= 0) threads_per_block = 256;
+  if (threads_per_block > 1024 || (threads_per_block % 64) != 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT,
+                "threads_per_block must be a multiple of 64 and at most 1024");
+  VGT_TRY_HIP(hipSetDevice(device), "Failed to set device");
+  vgt_hip_ctx* ctx = new (std::nothrow) vgt_hip_ctx();
+  if (!ctx) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
+  ctx->device = device;
+  ctx->threads_per_block = threads_per_block;
+  hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&ctx->minmax_out), 256);
+  if (err != hipSuccess)
+  {
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return FailHip("create context", err);
+  }
+  ctx->stream = ctx->own_stream;
+  *out_ctx = ctx;
+  return VGT_HIP_OK;
+}
+
+void vgt_hip_destroy(vgt_hip_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stage) (void)hipFree(ctx->stage);
+  if (ctx->minmax_out) (void)hipFree(ctx->minmax_out);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream)
+{
+  if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_synchronize(vgt_hip_ctx* ctx)
+{
+  if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "synchronize");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
+{
+  if (!ctx || variant < 0 || variant > 1)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
+  ctx->variant = static_cast<vgt::EdtVariant>(variant);
+  return VGT_HIP_OK;
+}
+
+/* ------------------------------ tracking grids ------------------------------ */
+
+int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t num_grids,
+                                  vgt_hip_grids** out_grids)
+{
+  if (!ctx || !out_grids) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *out_grids = nullptr;
+  // zero-element buffers are an error, as in the reference (cuda_voxelization_helpers.cu:457-460)
+  if (num_cells <= 0 || num_grids <= 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "num_elements must be > 0");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt_hip_grids* g = new (std::nothrow) vgt_hip_grids();
+  if (!g) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
+  g->ctx = ctx;
+  g->num_cells = num_cells;
+  g->num_grids = num_grids;
+  const size_t bytes = static_cast<size_t>(num_cells) * num_grids * 2 * sizeof(int32_t);
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&g->dev), bytes);
+  if (err == hipSuccess)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    err = hipMemsetAsync(g->dev, 0, bytes, ctx->stream);
+  }
+  if (err != hipSuccess)
+  {
+    if (g->dev) (void)hipFree(g->dev);
+    delete g;
+    return FailHip("Failed to allocate tracking grids", err);
+  }
+  *out_grids = g;
+  return VGT_HIP_OK;
+}
+
+void vgt_hip_tracking_grids_destroy(vgt_hip_grids* grids)
+{
+  if (!grids) return;
+  (void)hipSetDevice(grids->ctx->device);
+  (void)hipStreamSynchronize(grids->ctx->stream);
+  if (grids->dev) (void)hipFree(grids->dev);
+  delete grids;
+}
+
+int64_t vgt_hip_tracking_grids_num_cells(const vgt_hip_grids* grids)
+{
+  return grids ? grids->num_cells : 0;
+}
+int32_t vgt_hip_tracking_grids_num_grids(const vgt_hip_grids* grids)
+{
+  return grids ? grids->num_grids : 0;
+}
+int64_t vgt_hip_tracking_grids_offset(const vgt_hip_grids* grids, size_t grid_index)
+{
+  if (!grids || grid_index >= static_cast<size_t>(grids->num_grids)) return -1;
+  return static_cast<int64_t>(grid_index) * grids->num_cells * 2;
+}
+void* vgt_hip_tracking_grids_dev_ptr(const vgt_hip_grids* grids, size_t grid_index)
+{
+  if (!grids || grid_index >= static_cast<size_t>(grids->num_grids)) return nullptr;
+  return grids->dev + static_cast<int64_t>(grid_index) * grids->num_cells * 2;
+}
+
+int vgt_hip_tracking_grids_clear(vgt_hip_ctx* ctx, vgt_hip_grids* grids)
+{
+  if (!ctx || !grids || grids->ctx != ctx)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid tracking grids");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const size_t bytes = static_cast<size_t>(grids->num_cells) * grids->num_grids * 2 * sizeof(int32_t);
+  VGT_TRY_HIP(hipMemsetAsync(grids->dev, 0, bytes, ctx->stream), "clear tracking grids");
+  return VGT_HIP_OK;
+}
+
+/* --------------------------------- raycast ---------------------------------- */
+
+int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                   const float* points_xyz_dev, int64_t num_points,
+                                   float max_range, const float* grid_pointcloud_transform,
+                                   float voxel_size, float inverse_voxel_size, float grid_x_size,
+                                   float grid_y_size, float grid_z_size, int32_t num_x_voxels,
+                                   int32_t num_y_voxels, int32_t num_z_voxels)
+{
+  const int rc = CheckRaycastArgs(ctx, grids, grid_index, points_xyz_dev, num_points,
+                                  grid_pointcloud_transform, num_x_voxels, num_y_voxels,
+                                  num_z_voxels);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_points == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::RaycastGridF32 g;
+  g.max_range = max_range;
+  std::memcpy(g.xform, grid_pointcloud_transform, sizeof(g.xform));
+  g.voxel_size = voxel_size;
+  g.inverse_voxel_size = inverse_voxel_size;
+  g.grid_size[0] = grid_x_size;
+  g.grid_size[1] = grid_y_size;
+  g.grid_size[2] = grid_z_size;
+  g.counts[0] = num_x_voxels;
+  g.counts[1] = num_y_voxels;
+  g.counts[2] = num_z_voxels;
+  int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, g, tracking,
+                                    ctx->threads_per_block, ctx->stream),
+              "Failed to dispatch raycast kernel");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                               const float* points_xyz_host, int64_t num_points, float max_range,
+                               const float* grid_pointcloud_transform, float voxel_size,
+                               float inverse_voxel_size, float grid_x_size, float grid_y_size,
+                               float grid_z_size, int32_t num_x_voxels, int32_t num_y_voxels,
+                               int32_t num_z_voxels)
+{
+  const int rc = CheckRaycastArgs(ctx, grids, grid_index, points_xyz_host, num_points,
+                                  grid_pointcloud_transform, num_x_voxels, num_y_voxels,
+                                  num_z_voxels);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_points == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::RaycastGridF32 g;
+  g.max_range = max_range;
+  std::memcpy(g.xform, grid_pointcloud_transform, sizeof(g.xform));
+  g.voxel_size = voxel_size;
+  g.inverse_voxel_size = inverse_voxel_size;
+  g.grid_size[0] = grid_x_size;
+  g.grid_size[1] = grid_y_size;
+  g.grid_size[2] = grid_z_size;
+  g.counts[0] = num_x_voxels;
+  g.counts[1] = num_y_voxels;
+  g.counts[2] = num_z_voxels;
+  int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
+  const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(float);
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const int src = EnsureStage(ctx, bytes);
+  if (src != VGT_HIP_OK) return src;
+  // Stream order protects the staging buffer: this copy queues behind the previous kernel.
+  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, points_xyz_host, bytes, hipMemcpyHostToDevice,
+                             ctx->stream),
+              "Failed to copy points to the device");
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(static_cast<const float*>(ctx->stage), num_points, g, tracking,
+                                    ctx->threads_per_block, ctx->stream),
+              "Failed to dispatch raycast kernel");
+  // The host buffer may be released by the caller as soon as we return.
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                               const double* points_xyz_host, int64_t num_points,
+                               double max_range, const double* grid_pointcloud_transform,
+                               double voxel_size, double inverse_voxel_size, double grid_x_size,
+                               double grid_y_size, double grid_z_size, int32_t num_x_voxels,
+                               int32_t num_y_voxels, int32_t num_z_voxels)
+{
+  const int rc = CheckRaycastArgs(ctx, grids, grid_index, points_xyz_host, num_points,
+                                  grid_pointcloud_transform, num_x_voxels, num_y_voxels,
+                                  num_z_voxels);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_points == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::RaycastGridF64 g;
+  g.max_range = max_range;
+  std::memcpy(g.xform, grid_pointcloud_transform, sizeof(g.xform));
+  g.voxel_size = voxel_size;
+  g.inverse_voxel_size = inverse_voxel_size;
+  g.grid_size[0] = grid_x_size;
+  g.grid_size[1] = grid_y_size;
+  g.grid_size[2] = grid_z_size;
+  g.counts[0] = num_x_voxels;
+  g.counts[1] = num_y_voxels;
+  g.counts[2] = num_z_voxels;
+  int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
+  const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(double);
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const int src = EnsureStage(ctx, bytes);
+  if (src != VGT_HIP_OK) return src;
+  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, points_xyz_host, bytes, hipMemcpyHostToDevice,
+                             ctx->stream),
+              "Failed to copy points to the device");
+  VGT_TRY_HIP(vgt::LaunchRaycastF64(static_cast<const double*>(ctx->stage), num_points, g,
+                                    tracking, ctx->threads_per_block, ctx->stream),
+              "Failed to dispatch raycast kernel");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
+  return VGT_HIP_OK;
+}
+
+/* --------------------------------- filter ----------------------------------- */
+
+int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float* occupancy_host,
+                               vgt_hip_filter** out_filter)
+{
+  if (!ctx || !out_filter) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *out_filter = nullptr;
+  if (num_cells <= 0) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "num_elements must be > 0");
+  if (!occupancy_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "to_copy cannot be nullptr");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt_hip_filter* f = new (std::nothrow) vgt_hip_filter();
+  if (!f) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
+  f->ctx = ctx;
+  f->num_cells = num_cells;
+  const size_t bytes = static_cast<size_t>(num_cells) * sizeof(float);
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&f->dev), bytes);
+  if (err == hipSuccess)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    err = hipMemcpyAsync(f->dev, occupancy_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+  }
+  if (err != hipSuccess)
+  {
+    if (f->dev) (void)hipFree(f->dev);
+    delete f;
+    return FailHip("Failed to prepare filter grid", err);
+  }
+  *out_filter = f;
+  return VGT_HIP_OK;
+}
+
+void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter)
+{
+  if (!filter) return;
+  (void)hipSetDevice(filter->ctx->device);
+  (void)hipStreamSynchronize(filter->ctx->stream);
+  if (filter->dev) (void)hipFree(filter->dev);
+  delete filter;
+}
+
+int64_t vgt_hip_filter_grid_num_cells(const vgt_hip_filter* filter)
+{
+  return filter ? filter->num_cells : 0;
+}
+void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter)
+{
+  return filter ? filter->dev : nullptr;
+}
+
+static int FilterImpl(vgt_hip_ctx* ctx, const vgt_hip_grids* grids, double percent_seen_free,
+                      int32_t outlier_points_threshold, int32_t num_cameras_seen_free,
+                      bool ratio_in_double, vgt_hip_filter* filter)
+{
+  if (!ctx || !grids || !filter) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (grids->ctx != ctx || filter->ctx != ctx)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "handles belong to another context");
+  if (grids->num_cells != filter->num_cells)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grids and filter grid differ in size");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(vgt::LaunchFilter(grids->dev, grids->num_cells, grids->num_grids, percent_seen_free,
+                                outlier_points_threshold, num_cameras_seen_free, ratio_in_double,
+                                filter->dev, ctx->threads_per_block, ctx->stream),
+              "Failed to dispatch filter kernel");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_filter_tracking_grids(vgt_hip_ctx* ctx, const vgt_hip_grids* grids,
+                                  float percent_seen_free, int32_t outlier_points_threshold,
+                                  int32_t num_cameras_seen_free, vgt_hip_filter* filter)
+{
+  return FilterImpl(ctx, grids, static_cast<double>(percent_seen_free), outlier_points_threshold,
+                    num_cameras_seen_free, false, filter);
+}
+
+int vgt_hip_filter_tracking_grids_f64(vgt_hip_ctx* ctx, const vgt_hip_grids* grids,
+                                      double percent_seen_free, int32_t outlier_points_threshold,
+                                      int32_t num_cameras_seen_free, vgt_hip_filter* filter)
+{
+  return FilterImpl(ctx, grids, percent_seen_free, outlier_points_threshold,
+                    num_cameras_seen_free, true, filter);
+}
+
+int vgt_hip_retrieve_tracking_grid(vgt_hip_ctx* ctx, const vgt_hip_grids* grids, size_t grid_index,
+                                   void* host_out)
+{
+  if (!ctx || !grids || !host_out || grids->ctx != ctx)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (grid_index >= static_cast<size_t>(grids->num_grids))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grid index out of range");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const size_t bytes = static_cast<size_t>(grids->num_cells) * 2 * sizeof(int32_t);
+  VGT_TRY_HIP(hipMemcpyAsync(host_out, vgt_hip_tracking_grids_dev_ptr(grids, grid_index), bytes,
+                             hipMemcpyDeviceToHost, ctx->stream),
+              "Failed to memcpy the tracking grid back to the host");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "retrieve tracking grid");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filter, void* host_out)
+{
+  if (!ctx || !filter || !host_out || filter->ctx != ctx)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const size_t bytes = static_cast<size_t>(filter->num_cells) * sizeof(float);
+  VGT_TRY_HIP(hipMemcpyAsync(host_out, filter->dev, bytes, hipMemcpyDeviceToHost, ctx->stream),
+              "Failed to memcpy the filter grid back to the host");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "retrieve filtered grid");
+  return VGT_HIP_OK;
+}
+
+/* ----------------------------------- SDF ------------------------------------ */
+
+size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
+{
+  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return CarveWorkspace(nullptr, nx * ny * nz).bytes;
+}
+
+int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,
+                                   int64_t ny, int64_t nz, double resolution,
+                                   int unknown_is_filled, int add_virtual_border, float* sdf_host,
+                                   float* out_min, float* out_max)
+{
+  const vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0,
+                         add_virtual_border ? 1 : 0};
+  return SdfFromHost<float>(ctx, occupancy_host, p, sdf_host, out_min, out_max);
+}
+
+int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, int64_t nx,
+                             int64_t ny, int64_t nz, double resolution, int add_virtual_border,
+                             float* sdf_host, float* out_min, float* out_max)
+{
+  const vgt::SdfParams p{nx, ny, nz, resolution, 0, add_virtual_border ? 1 : 0};
+  return SdfFromHost<uint8_t>(ctx, filled_mask_host, p, sdf_host, out_min, out_max);
+}
+
+int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
+                    int64_t nz, double resolution, int unknown_is_filled, int add_virtual_border,
+                    float* sdf_dev, void* workspace_dev, size_t workspace_bytes, float* minmax_dev)
+{
+  if (!ctx || !occupancy_dev || !sdf_dev)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0,
+                         add_virtual_border ? 1 : 0};
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  return RunSdfPipeline<float>(ctx, occupancy_dev, p, sdf_dev, workspace_dev, workspace_bytes,
+                               minmax_dev, nullptr);
+}
+
+int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
+                          int64_t nz, double resolution, int unknown_is_filled,
+                          int add_virtual_border, float* sdf_dev, void* workspace_dev,
+                          size_t workspace_bytes, float* minmax_dev, float* kernel_ms)
+{
+  if (!ctx || !occupancy_dev || !sdf_dev || !kernel_ms)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0,
+                         add_virtual_border ? 1 : 0};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int result = VGT_HIP_OK;
+  for (int i = 0; i < 4 && result == VGT_HIP_OK; i++)
+  {
+    const hipError_t err = hipEventCreate(&ev[i]);
+    if (err != hipSuccess) result = FailHip("create event", err);
+  }
+  if (result == VGT_HIP_OK)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    result = RunSdfPipeline<float>(ctx, occupancy_dev, p, sdf_dev, workspace_dev, workspace_bytes,
+                                   minmax_dev, ev);
+    const hipError_t err = hipStreamSynchronize(ctx->stream);
+    if (result == VGT_HIP_OK && err != hipSuccess) result = FailHip("synchronize", err);
+    for (int i = 0; i < 3 && result == VGT_HIP_OK; i++)
+    {
+      const hipError_t terr = hipEventElapsedTime(&kernel_ms[i], ev[i], ev[i + 1]);
+      if (terr != hipSuccess) result = FailHip("event elapsed", terr);
+    }
+  }
+  for (int i = 0; i < 4; i++)
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+  return result;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Internal declarations shared by the HIP translation units of libvgt_hip.so.
+// Not part of the public ABI (that is include/vgt_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace vgt
+{
+// Intermediate encodings of the signed Euclidean distance transform.
+//  pass 1 (Z scan)  -> int16: +d for a free voxel, -d for a filled voxel, d = distance in
+//                      voxels along Z to the nearest voxel of the OTHER class,
+//                      |value| == kInf16 when the line holds no such voxel.
+//  pass 2 (Y pass)  -> int32: +-(squared distance in the YZ plane), kInf32 when none.
+//  pass 3 (X pass)  -> float SDF.
+constexpr int16_t kInf16 = 32767;
+constexpr int32_t kInf32 = 0x7fffffff;
+// Largest supported extent per axis: keeps every squared distance (<= 3*kMaxExtent^2)
+// and every parabola value below 2^31.
+constexpr int64_t kMaxExtent = 16384;
+
+struct SdfParams
+{
+  int64_t nx, ny, nz;
+  double resolution;
+  int unknown_is_filled;
+  int add_virtual_border;
+};
+
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1 };
+
+// --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
+// Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
+hipError_t LaunchScanZFromOccupancy(const float* occupancy, int16_t* out16, const SdfParams& p,
+                                    hipStream_t stream);
+hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfParams& p,
+                                hipStream_t stream);
+// Y pass: int16 -> int32 signed squared distance.
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
+                       hipStream_t stream);
+// X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
+// order-preserving encoding, must be pre-initialised by InitMinMax).
+hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                               const SdfParams& p, EdtVariant variant, hipStream_t stream);
+hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
+hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
+
+// --- launchers (voxelizer_kernels.hip) ---
+struct RaycastGridF32
+{
+  float max_range;
+  float xform[16];
+  float voxel_size, inverse_voxel_size;
+  float grid_size[3];
+  int32_t counts[3];
+};
+struct RaycastGridF64
+{
+  double max_range;
+  double xform[16];
+  double voxel_size, inverse_voxel_size;
+  double grid_size[3];
+  int32_t counts[3];
+};
+hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, const RaycastGridF32& g,
+                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream);
+hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
+                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream);
+hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
+                        double percent_seen_free, int32_t outlier_points_threshold,
+                        int32_t num_cameras_seen_free, bool ratio_in_double, float* occupancy_dev,
+                        int threads_per_block, hipStream_t stream);
+}  // namespace vgt

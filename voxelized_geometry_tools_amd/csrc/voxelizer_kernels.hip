@@ -1,0 +1,252 @@
+// Pointcloud raycast voxelization for gfx950: per-ray 3-D DDA with atomic seen-free /
+// seen-filled accumulation, and the per-voxel combine-and-filter.
+//
+// Behaviour follows the reference's device kernels (src/voxelized_geometry_tools/
+// cuda_voxelization_helpers.cu:73-356 "RaycastPoint", :358-426 "FilterGrids") including their
+// quirks (final voxel marked first and never as free-by-walk, `t2 > tmax` slab update, the
+// 1e-10 nudge that vanishes in float).  This TU is compiled with -ffp-contract=off so the
+// float arithmetic is the plain left-to-right evaluation the oracle restates; sqrt and
+// division are correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+// Differences from the reference kernels, none of which change results on grids the
+// reference can index: 64-bit cell indices (the reference's int32 index overflows at 2^30
+// cells), tracking counters addressed as (cell*2 + {0 free, 1 filled}).
+#include "vgt_internal.hpp"
+
+#include <cmath>
+
+namespace vgt
+{
+namespace
+{
+template <typename Real>
+struct RaycastTraits;
+template <>
+struct RaycastTraits<float>
+{
+  using Grid = RaycastGridF32;
+  static constexpr float kFlat = 1e-10f;
+  static constexpr float kNudge = 1e-10f;
+};
+template <>
+struct RaycastTraits<double>
+{
+  using Grid = RaycastGridF64;
+  static constexpr double kFlat = 1e-10;
+  static constexpr double kNudge = 1e-10;
+};
+
+template <typename Real>
+__device__ __forceinline__ Real AxisT(Real point, Real ray, Real lo, Real hi)
+{
+  // GetAxisTValue, cuda_voxelization_helpers.cu:52-71
+  if (ray > Real(0)) return fabs((hi - point) / ray);
+  if (ray < -Real(0)) return fabs((point - lo) / ray);
+  return static_cast<Real>(INFINITY);
+}
+
+__device__ __forceinline__ bool InGrid(const int32_t idx[3], const int32_t counts[3])
+{
+  return idx[0] >= 0 && idx[0] < counts[0] && idx[1] >= 0 && idx[1] < counts[1] && idx[2] >= 0 &&
+         idx[2] < counts[2];
+}
+
+__device__ __forceinline__ int64_t CellIndex(const int32_t idx[3], const int32_t counts[3])
+{
+  return (static_cast<int64_t>(idx[0]) * counts[1] + idx[1]) * counts[2] + idx[2];
+}
+
+// One thread per point.  Real = float reproduces the reference device kernels, Real = double
+// the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
+template <typename Real>
+__global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_points,
+                              const typename RaycastTraits<Real>::Grid g,
+                              int32_t* __restrict__ tracking)
+{
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= num_points) return;
+
+  const Real px = points[3 * i + 0];
+  const Real py = points[3 * i + 1];
+  const Real pz = points[3 * i + 2];
+  if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) return;
+
+  const Real* T = g.xform;
+  // point and cloud origin in the grid frame
+  const Real gp[3] = {T[0] * px + T[4] * py + T[8] * pz + T[12],
+                      T[1] * px + T[5] * py + T[9] * pz + T[13],
+                      T[2] * px + T[6] * py + T[10] * pz + T[14]};
+  const Real origin[3] = {T[12], T[13], T[14]};
+
+  // clip the ray to max_range
+  const Real ray[3] = {gp[0] - origin[0], gp[1] - origin[1], gp[2] - origin[2]};
+  const Real length = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+  const bool clipped = length > g.max_range;
+  Real last[3] = {gp[0], gp[1], gp[2]};
+  if (clipped)
+  {
+    for (int a = 0; a < 3; a++) last[a] = origin[a] + (ray[a] * (g.max_range / length));
+  }
+
+  // entry point: the origin itself, or where the ray enters the grid's box
+  int32_t origin_idx[3];
+  for (int a = 0; a < 3; a++)
+    origin_idx[a] = static_cast<int32_t>(floor(origin[a] * g.inverse_voxel_size));
+  Real first[3] = {origin[0], origin[1], origin[2]};
+  if (!InGrid(origin_idx, g.counts))
+  {
+    Real tmin = Real(0);
+    Real tmax = g.max_range;
+    Real dir[3];
+    for (int a = 0; a < 3; a++) dir[a] = ray[a] / length;
+    for (int a = 0; a < 3; a++)
+    {
+      if (fabs(dir[a]) < RaycastTraits<Real>::kFlat)
+      {
+        if (!(origin[a] >= Real(0) && origin[a] < g.grid_size[a])) return;
+      }
+      else
+      {
+        const Real ood = Real(1) / dir[a];
+        const Real tlow = (Real(0) - origin[a]) * ood;
+        const Real thigh = (g.grid_size[a] - origin[a]) * ood;
+        const Real t1 = (tlow <= thigh) ? tlow : thigh;
+        const Real t2 = (tlow <= thigh) ? thigh : tlow;
+        if (t1 > tmin) tmin = t1;
+        if (t2 > tmax) tmax = t2;  // as the reference (cuda_voxelization_helpers.cu:206-209)
+        if (tmin > tmax) return;
+      }
+    }
+    for (int a = 0; a < 3; a++)
+      first[a] = origin[a] + (dir[a] * (tmin + RaycastTraits<Real>::kNudge));
+  }
+
+  int32_t cur[3], end[3], step[3];
+  Real t[3], dt[3];
+  const Real half = g.voxel_size * Real(0.5);
+  for (int a = 0; a < 3; a++)
+  {
+    cur[a] = static_cast<int32_t>(floor(first[a] * g.inverse_voxel_size));
+    end[a] = static_cast<int32_t>(floor(last[a] * g.inverse_voxel_size));
+    const int32_t diff = end[a] - cur[a];
+    step[a] = (diff > 0) - (diff < 0);
+    const Real centre = (static_cast<Real>(cur[a]) + Real(0.5)) * g.voxel_size;
+    t[a] = AxisT<Real>(first[a], ray[a], centre - half, centre + half);
+    dt[a] = fabs(g.voxel_size / ray[a]);
+  }
+
+  // the end voxel is recorded first: seen-free if the ray was clipped, seen-filled otherwise
+  if (InGrid(end, g.counts))
+    atomicAdd(&tracking[CellIndex(end, g.counts) * 2 + (clipped ? 0 : 1)], 1);
+
+  while (cur[0] != end[0] || cur[1] != end[1] || cur[2] != end[2])
+  {
+    if (!InGrid(cur, g.counts)) break;
+    atomicAdd(&tracking[CellIndex(cur, g.counts) * 2], 1);
+    int a;
+    if (t[0] <= t[1] && t[0] <= t[2])
+      a = 0;
+    else if (t[1] <= t[0] && t[1] <= t[2])
+      a = 1;
+    else
+      a = 2;
+    // select without dynamically indexing the register arrays
+    if (a == 0)
+    {
+      if (cur[0] == end[0]) break;
+      cur[0] += step[0];
+      t[0] += dt[0];
+    }
+    else if (a == 1)
+    {
+      if (cur[1] == end[1]) break;
+      cur[1] += step[1];
+      t[1] += dt[1];
+    }
+    else
+    {
+      if (cur[2] == end[2]) break;
+      cur[2] += step[2];
+      t[2] += dt[2];
+    }
+  }
+}
+
+// One thread per voxel; cells whose static occupancy is > 0.5 are left alone.
+template <typename Ratio>
+__global__ void FilterKernel(const int32_t* __restrict__ tracking, int64_t num_cells,
+                             int32_t num_grids, Ratio percent_seen_free,
+                             int32_t outlier_points_threshold, int32_t num_cameras_seen_free,
+                             float* __restrict__ occupancy)
+{
+  for (int64_t cell = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+       cell < num_cells; cell += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    if (!(occupancy[cell] <= 0.5f)) continue;
+    int32_t seen_filled = 0, seen_free = 0;
+    for (int32_t grid = 0; grid < num_grids; grid++)
+    {
+      const int2 counts = *reinterpret_cast<const int2*>(
+          tracking + (static_cast<int64_t>(grid) * num_cells + cell) * 2);
+      const int32_t free_count = counts.x;
+      const int32_t filled_count = (counts.y >= outlier_points_threshold) ? counts.y : 0;
+      if (free_count > 0 && filled_count > 0)
+      {
+        const Ratio ratio =
+            static_cast<Ratio>(free_count) / static_cast<Ratio>(free_count + filled_count);
+        if (ratio >= percent_seen_free)
+          seen_free++;
+        else
+          seen_filled++;
+      }
+      else if (free_count > 0)
+        seen_free++;
+      else if (filled_count > 0)
+        seen_filled++;
+    }
+    occupancy[cell] =
+        (seen_filled > 0) ? 1.0f : ((seen_free >= num_cameras_seen_free) ? 0.0f : 0.5f);
+  }
+}
+}  // namespace
+
+hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, const RaycastGridF32& g,
+                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream)
+{
+  if (num_points <= 0) return hipSuccess;
+  const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
+  hipLaunchKernelGGL(RaycastKernel<float>, dim3(static_cast<unsigned>(blocks)),
+                     dim3(threads_per_block), 0, stream, points_dev, num_points, g, tracking_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
+                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream)
+{
+  if (num_points <= 0) return hipSuccess;
+  const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
+  hipLaunchKernelGGL(RaycastKernel<double>, dim3(static_cast<unsigned>(blocks)),
+                     dim3(threads_per_block), 0, stream, points_dev, num_points, g, tracking_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
+                        double percent_seen_free, int32_t outlier_points_threshold,
+                        int32_t num_cameras_seen_free, bool ratio_in_double, float* occupancy_dev,
+                        int threads_per_block, hipStream_t stream)
+{
+  int64_t blocks = (num_cells + threads_per_block - 1) / threads_per_block;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (blocks < 1) blocks = 1;
+  if (ratio_in_double)
+    hipLaunchKernelGGL(FilterKernel<double>, dim3(static_cast<unsigned>(blocks)),
+                       dim3(threads_per_block), 0, stream, tracking_dev, num_cells, num_grids,
+                       percent_seen_free, outlier_points_threshold, num_cameras_seen_free,
+                       occupancy_dev);
+  else
+    hipLaunchKernelGGL(FilterKernel<float>, dim3(static_cast<unsigned>(blocks)),
+                       dim3(threads_per_block), 0, stream, tracking_dev, num_cells, num_grids,
+                       static_cast<float>(percent_seen_free), outlier_points_threshold,
+                       num_cameras_seen_free, occupancy_dev);
+  return hipGetLastError();
+}
+}  // namespace vgt
