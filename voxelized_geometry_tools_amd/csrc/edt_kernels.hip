@@ -18,13 +18,13 @@
 // This file currently holds the Z scan and the simple pruned-search line pass
 // (EdtVariant::kBruteForce, exact for any size); the LDS-tiled envelope pass lives in
 // edt_hull_kernels.hip.
-#include "vgt_internal.hpp"
+#include "edt_device.hpp"
 
 namespace vgt
 {
 namespace
 {
-constexpr int kWave = 64;
+constexpr int kWave = kWaveSize;
 constexpr int kScanBlock = 256;
 constexpr int kScanWaves = kScanBlock / kWave;
 constexpr int kMaxChunks = static_cast<int>(kMaxExtent / kWave);
@@ -129,21 +129,6 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Decoding of the intermediate encodings into (class, squared distance so far).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void Decode(int16_t v, bool& negative, int32_t& f)
-{
-  negative = v < 0;
-  const int32_t a = negative ? -static_cast<int32_t>(v) : static_cast<int32_t>(v);
-  f = (a == kInf16) ? kInf32 : a * a;
-}
-__device__ __forceinline__ void Decode(int32_t v, bool& negative, int32_t& f)
-{
-  negative = v < 0;
-  f = negative ? -v : v;
-}
-
 // Exact 1-D lower-envelope value at position q by outward search with pruning: a site at
 // offset k can only improve the answer while k*k < best, and the first voxel of the other
 // class (a zero-valued site) ends the search on both sides.  O(sqrt(answer)) per voxel.
@@ -192,76 +177,6 @@ __global__ __launch_bounds__(256) void PassYBruteKernel(const int16_t* __restric
     Decode(in[i], negative, own);
     const int32_t best = LineSearch(in + i, static_cast<int64_t>(nz), y, ny, negative, own);
     out[i] = negative ? -best : best;
-  }
-}
-
-// Order-preserving float <-> uint32 map so min / max can use integer atomics.
-__device__ __forceinline__ uint32_t EncodeOrdered(float v)
-{
-  const uint32_t b = __float_as_uint(v);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float DecodeOrdered(uint32_t e)
-{
-  const uint32_t b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
-  return __uint_as_float(b);
-}
-
-}  // namespace
-
-// Final conversion shared by every X-pass implementation: squared voxel distance -> float SDF.
-// Matches signed_distance_field_generation.hpp:98-105 evaluated in double, and the
-// virtual-border branch (:134-284) through its closed form min(d2, b^2) with b the distance to
-// the nearest virtual border cell.
-__device__ __forceinline__ float FinalizeSdf(int32_t d2, bool negative, int x, int y, int z,
-                                             int nx, int ny, int nz, double resolution,
-                                             int add_virtual_border)
-{
-  if (add_virtual_border)
-  {
-    int32_t b = kInf32;
-    if (nx > 1) b = min(b, min(x + 1, nx - x));
-    if (ny > 1) b = min(b, min(y + 1, ny - y));
-    if (nz > 1) b = min(b, min(z + 1, nz - z));
-    if (b != kInf32) d2 = min(d2, b * b);
-  }
-  float dist;
-  if (d2 == kInf32)
-    dist = __uint_as_float(0x7f800000u);
-  else
-    dist = static_cast<float>(sqrt(static_cast<double>(d2)) * resolution);
-  return negative ? -dist : dist;
-}
-
-namespace
-{
-// Wave + block reduction of the ordered encodings, one atomic pair per block.
-__device__ __forceinline__ void BlockMinMax(uint32_t lo, uint32_t hi, uint32_t* minmax_enc)
-{
-  __shared__ uint32_t s_lo[16], s_hi[16];
-  for (int off = kWave / 2; off > 0; off >>= 1)
-  {
-    lo = min(lo, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), off)));
-    hi = max(hi, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), off)));
-  }
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  if (lane == 0)
-  {
-    s_lo[wave] = lo;
-    s_hi[wave] = hi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0)
-  {
-    const int nwaves = (blockDim.x + kWave - 1) / kWave;
-    for (int w = 1; w < nwaves; w++)
-    {
-      lo = min(lo, s_lo[w]);
-      hi = max(hi, s_hi[w]);
-    }
-    atomicMin(&minmax_enc[0], lo);
-    atomicMax(&minmax_enc[1], hi);
   }
 }
 
