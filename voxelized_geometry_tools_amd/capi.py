@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvgt_hip.so")
+LIB_PATH = os.environ.get("VGT_HIP_LIB") or os.path.join(_HERE, "libvgt_hip.so")  # override: diagnostic builds
 _LIB = None
 
 _i64 = ctypes.c_int64

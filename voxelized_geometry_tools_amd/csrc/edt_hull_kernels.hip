@@ -23,8 +23,27 @@
 // The domination predicate is evaluated in 64-bit integers, never as a quotient.
 #include "edt_device.hpp"
 
+#include <cstdlib>
+
 namespace vgt
 {
+#ifdef VGT_HULL_STATS
+// Diagnostic build only (make STATS=1): per-phase cycle sums and operation counts.
+// [0..4] cycles load/local/merge/eval/total (thread 0 of each workgroup), [5] workgroups,
+// [6] mask words read, [7] predicate tests, [8] local pops, [9] merge kills,
+// [10] bisection steps, [11] evaluation advances, [12] longest merge walk (max)
+__device__ unsigned long long g_hull_stats[32];  // [0..15] Y pass, [16..31] X pass
+__device__ int g_hull_stats_base;
+#define VGT_STAT_ADD(i, v) atomicAdd(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
+#define VGT_STAT_MAX(i, v) atomicMax(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
+#define VGT_STAT_LOCAL(name) unsigned int name = 0
+#define VGT_STAT_INC(name) (name)++
+#else
+#define VGT_STAT_ADD(i, v)
+#define VGT_STAT_MAX(i, v)
+#define VGT_STAT_LOCAL(name)
+#define VGT_STAT_INC(name)
+#endif
 namespace
 {
 constexpr int kBandRows = 32;
@@ -55,6 +74,9 @@ struct Tile
   // Rows that are sites for a run of class `neg`: survivors, plus every voxel of the other class.
   __device__ __forceinline__ uint32_t KWord(int j, bool neg) const
   {
+#ifdef VGT_HULL_STATS
+    atomicAdd(&g_hull_stats[g_hull_stats_base + 6], 1ull);
+#endif
     const uint32_t s = S[j * W + w];
     const uint32_t a = A[j * W + w];
     const int tail = n - (j << 5);
@@ -125,6 +147,9 @@ struct Tile
 // test `s <= z[k]` of signed_distance_field_generation.cpp:193-197.
 __device__ __forceinline__ bool Dominated(int32_t Ga, int a, int32_t Gb, int b, int32_t Gc, int c)
 {
+#ifdef VGT_HULL_STATS
+  atomicAdd(&g_hull_stats[g_hull_stats_base + 7], 1ull);
+#endif
   const int64_t lhs = static_cast<int64_t>(Gc - Gb) * static_cast<int64_t>(b - a);
   const int64_t rhs = static_cast<int64_t>(Gb - Ga) * static_cast<int64_t>(c - b);
   return lhs <= rhs;
@@ -141,6 +166,8 @@ struct HullGeom
   int pass_axis;         // 0 = X pass (outer = y), 1 = Y pass (outer = x)
   double resolution;
   int add_virtual_border;
+  int vector_io;         // rows and base pointers are 16-byte aligned
+  int debug_skip;        // timing experiments only (VGT_HULL_SKIP): 1 merges, 2 evaluation, 4 pops
 };
 
 template <typename InT, typename OutT, bool kFinal, int W>
@@ -166,18 +193,90 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int band = threadIdx.x / W;
   const int z = z0 + t.w;
   const bool active = (band < nwords) && (z < g.nz);
+#ifdef VGT_HULL_STATS
+  const long long clk0 = clock64();
+#endif
 
-  // ---- load: rows are contiguous 4*W-byte (2*W for int16) segments ----
-  for (int e = threadIdx.x; e < n * W; e += blockDim.x)
+  // ---- load: rows are contiguous 4*W-byte (2*W for int16) segments; 16-byte chunks per
+  // lane when the tile is full and aligned, several loads in flight per lane either way ----
   {
-    const int row = e / W;
-    const int ww = e % W;
-    int32_t v = kInf32;
-    if (z0 + ww < g.nz) v = ToSignedSquare(in[base + static_cast<int64_t>(row) * g.row_stride + ww]);
-    t.F[e] = v;
+    constexpr int kVec = 16 / static_cast<int>(sizeof(InT));  // elements per 16-byte chunk
+    constexpr int kChunksPerRow = W / kVec;
+    constexpr int kBatch = 4;
+    if (g.vector_io && (z0 + W <= g.nz))
+    {
+      using Chunk = __attribute__((__vector_size__(16))) int;
+      const int total = n * kChunksPerRow;
+      for (int c0 = threadIdx.x; c0 < total; c0 += blockDim.x * kBatch)
+      {
+        Chunk buf[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+        {
+          const int c = c0 + k * blockDim.x;
+          if (c < total)
+          {
+            const int row = c / kChunksPerRow;
+            const int part = c % kChunksPerRow;
+            buf[k] = *reinterpret_cast<const Chunk*>(
+                in + base + static_cast<int64_t>(row) * g.row_stride + part * kVec);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+        {
+          const int c = c0 + k * blockDim.x;
+          if (c < total)
+          {
+            const int row = c / kChunksPerRow;
+            const int part = c % kChunksPerRow;
+            const InT* vals = reinterpret_cast<const InT*>(&buf[k]);
+            int32_t* dst = t.F + row * W + part * kVec;
+#pragma unroll
+            for (int u = 0; u < kVec; u += 4)
+            {
+              int4 q;
+              q.x = ToSignedSquare(vals[u + 0]);
+              q.y = ToSignedSquare(vals[u + 1]);
+              q.z = ToSignedSquare(vals[u + 2]);
+              q.w = ToSignedSquare(vals[u + 3]);
+              *reinterpret_cast<int4*>(dst + u) = q;
+            }
+          }
+        }
+      }
+    }
+    else
+    {
+      constexpr int kScalarBatch = 8;
+      const int total = n * W;
+      for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * kScalarBatch)
+      {
+        InT buf[kScalarBatch];
+#pragma unroll
+        for (int k = 0; k < kScalarBatch; k++)
+        {
+          const int e = e0 + k * blockDim.x;
+          const int row = e / W;
+          const int ww = e % W;
+          buf[k] = InT(0);
+          if (e < total && z0 + ww < g.nz)
+            buf[k] = in[base + static_cast<int64_t>(row) * g.row_stride + ww];
+        }
+#pragma unroll
+        for (int k = 0; k < kScalarBatch; k++)
+        {
+          const int e = e0 + k * blockDim.x;
+          if (e < total) t.F[e] = (z0 + (e % W) < g.nz) ? ToSignedSquare(buf[k]) : kInf32;
+        }
+      }
+    }
   }
   __syncthreads();
 
+#ifdef VGT_HULL_STATS
+  const long long clk1 = clock64();
+#endif
   const int r0 = band * kBandRows;
   const int r1 = min(r0 + kBandRows, n);
   uint32_t sbits = 0;
@@ -191,6 +290,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     int32_t Gtop = 0, Gsec = 0;
 
     auto pop = [&]() {
+      VGT_STAT_ADD(8, 1);
       abits &= ~(1u << (top - r0));
       top = sec;
       Gtop = Gsec;
@@ -252,7 +352,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (f != kInf32)
       {
         const int32_t Gc = f + r * r;
-        while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gc, r)) pop();
+        while (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r)) pop();
         sec = top;
         Gsec = Gtop;
         top = r;
@@ -270,10 +370,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   }
   __syncthreads();
 
+#ifdef VGT_HULL_STATS
+  const long long clk2 = clock64();
+#endif
   // ---- 2. merge hulls of adjacent blocks, doubling the block size each level ----
   for (int half = 1; half < nwords; half <<= 1)
   {
-    if (active && (band % (2 * half)) == half)
+    if (active && !(g.debug_skip & 1) && (band % (2 * half)) == half)
     {
       const int R = r0;  // first row of the right block
       const bool neg = t.Neg(R);
@@ -285,6 +388,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         int j = t.NextSite(R - 1, hi, neg);
         if (i >= 0 && j >= 0)
         {
+          VGT_STAT_LOCAL(walk);
           bool mi, mj, ma, mc;
           int32_t Gi = t.SiteF(i, neg, mi) + i * i;
           int32_t Gj = t.SiteF(j, neg, mj) + j * j;
@@ -297,6 +401,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             if (a >= 0 && Dominated(Ga, a, Gi, i, Gj, j))
             {
               t.Kill(i);
+              VGT_STAT_INC(walk);
               i = a;
               Gi = Ga;
               mi = ma;
@@ -307,6 +412,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             if (c >= 0 && Dominated(Gi, i, Gj, j, Gc, c))
             {
               t.Kill(j);
+              VGT_STAT_INC(walk);
               j = c;
               Gj = Gc;
               mj = mc;
@@ -316,15 +422,22 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             }
             break;
           }
+#ifdef VGT_HULL_STATS
+          VGT_STAT_ADD(9, walk);
+          VGT_STAT_MAX(12, walk);
+#endif
         }
       }
     }
     __syncthreads();
   }
 
+#ifdef VGT_HULL_STATS
+  const long long clk3 = clock64();
+#endif
   // ---- 3. evaluate this band's rows against the final hull, store ----
   uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
-  if (active)
+  if (active && !(g.debug_skip & 2))
   {
     bool neg = false, have = false;
     int cur = -1, nxt = -1;
@@ -348,38 +461,47 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           if (cur < 0) cur = t.NextSite(r, n, neg);
           if (cur >= 0)
           {
+            // The owner o of row r satisfies (r-o)^2 <= value of ANY site at r, so it lies
+            // within R rows of r.  Along the hull "the successor is strictly better at r" holds
+            // exactly for the sites before the owner, so bisect on the row position.
             fcur = t.SiteF(cur, neg, mcur);
-            int32_t vcur = (r - cur) * (r - cur) + fcur;
-            bool moved = false;
-            while (mcur || cur > r)
+            const int32_t v0 = (r - cur) * (r - cur) + fcur;
+            const int R = static_cast<int>(sqrtf(static_cast<float>(v0))) + 1;
+            int lo = max(r - R, 0);
+            int hi = min(r + R, n - 1);
+            while (lo < hi)
             {
-              const int p = t.PrevSite(cur, 0, neg);
-              if (p < 0) break;
-              bool mp;
-              const int32_t fp = t.SiteF(p, neg, mp);
-              const int32_t vp = (r - p) * (r - p) + fp;
-              if (vp >= vcur) break;
-              cur = p;
-              fcur = fp;
-              vcur = vp;
-              mcur = mp;
-              moved = true;
-            }
-            if (!moved)
-            {
-              while (mcur || cur < r)
+              VGT_STAT_ADD(10, 1);
+              const int mid = (lo + hi) >> 1;
+              bool successor_better = true;  // no site at or below mid: the owner is above
+              const int h = t.PrevSite(mid + 1, 0, neg);
+              if (h >= 0)
               {
-                const int q = t.NextSite(cur, n, neg);
-                if (q < 0) break;
-                bool mq;
-                const int32_t fq = t.SiteF(q, neg, mq);
-                const int32_t vq = (r - q) * (r - q) + fq;
-                if (vq >= vcur) break;
-                cur = q;
-                fcur = fq;
-                vcur = vq;
-                mcur = mq;
+                bool mh;
+                const int32_t fh = t.SiteF(h, neg, mh);
+                successor_better = false;
+                if (mh || h < r)
+                {
+                  const int hn = t.NextSite(h, n, neg);
+                  if (hn >= 0)
+                  {
+                    bool mhn;
+                    const int32_t fhn = t.SiteF(hn, neg, mhn);
+                    successor_better =
+                        ((r - hn) * (r - hn) + fhn) < ((r - h) * (r - h) + fh);
+                  }
+                }
               }
+              if (successor_better)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+            const int owner = t.PrevSite(lo + 1, 0, neg);
+            if (owner >= 0)
+            {
+              cur = owner;
+              fcur = t.SiteF(cur, neg, mcur);
             }
           }
         }
@@ -404,6 +526,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           const int32_t vn = (r - nxt) * (r - nxt) + fnxt;
           if (vn >= best) break;
           cur = nxt;
+          VGT_STAT_ADD(11, 1);
           fcur = fnxt;
           best = vn;
           const bool member = (t.Raw(cur) < 0) == neg;
@@ -434,6 +557,19 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     }
   }
   if constexpr (kFinal) BlockMinMax(lo_enc, hi_enc, minmax_enc);
+#ifdef VGT_HULL_STATS
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const long long clk4 = clock64();
+    VGT_STAT_ADD(0, clk1 - clk0);
+    VGT_STAT_ADD(1, clk2 - clk1);
+    VGT_STAT_ADD(2, clk3 - clk2);
+    VGT_STAT_ADD(3, clk4 - clk3);
+    VGT_STAT_ADD(4, clk4 - clk0);
+    VGT_STAT_ADD(5, 1);
+  }
+#endif
 }
 
 // Lines per tile for n rows: the F tile (n * W * 4 bytes) must fit in 128 KiB of LDS and the
@@ -461,6 +597,15 @@ hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const Hull
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
   if (err != hipSuccess) return err;
+#ifdef VGT_HULL_STATS
+  {
+    const int stats_base = kFinal ? 16 : 0;
+    err = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_hull_stats_base), &stats_base, sizeof(int), 0,
+                                 hipMemcpyHostToDevice, stream);
+    if (err != hipSuccess) return err;
+    (void)hipStreamSynchronize(stream);
+  }
+#endif
   const int64_t blocks = outer_count * g.ztiles;
   hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), lds, stream, in,
                      out, minmax_enc, g);
@@ -475,6 +620,10 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
+  static const int debug_skip = getenv("VGT_HULL_SKIP") ? atoi(getenv("VGT_HULL_SKIP")) : 0;
+  g.debug_skip = debug_skip;
+  constexpr int kVec = 16 / static_cast<int>(sizeof(InT));
+  g.vector_io = (g.nz % kVec == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (W % kVec == 0);
   if (outer_count * g.ztiles > 0x7fffffffLL)
   {
     *handled = false;
@@ -524,3 +673,18 @@ hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* mi
   return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, p.ny, stream, handled);
 }
 }  // namespace vgt
+
+#ifdef VGT_HULL_STATS
+// Diagnostic build only: read (and clear) the counters.
+extern "C" int vgt_hip_debug_hull_stats(unsigned long long* out32, int reset)
+{
+  hipError_t err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_hull_stats), 32 * sizeof(unsigned long long));
+  if (err == hipSuccess && reset)
+  {
+    unsigned long long zeros[32] = {0};
+    err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_hull_stats), zeros, sizeof(zeros));
+  }
+  return err == hipSuccess ? 0 : 2;
+}
+#endif
