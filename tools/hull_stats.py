@@ -19,8 +19,8 @@ import torch
 import bench
 from voxelized_geometry_tools_amd import capi
 
-NAMES = ["cyc_load", "cyc_local", "cyc_merge", "cyc_eval", "cyc_total", "workgroups", "mask_words",
-         "predicates", "local_pops", "merge_kills", "bisect_steps", "eval_advances", "max_merge_walk"]
+NAMES = ["cyc_load", "cyc_local", "cyc_merge", "cyc_starts", "cyc_eval", "workgroups", "cyc_total",
+         "predicates", "local_pops", "merge_kills", "survivors", "-", "max_merge_walk"]
 
 
 def main():
@@ -46,8 +46,8 @@ def main():
         wg = max(vals[5], 1)
         print("== %s (%s^3 %s): %d workgroups" % (name, size, dist, vals[5]))
         for i in range(5):
-            print("  %-12s %10.0f cycles/WG  %5.1f %%" % (NAMES[i], vals[i] / wg, 100.0 * vals[i] / max(vals[4], 1)))
-        for i in range(6, 12):
+            print("  %-12s %10.0f cycles/WG  %5.1f %%" % (NAMES[i], vals[i] / wg, 100.0 * vals[i] / max(vals[6], 1)))
+        for i in range(7, 11):
             print("  %-14s %14d  %8.3f per voxel" % (NAMES[i], vals[i], vals[i] / vox))
         print("  %-14s %14d" % (NAMES[12], vals[12]))
 

@@ -8,19 +8,26 @@
 //
 // Per line the pass computes, for every row q, min over sites o of (q-o)^2 + f(o), where the
 // sites seen by a voxel of one class are the voxels of its own class with their value so far
-// and every voxel of the other class with value 0.  A zero-valued site shields everything
-// behind it, so a line splits into maximal same-class RUNS that are independent envelope
-// problems: sites = members of the run + the one voxel of the other class on either side.
-// Total work is one Felzenszwalb-Huttenlocher sweep per line for both classes together.
+// ("members", value f) and every voxel of the other class with value 0.  A zero-valued site
+// shields everything behind it, so a line splits into maximal same-class RUNS [a, b] and
+//     out(q) = min( lower envelope of the run's members at q, (q-(a-1))^2, ((b+1)-q)^2 ),
+// i.e. one Felzenszwalb-Huttenlocher envelope per run over members only, plus the distance to
+// the two voxels of the other class that bound the run (when they exist).
 //
 // Parallelisation inside a line: the line is cut into bands of 32 rows, one thread per
-// (line, band); lanes of a wave are different lines (neighbouring Z), which keeps them in
-// near lockstep.  The envelope is kept as a bit mask (bit = site survives), one 32-bit word
-// per band, so "pop" is clearing a bit and stack neighbours are clz/ffs:
-//   1. each thread builds the hull of its band (stack algorithm, exact integer predicate),
-//   2. hulls of adjacent bands are merged pairwise (log2(bands) levels, tangent walk),
-//   3. each thread walks the final hull to evaluate its 32 rows and stores them.
-// The domination predicate is evaluated in 64-bit integers, never as a quotient.
+// (line, band); lanes of a wave are different lines (neighbouring Z).  An envelope is a bit mask
+// (bit = member survives), one 32-bit word per band, so "pop" clears a bit and stack neighbours
+// are clz/ffs; a per-line summary word skips empty mask words.  Phases (workgroup barriers
+// between them):
+//   1  each thread builds the hull of its band (stack algorithm, exact integer predicate)
+//   1b per-word carries of the nearest row of either class below/above (wave scans)
+//   2  hulls of adjacent blocks are merged pairwise (log2(bands) levels, tangent walk)
+//   2b every surviving member computes the first row it owns (exact floor division); members
+//      that own no row are dropped, the others set a "start" bit at that row
+//   2c per-word prefix counts of survivors and of start bits (wave scans)
+//   3  each thread evaluates its 32 rows: the owner of a row is the k-th survivor, k = number of
+//      start bits at or below the row (rank / select), then advances at every start bit.
+// All predicates are integer-exact (64-bit cross multiplication / exact floor of a quotient).
 #include "edt_device.hpp"
 
 #include <cstdlib>
@@ -29,115 +36,121 @@ namespace vgt
 {
 #ifdef VGT_HULL_STATS
 // Diagnostic build only (make STATS=1): per-phase cycle sums and operation counts.
-// [0..4] cycles load/local/merge/eval/total (thread 0 of each workgroup), [5] workgroups,
-// [6] mask words read, [7] predicate tests, [8] local pops, [9] merge kills,
-// [10] bisection steps, [11] evaluation advances, [12] longest merge walk (max)
+// [0..4] cycles load/local/merge/starts/eval, [5] workgroups, [6] total cycles,
+// [7] predicate tests, [8] local pops, [9] merge kills, [10] survivors after 2b,
+// [12] longest merge walk (max)
 __device__ unsigned long long g_hull_stats[32];  // [0..15] Y pass, [16..31] X pass
 __device__ int g_hull_stats_base;
-#define VGT_STAT_ADD(i, v) atomicAdd(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
-#define VGT_STAT_MAX(i, v) atomicMax(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
-#define VGT_STAT_LOCAL(name) unsigned int name = 0
-#define VGT_STAT_INC(name) (name)++
+#define VGT_STAT_ADD(i, v) \
+  atomicAdd(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
+#define VGT_STAT_MAX(i, v) \
+  atomicMax(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
 #else
 #define VGT_STAT_ADD(i, v)
 #define VGT_STAT_MAX(i, v)
-#define VGT_STAT_LOCAL(name)
-#define VGT_STAT_INC(name)
 #endif
 namespace
 {
 constexpr int kBandRows = 32;
 
+__device__ __forceinline__ uint32_t LowMask(int bits)  // bits in [0, 32]
+{
+  return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
+}
+
 template <int W>
 struct Tile
 {
-  int32_t* F;   // [n][W]  signed squared value (sign = class, |.| = distance^2 or kInf32)
-  uint32_t* S;  // [nwords][W] sign bits (1 = negative class)
-  uint32_t* A;  // [nwords][W] survivor bits
+  int32_t* F;          // [n][W]  signed squared value (sign = class, |.| = distance^2 or kInf32)
+  uint32_t* S;         // [nwords][W] sign bits (1 = negative class)
+  uint32_t* A;         // [nwords][W] hull bits while merging
+  uint32_t* A2;        // [nwords][W] members that own at least one row
+  uint32_t* T;         // [nwords][W] start bits
+  int16_t* last_neg;   // [nwords][W] highest negative row below the word, -1 if none
+  int16_t* last_pos;   //             same for positive rows
+  int16_t* next_neg;   // [nwords][W] lowest negative row above the word, n if none
+  int16_t* next_pos;
+  uint16_t* cumA;      // [nwords][W] survivors in lower words
+  uint16_t* cumT;      // [nwords][W] start bits in lower words
+  uint64_t* sumA;      // [W] words of A that may be non-empty (superset)
+  uint64_t* sumA2;     // [W] words of A2 that are non-empty
   int n;
   int nwords;
   int w;  // this thread's line
 
   __device__ __forceinline__ int32_t Raw(int row) const { return F[row * W + w]; }
+  __device__ __forceinline__ int32_t Mag(int row) const
+  {
+    const int32_t v = Raw(row);
+    return v < 0 ? -v : v;
+  }
+  __device__ __forceinline__ uint32_t Valid(int j) const { return LowMask(n - (j << 5)); }
   __device__ __forceinline__ bool Neg(int row) const
   {
     return (S[(row >> 5) * W + w] >> (row & 31)) & 1u;
   }
-  // Value of `row` as a site of a run of class `neg`: members carry their value, voxels of the
-  // other class are zero-valued sites.
-  __device__ __forceinline__ int32_t SiteF(int row, bool neg, bool& member) const
+  // nearest row of the OTHER class strictly below `row` (-1 if none)
+  __device__ __forceinline__ int PrevOpp(int row, bool neg) const
   {
-    const int32_t v = Raw(row);
-    member = (v < 0) == neg;
-    return member ? (v < 0 ? -v : v) : 0;
-  }
-  // Rows that are sites for a run of class `neg`: survivors, plus every voxel of the other class.
-  __device__ __forceinline__ uint32_t KWord(int j, bool neg) const
-  {
-#ifdef VGT_HULL_STATS
-    atomicAdd(&g_hull_stats[g_hull_stats_base + 6], 1ull);
-#endif
+    const int j = row >> 5;
     const uint32_t s = S[j * W + w];
-    const uint32_t a = A[j * W + w];
-    const int tail = n - (j << 5);
-    const uint32_t valid = (tail >= 32) ? ~0u : ((1u << tail) - 1u);
-    return (a | (neg ? ~s : s)) & valid;
+    const uint32_t m = (neg ? ~s : s) & LowMask(row & 31);
+    if (m) return (j << 5) + 31 - __clz(static_cast<int>(m));
+    return neg ? last_pos[j * W + w] : last_neg[j * W + w];
   }
-  // highest site row in [lo, r), or -1
-  __device__ int PrevK(int r, int lo, bool neg) const
+  // nearest row of the OTHER class strictly above `row` (n if none)
+  __device__ __forceinline__ int NextOpp(int row, bool neg) const
+  {
+    const int j = row >> 5;
+    const uint32_t s = S[j * W + w];
+    const uint32_t m = (neg ? ~s : s) & Valid(j) & ~LowMask((row & 31) + 1);
+    if (m) return (j << 5) + __ffs(static_cast<int>(m)) - 1;
+    return neg ? next_pos[j * W + w] : next_neg[j * W + w];
+  }
+  // highest set bit of mask M over rows [lo, r), or -1
+  __device__ int PrevBit(const uint32_t* M, const uint64_t* sum, int r, int lo) const
   {
     if (r <= lo) return -1;
-    int j = (r - 1) >> 5;
+    const int j = (r - 1) >> 5;
     const int jlo = lo >> 5;
-    uint32_t m = KWord(j, neg);
-    const int rb = r - (j << 5);
-    if (rb < 32) m &= (1u << rb) - 1u;
-    for (;;)
+    uint32_t m = M[j * W + w] & LowMask(r - (j << 5));
+    if (j == jlo) m &= ~LowMask(lo & 31);
+    if (m) return (j << 5) + 31 - __clz(static_cast<int>(m));
+    if (j == jlo) return -1;
+    uint64_t cand = sum[w] & ((1ull << j) - 1ull) & ~((1ull << jlo) - 1ull);
+    while (cand)
     {
-      if (j == jlo) m &= ~((1u << (lo & 31)) - 1u);
-      if (m) return (j << 5) + 31 - __clz(static_cast<int>(m));
-      if (j == jlo) return -1;
-      j--;
-      m = KWord(j, neg);
+      const int jj = 63 - __clzll(static_cast<long long>(cand));
+      m = M[jj * W + w];
+      if (jj == jlo) m &= ~LowMask(lo & 31);
+      if (m) return (jj << 5) + 31 - __clz(static_cast<int>(m));
+      cand &= ~(1ull << jj);
     }
+    return -1;
   }
-  // lowest site row in (r, hi), or -1
-  __device__ int NextK(int r, int hi, bool neg) const
+  // lowest set bit of mask M over rows (r, hi), or -1  (r may be -1)
+  __device__ int NextBit(const uint32_t* M, const uint64_t* sum, int r, int hi) const
   {
     const int start = r + 1;
     if (start >= hi) return -1;
-    int j = start >> 5;
+    const int j = start >> 5;
     const int jhi = (hi - 1) >> 5;
-    uint32_t m = KWord(j, neg) & ~((1u << (start & 31)) - 1u);
-    for (;;)
+    uint32_t m = M[j * W + w] & ~LowMask(start & 31);
+    if (j == jhi) m &= LowMask(hi - (j << 5));
+    if (m) return (j << 5) + __ffs(static_cast<int>(m)) - 1;
+    if (j == jhi) return -1;
+    uint64_t cand = sum[w] & ~((2ull << j) - 1ull);
+    if (jhi < 63) cand &= (2ull << jhi) - 1ull;
+    while (cand)
     {
-      if (j == jhi)
-      {
-        const int hb = hi - (j << 5);
-        if (hb < 32) m &= (1u << hb) - 1u;
-      }
-      if (m) return (j << 5) + __ffs(static_cast<int>(m)) - 1;
-      if (j == jhi) return -1;
-      j++;
-      m = KWord(j, neg);
+      const int jj = __ffsll(static_cast<long long>(cand)) - 1;
+      m = M[jj * W + w];
+      if (jj == jhi) m &= LowMask(hi - (jj << 5));
+      if (m) return (jj << 5) + __ffs(static_cast<int>(m)) - 1;
+      cand &= cand - 1ull;
     }
+    return -1;
   }
-  // Neighbour in the site list of the run, restricted to the block [lo, hi) being worked on.
-  // The voxel of the other class just outside the block belongs to the list of the block that
-  // holds the adjacent end of the run.
-  __device__ __forceinline__ int PrevSite(int r, int lo, bool neg) const
-  {
-    int p = PrevK(r, lo, neg);
-    if (p < 0 && lo > 0 && ((Raw(lo - 1) < 0) != neg)) p = lo - 1;
-    return p;
-  }
-  __device__ __forceinline__ int NextSite(int r, int hi, bool neg) const
-  {
-    int p = NextK(r, hi, neg);
-    if (p < 0 && hi < n && ((Raw(hi) < 0) != neg)) p = hi;
-    return p;
-  }
-  __device__ __forceinline__ void Kill(int row) { A[(row >> 5) * W + w] &= ~(1u << (row & 31)); }
 };
 
 // Site b (between a and c) never owns a point of the envelope: with G(v) = f(v) + v^2 the
@@ -147,12 +160,21 @@ struct Tile
 // test `s <= z[k]` of signed_distance_field_generation.cpp:193-197.
 __device__ __forceinline__ bool Dominated(int32_t Ga, int a, int32_t Gb, int b, int32_t Gc, int c)
 {
-#ifdef VGT_HULL_STATS
-  atomicAdd(&g_hull_stats[g_hull_stats_base + 7], 1ull);
-#endif
+  VGT_STAT_ADD(7, 1);
   const int64_t lhs = static_cast<int64_t>(Gc - Gb) * static_cast<int64_t>(b - a);
   const int64_t rhs = static_cast<int64_t>(Gb - Ga) * static_cast<int64_t>(c - b);
   return lhs <= rhs;
+}
+
+// First row at which site h beats its predecessor p (p < h): smallest integer q with
+// (q-h)^2 + f(h) < (q-p)^2 + f(p)  <=>  q > (Gh - Gp) / (2 (h - p)).
+// |Gh - Gp| < 2^31 and the divisor < 2^16, so the double quotient is correctly rounded and its
+// floor is exact (an exactly integral quotient is computed exactly).
+__device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int h)
+{
+  const double q = floor(static_cast<double>(Gh - Gp) / static_cast<double>(2 * (h - p)));
+  // clamp before converting: the caller clamps to the run anyway
+  return static_cast<int>(fmin(fmax(q, -2.0), 1.0e6)) + 1;
 }
 
 struct HullGeom
@@ -170,7 +192,18 @@ struct HullGeom
   int debug_skip;        // timing experiments only (VGT_HULL_SKIP): 1 merges, 2 evaluation, 4 pops
 };
 
-template <typename InT, typename OutT, bool kFinal, int W>
+// Bytes of dynamic LDS for a tile of n rows x W lines.
+template <int W>
+size_t TileBytes(int n)
+{
+  const size_t nwords = static_cast<size_t>((n + kBandRows - 1) / kBandRows);
+  return static_cast<size_t>(n) * W * sizeof(int32_t) + 4 * nwords * W * sizeof(uint32_t) +
+         4 * nwords * W * sizeof(int16_t) + 2 * nwords * W * sizeof(uint16_t) +
+         2 * W * sizeof(uint64_t);
+}
+
+// SW = lanes used per line in the transposed scans (32 when a line has <= 32 words, else 64).
+template <typename InT, typename OutT, bool kFinal, int W, int SW>
 __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ in,
                                                       OutT* __restrict__ out,
                                                       uint32_t* __restrict__ minmax_enc,
@@ -179,10 +212,21 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   extern __shared__ __align__(16) unsigned char smem[];
   const int n = g.n;
   const int nwords = (n + kBandRows - 1) / kBandRows;
+  const int mw = nwords * W;
   Tile<W> t;
   t.F = reinterpret_cast<int32_t*>(smem);
-  t.S = reinterpret_cast<uint32_t*>(t.F + static_cast<size_t>(n) * W);
-  t.A = t.S + static_cast<size_t>(nwords) * W;
+  t.sumA = reinterpret_cast<uint64_t*>(t.F + static_cast<size_t>(n) * W);
+  t.sumA2 = t.sumA + W;
+  t.S = reinterpret_cast<uint32_t*>(t.sumA2 + W);
+  t.A = t.S + mw;
+  t.A2 = t.A + mw;
+  t.T = t.A2 + mw;
+  t.last_neg = reinterpret_cast<int16_t*>(t.T + mw);
+  t.last_pos = t.last_neg + mw;
+  t.next_neg = t.last_pos + mw;
+  t.next_pos = t.next_neg + mw;
+  t.cumA = reinterpret_cast<uint16_t*>(t.next_pos + mw);
+  t.cumT = t.cumA + mw;
   t.n = n;
   t.nwords = nwords;
   t.w = threadIdx.x % W;
@@ -197,7 +241,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const long long clk0 = clock64();
 #endif
 
-  // ---- load: rows are contiguous 4*W-byte (2*W for int16) segments; 16-byte chunks per
+  // ---- 0. load: rows are contiguous 4*W-byte (2*W for int16) segments; 16-byte chunks per
   // lane when the tile is full and aligned, several loads in flight per lane either way ----
   {
     constexpr int kVec = 16 / static_cast<int>(sizeof(InT));  // elements per 16-byte chunk
@@ -273,151 +317,166 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     }
   }
   __syncthreads();
-
 #ifdef VGT_HULL_STATS
   const long long clk1 = clock64();
 #endif
+
   const int r0 = band * kBandRows;
   const int r1 = min(r0 + kBandRows, n);
   uint32_t sbits = 0;
 
-  // ---- 1. hull of this band ----
-  if (active)
+  // ---- 1. hull of this band, members only; the stack restarts at every class change ----
+  if (band < nwords)
   {
     uint32_t abits = 0;
-    bool neg = false, have_run = false;
-    int top = -1, sec = -1, zero_bottom = -1, run_bit0 = 0;
-    int32_t Gtop = 0, Gsec = 0;
-
-    auto pop = [&]() {
-      VGT_STAT_ADD(8, 1);
-      abits &= ~(1u << (top - r0));
-      top = sec;
-      Gtop = Gsec;
-      if (top == zero_bottom)
-        sec = -1;
-      else
-      {
-        const uint32_t m = abits & ((1u << (top - r0)) - 1u) & ~((1u << run_bit0) - 1u);
-        if (m)
-        {
-          sec = r0 + 31 - __clz(static_cast<int>(m));
-          const int32_t v = t.Raw(sec);
-          Gsec = (v < 0 ? -v : v) + sec * sec;
-        }
-        else if (zero_bottom >= 0)
-        {
-          sec = zero_bottom;
-          Gsec = zero_bottom * zero_bottom;
-        }
-        else
-          sec = -1;
-      }
-    };
-
-    for (int r = r0; r < r1; r++)
+    if (z < g.nz)
     {
-      const int32_t v = t.Raw(r);
-      const bool sneg = v < 0;
-      const int32_t f = sneg ? -v : v;
-      if (sneg) sbits |= 1u << (r - r0);
-      if (!have_run || sneg != neg)
+      bool neg = false, have_run = false;
+      int top = -1, sec = -1, run_bit0 = 0;
+      int32_t Gtop = 0, Gsec = 0;
+      for (int r = r0; r < r1; r++)
       {
-        bool left_zero;
-        if (have_run)
+        const int32_t v = t.Raw(r);
+        const bool sneg = v < 0;
+        const int32_t f = sneg ? -v : v;
+        if (sneg) sbits |= 1u << (r - r0);
+        if (!have_run || sneg != neg)
         {
-          // the voxel at r (other class) closes the run that ends at r-1
-          const int32_t Gc = r * r;
-          while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gc, r)) pop();
-          left_zero = true;
+          neg = sneg;
+          have_run = true;
+          top = sec = -1;
+          run_bit0 = r - r0;
         }
-        else
-          left_zero = (r0 > 0) && ((t.Raw(r0 - 1) < 0) != sneg);
-        neg = sneg;
-        have_run = true;
-        sec = -1;
-        run_bit0 = r - r0;
-        if (left_zero)
+        if (f != kInf32)
         {
-          top = r - 1;
-          Gtop = (r - 1) * (r - 1);
-          zero_bottom = r - 1;
-        }
-        else
-        {
-          top = -1;
-          zero_bottom = -1;
+          const int32_t Gc = f + r * r;
+          while (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
+          {
+            VGT_STAT_ADD(8, 1);
+            abits &= ~(1u << (top - r0));
+            top = sec;
+            Gtop = Gsec;
+            const uint32_t m = abits & LowMask(top - r0) & ~LowMask(run_bit0);
+            if (m)
+            {
+              sec = r0 + 31 - __clz(static_cast<int>(m));
+              Gsec = t.Mag(sec) + sec * sec;
+            }
+            else
+              sec = -1;
+          }
+          sec = top;
+          Gsec = Gtop;
+          top = r;
+          Gtop = Gc;
+          abits |= 1u << (r - r0);
         }
       }
-      if (f != kInf32)
-      {
-        const int32_t Gc = f + r * r;
-        while (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r)) pop();
-        sec = top;
-        Gsec = Gtop;
-        top = r;
-        Gtop = Gc;
-        abits |= 1u << (r - r0);
-      }
-    }
-    if (r1 < n && ((t.Raw(r1) < 0) != neg))
-    {
-      const int32_t Gc = r1 * r1;
-      while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gc, r1)) pop();
     }
     t.S[band * W + t.w] = sbits;
     t.A[band * W + t.w] = abits;
+    t.T[band * W + t.w] = 0u;
   }
   __syncthreads();
 
+  // ---- 1b. per word: nearest row of either class below / above, and the summary of A ----
+  for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
+  {
+    const int line = tt / SW;
+    const int j = tt % SW;
+    const bool ok = j < nwords;
+    const uint32_t s = ok ? t.S[j * W + line] : 0u;
+    const uint32_t p = ok ? (~s & LowMask(n - (j << 5))) : 0u;
+    const uint32_t a = ok ? t.A[j * W + line] : 0u;
+    int hi_neg = s ? (j << 5) + 31 - __clz(static_cast<int>(s)) : -1;
+    int hi_pos = p ? (j << 5) + 31 - __clz(static_cast<int>(p)) : -1;
+    int lo_neg = s ? (j << 5) + __ffs(static_cast<int>(s)) - 1 : n;
+    int lo_pos = p ? (j << 5) + __ffs(static_cast<int>(p)) - 1 : n;
+    for (int d = 1; d < SW; d <<= 1)
+    {
+      const int un = __shfl_up(hi_neg, d, SW), up = __shfl_up(hi_pos, d, SW);
+      const int dn = __shfl_down(lo_neg, d, SW), dp = __shfl_down(lo_pos, d, SW);
+      if (j >= d)
+      {
+        hi_neg = max(hi_neg, un);
+        hi_pos = max(hi_pos, up);
+      }
+      if (j + d < SW)
+      {
+        lo_neg = min(lo_neg, dn);
+        lo_pos = min(lo_pos, dp);
+      }
+    }
+    // exclusive: shift by one word
+    const int ex_hn = __shfl_up(hi_neg, 1, SW), ex_hp = __shfl_up(hi_pos, 1, SW);
+    const int ex_ln = __shfl_down(lo_neg, 1, SW), ex_lp = __shfl_down(lo_pos, 1, SW);
+    const uint64_t any = __ballot(a != 0u);
+    if (ok)
+    {
+      t.last_neg[j * W + line] = static_cast<int16_t>(j == 0 ? -1 : ex_hn);
+      t.last_pos[j * W + line] = static_cast<int16_t>(j == 0 ? -1 : ex_hp);
+      t.next_neg[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_ln);
+      t.next_pos[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_lp);
+    }
+    if (j == 0)
+    {
+      const int sh = (threadIdx.x & 63) / SW * SW;  // 0 or 32 when SW == 32
+      t.sumA[line] = (SW == 64) ? any : ((any >> sh) & 0xffffffffull);
+    }
+  }
+  __syncthreads();
 #ifdef VGT_HULL_STATS
   const long long clk2 = clock64();
 #endif
+
   // ---- 2. merge hulls of adjacent blocks, doubling the block size each level ----
   for (int half = 1; half < nwords; half <<= 1)
   {
     if (active && !(g.debug_skip & 1) && (band % (2 * half)) == half)
     {
       const int R = r0;  // first row of the right block
-      const bool neg = t.Neg(R);
+      const bool neg = (sbits & 1u) != 0u;
       if (t.Neg(R - 1) == neg)  // the run continues across the block boundary
       {
-        const int lo = (band - half) * kBandRows;
-        const int hi = min((band + half) * kBandRows, n);
-        int i = t.PrevSite(R, lo, neg);
-        int j = t.NextSite(R - 1, hi, neg);
+        const int lo = max((band - half) * kBandRows, t.PrevOpp(R, neg) + 1);
+        const int hi = min(min((band + half) * kBandRows, n), t.NextOpp(R - 1, neg));
+        int i = t.PrevBit(t.A, t.sumA, R, lo);
+        int j = t.NextBit(t.A, t.sumA, R - 1, hi);
         if (i >= 0 && j >= 0)
         {
-          VGT_STAT_LOCAL(walk);
-          bool mi, mj, ma, mc;
-          int32_t Gi = t.SiteF(i, neg, mi) + i * i;
-          int32_t Gj = t.SiteF(j, neg, mj) + j * j;
-          int a = mi ? t.PrevSite(i, lo, neg) : -1;
-          int32_t Ga = (a >= 0) ? t.SiteF(a, neg, ma) + a * a : 0;
-          int c = mj ? t.NextSite(j, hi, neg) : -1;
-          int32_t Gc = (c >= 0) ? t.SiteF(c, neg, mc) + c * c : 0;
+#ifdef VGT_HULL_STATS
+          unsigned int walk = 0;
+#endif
+          int32_t Gi = t.Mag(i) + i * i;
+          int32_t Gj = t.Mag(j) + j * j;
+          int a = t.PrevBit(t.A, t.sumA, i, lo);
+          int32_t Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+          int c = t.NextBit(t.A, t.sumA, j, hi);
+          int32_t Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
           for (;;)
           {
             if (a >= 0 && Dominated(Ga, a, Gi, i, Gj, j))
             {
-              t.Kill(i);
-              VGT_STAT_INC(walk);
+              t.A[(i >> 5) * W + t.w] &= ~(1u << (i & 31));
               i = a;
               Gi = Ga;
-              mi = ma;
-              a = mi ? t.PrevSite(i, lo, neg) : -1;
-              Ga = (a >= 0) ? t.SiteF(a, neg, ma) + a * a : 0;
+              a = t.PrevBit(t.A, t.sumA, i, lo);
+              Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+#ifdef VGT_HULL_STATS
+              walk++;
+#endif
               continue;
             }
             if (c >= 0 && Dominated(Gi, i, Gj, j, Gc, c))
             {
-              t.Kill(j);
-              VGT_STAT_INC(walk);
+              t.A[(j >> 5) * W + t.w] &= ~(1u << (j & 31));
               j = c;
               Gj = Gc;
-              mj = mc;
-              c = mj ? t.NextSite(j, hi, neg) : -1;
-              Gc = (c >= 0) ? t.SiteF(c, neg, mc) + c * c : 0;
+              c = t.NextBit(t.A, t.sumA, j, hi);
+              Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
+#ifdef VGT_HULL_STATS
+              walk++;
+#endif
               continue;
             }
             break;
@@ -431,113 +490,159 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     }
     __syncthreads();
   }
-
 #ifdef VGT_HULL_STATS
   const long long clk3 = clock64();
 #endif
-  // ---- 3. evaluate this band's rows against the final hull, store ----
-  uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
-  if (active && !(g.debug_skip & 2))
+
+  // ---- 2b. first owned row of every hull member; drop members that own no row ----
+  if (band < nwords)
   {
-    bool neg = false, have = false;
-    int cur = -1, nxt = -1;
-    int32_t fcur = 0, fnxt = 0;
-    for (int r = r0; r < r1; r++)
+    uint32_t a2 = 0;
+    if (z < g.nz)
     {
-      const bool sneg = (sbits >> (r - r0)) & 1u;
-      if (!have || sneg != neg)
+      uint32_t bits = t.A[band * W + t.w];
+      int run_a = 0, run_b = -1;        // current run [run_a, run_b]
+      int nxt = -1, start_nxt = 0;      // cached successor of the previous member + its start
+      int32_t Gnxt = 0;
+      while (bits)
       {
-        neg = sneg;
-        bool mcur = false;
-        if (have)
+        const int h = r0 + __ffs(static_cast<int>(bits)) - 1;
+        bits &= bits - 1u;
+        int32_t Gh;
+        int start_h;
+        if (h > run_b)
         {
-          cur = r - 1;  // the voxel of the other class right before the run
-          fcur = 0;
+          const bool neg = (sbits >> (h - r0)) & 1u;
+          run_a = t.PrevOpp(h, neg) + 1;
+          run_b = t.NextOpp(h, neg) - 1;
+          nxt = -1;
+        }
+        if (nxt == h)
+        {
+          Gh = Gnxt;
+          start_h = start_nxt;
         }
         else
         {
-          // first row of the band: locate the owner of r in the hull of the run
-          cur = t.PrevSite(r + 1, 0, neg);
-          if (cur < 0) cur = t.NextSite(r, n, neg);
-          if (cur >= 0)
-          {
-            // The owner o of row r satisfies (r-o)^2 <= value of ANY site at r, so it lies
-            // within R rows of r.  Along the hull "the successor is strictly better at r" holds
-            // exactly for the sites before the owner, so bisect on the row position.
-            fcur = t.SiteF(cur, neg, mcur);
-            const int32_t v0 = (r - cur) * (r - cur) + fcur;
-            const int R = static_cast<int>(sqrtf(static_cast<float>(v0))) + 1;
-            int lo = max(r - R, 0);
-            int hi = min(r + R, n - 1);
-            while (lo < hi)
-            {
-              VGT_STAT_ADD(10, 1);
-              const int mid = (lo + hi) >> 1;
-              bool successor_better = true;  // no site at or below mid: the owner is above
-              const int h = t.PrevSite(mid + 1, 0, neg);
-              if (h >= 0)
-              {
-                bool mh;
-                const int32_t fh = t.SiteF(h, neg, mh);
-                successor_better = false;
-                if (mh || h < r)
-                {
-                  const int hn = t.NextSite(h, n, neg);
-                  if (hn >= 0)
-                  {
-                    bool mhn;
-                    const int32_t fhn = t.SiteF(hn, neg, mhn);
-                    successor_better =
-                        ((r - hn) * (r - hn) + fhn) < ((r - h) * (r - h) + fh);
-                  }
-                }
-              }
-              if (successor_better)
-                lo = mid + 1;
-              else
-                hi = mid;
-            }
-            const int owner = t.PrevSite(lo + 1, 0, neg);
-            if (owner >= 0)
-            {
-              cur = owner;
-              fcur = t.SiteF(cur, neg, mcur);
-            }
-          }
+          Gh = t.Mag(h) + h * h;
+          const int p = t.PrevBit(t.A, t.sumA, h, run_a);
+          start_h = run_a;
+          if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + p * p, p, Gh, h));
         }
-        have = true;
-        nxt = -1;
-        if (cur >= 0 && (cur < r || ((t.Raw(cur) < 0) == neg)))
+        nxt = t.NextBit(t.A, t.sumA, h, run_b + 1);
+        start_nxt = run_b + 1;
+        if (nxt >= 0)
         {
-          nxt = t.NextSite(cur, n, neg);
-          if (nxt >= 0)
+          Gnxt = t.Mag(nxt) + nxt * nxt;
+          start_nxt = min(run_b + 1, max(run_a, FirstOwnedRow(Gh, h, Gnxt, nxt)));
+        }
+        if (start_h < start_nxt)
+        {
+          a2 |= 1u << (h - r0);
+          atomicOr(&t.T[(start_h >> 5) * W + t.w], 1u << (start_h & 31));
+          VGT_STAT_ADD(10, 1);
+        }
+      }
+    }
+    t.A2[band * W + t.w] = a2;
+  }
+  __syncthreads();
+
+  // ---- 2c. per word: survivors and start bits in lower words, summary of A2 ----
+  for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
+  {
+    const int line = tt / SW;
+    const int j = tt % SW;
+    const bool ok = j < nwords;
+    const uint32_t a = ok ? t.A2[j * W + line] : 0u;
+    const uint32_t s = ok ? t.T[j * W + line] : 0u;
+    int ca = __popc(a), ct = __popc(s);
+    for (int d = 1; d < SW; d <<= 1)
+    {
+      const int ua = __shfl_up(ca, d, SW), ut = __shfl_up(ct, d, SW);
+      if (j >= d)
+      {
+        ca += ua;
+        ct += ut;
+      }
+    }
+    const uint64_t any = __ballot(a != 0u);
+    if (ok)
+    {
+      t.cumA[j * W + line] = static_cast<uint16_t>(ca - __popc(a));
+      t.cumT[j * W + line] = static_cast<uint16_t>(ct - __popc(s));
+    }
+    if (j == 0)
+    {
+      const int sh = (threadIdx.x & 63) / SW * SW;
+      t.sumA2[line] = (SW == 64) ? any : ((any >> sh) & 0xffffffffull);
+    }
+  }
+  __syncthreads();
+#ifdef VGT_HULL_STATS
+  const long long clk4 = clock64();
+#endif
+
+  // ---- 3. evaluate this band's rows, store ----
+  uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
+  if (active && !(g.debug_skip & 2))
+  {
+    const uint32_t tw = t.T[band * W + t.w];
+    // owner of r0: the k-th survivor of the line, k = number of start bits at or below r0
+    int cur = -1;
+    int32_t fcur = 0;
+    {
+      int k = t.cumT[band * W + t.w] + static_cast<int>(tw & 1u);
+      if (k > 0)
+      {
+        int lo = 0, hi = nwords - 1;  // largest word j with cumA[j] < k
+        while (lo < hi)
+        {
+          const int mid = (lo + hi + 1) >> 1;
+          if (t.cumA[mid * W + t.w] < k)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+        k -= t.cumA[lo * W + t.w];
+        uint32_t x = t.A2[lo * W + t.w];
+        int pos = 0;
+#pragma unroll
+        for (int width = 16; width >= 1; width >>= 1)
+        {
+          const int cnt = __popc(x & ((1u << width) - 1u));
+          if (k > cnt)
           {
-            bool mn;
-            fnxt = t.SiteF(nxt, neg, mn);
+            k -= cnt;
+            x >>= width;
+            pos += width;
           }
         }
+        cur = (lo << 5) + pos;
+        fcur = t.Mag(cur);
+      }
+    }
+    bool neg = false;
+    int prev_opp = -1, next_opp = n, run_a = 0;
+    for (int r = r0; r < r1; r++)
+    {
+      if (r > r0 && ((tw >> (r - r0)) & 1u))
+      {
+        cur = t.NextBit(t.A2, t.sumA2, cur, n);
+        fcur = t.Mag(cur);
+      }
+      const bool sneg = (sbits >> (r - r0)) & 1u;
+      if (r == r0 || sneg != neg)
+      {
+        neg = sneg;
+        prev_opp = (r == r0) ? t.PrevOpp(r, neg) : r - 1;
+        next_opp = t.NextOpp(r, neg);
+        run_a = prev_opp + 1;
       }
       int32_t best = kInf32;
-      if (cur >= 0)
-      {
-        best = (r - cur) * (r - cur) + fcur;
-        while (nxt >= 0)
-        {
-          const int32_t vn = (r - nxt) * (r - nxt) + fnxt;
-          if (vn >= best) break;
-          cur = nxt;
-          VGT_STAT_ADD(11, 1);
-          fcur = fnxt;
-          best = vn;
-          const bool member = (t.Raw(cur) < 0) == neg;
-          nxt = member ? t.NextSite(cur, n, neg) : -1;
-          if (nxt >= 0)
-          {
-            bool mn;
-            fnxt = t.SiteF(nxt, neg, mn);
-          }
-        }
-      }
+      if (cur >= run_a) best = (r - cur) * (r - cur) + fcur;
+      if (prev_opp >= 0) best = min(best, (r - prev_opp) * (r - prev_opp));
+      if (next_opp < n) best = min(best, (next_opp - r) * (next_opp - r));
       const int64_t idx = base + static_cast<int64_t>(r) * g.row_stride + t.w;
       if constexpr (kFinal)
       {
@@ -561,38 +666,37 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   __syncthreads();
   if (threadIdx.x == 0)
   {
-    const long long clk4 = clock64();
+    const long long clk5 = clock64();
     VGT_STAT_ADD(0, clk1 - clk0);
     VGT_STAT_ADD(1, clk2 - clk1);
     VGT_STAT_ADD(2, clk3 - clk2);
     VGT_STAT_ADD(3, clk4 - clk3);
-    VGT_STAT_ADD(4, clk4 - clk0);
+    VGT_STAT_ADD(4, clk5 - clk4);
     VGT_STAT_ADD(5, 1);
+    VGT_STAT_ADD(6, clk5 - clk0);
   }
 #endif
 }
 
-// Lines per tile for n rows: the F tile (n * W * 4 bytes) must fit in 128 KiB of LDS and the
-// (line, band) threads in one workgroup.
+// Lines per tile for n rows: the tile must fit in LDS and the (line, band) threads in one
+// workgroup; a line may have at most 64 mask words (one wave-wide scan).
 int LinesPerTile(int64_t n)
 {
   const int64_t rows = (n + kBandRows - 1) / kBandRows * kBandRows;
   if (rows * 32 <= 32768) return 32;
   if (rows * 16 <= 32768) return 16;
-  if (rows * 8 <= 32768) return 8;
   return 0;
 }
 
-template <typename InT, typename OutT, bool kFinal, int W>
+template <typename InT, typename OutT, bool kFinal, int W, int SW>
 hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const HullGeom& g,
                       int64_t outer_count, hipStream_t stream)
 {
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
-  const size_t lds = static_cast<size_t>(g.n) * W * sizeof(int32_t) +
-                     2 * static_cast<size_t>(nwords) * W * sizeof(uint32_t);
+  const size_t lds = TileBytes<W>(g.n);
   int threads = nwords * W;
   threads = (threads + 63) / 64 * 64;
-  auto kernel = HullPassKernel<InT, OutT, kFinal, W>;
+  auto kernel = HullPassKernel<InT, OutT, kFinal, W, SW>;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
@@ -623,21 +727,18 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   static const int debug_skip = getenv("VGT_HULL_SKIP") ? atoi(getenv("VGT_HULL_SKIP")) : 0;
   g.debug_skip = debug_skip;
   constexpr int kVec = 16 / static_cast<int>(sizeof(InT));
-  g.vector_io = (g.nz % kVec == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (W % kVec == 0);
+  g.vector_io = (g.nz % kVec == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0);
   if (outer_count * g.ztiles > 0x7fffffffLL)
   {
     *handled = false;
     return hipSuccess;
   }
-  switch (W)
-  {
-    case 32:
-      return LaunchHull<InT, OutT, kFinal, 32>(in, out, minmax_enc, g, outer_count, stream);
-    case 16:
-      return LaunchHull<InT, OutT, kFinal, 16>(in, out, minmax_enc, g, outer_count, stream);
-    default:
-      return LaunchHull<InT, OutT, kFinal, 8>(in, out, minmax_enc, g, outer_count, stream);
-  }
+  const int nwords = (g.n + kBandRows - 1) / kBandRows;
+  if (W == 32)
+    return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
+  if (nwords <= 32)
+    return LaunchHull<InT, OutT, kFinal, 16, 32>(in, out, minmax_enc, g, outer_count, stream);
+  return LaunchHull<InT, OutT, kFinal, 16, 64>(in, out, minmax_enc, g, outer_count, stream);
 }
 }  // namespace
 
@@ -679,7 +780,9 @@ hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* mi
 extern "C" int vgt_hip_debug_hull_stats(unsigned long long* out32, int reset)
 {
   hipError_t err = hipDeviceSynchronize();
-  if (err == hipSuccess) err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_hull_stats), 32 * sizeof(unsigned long long));
+  if (err == hipSuccess)
+    err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_hull_stats),
+                              32 * sizeof(unsigned long long));
   if (err == hipSuccess && reset)
   {
     unsigned long long zeros[32] = {0};
