@@ -41,10 +41,16 @@ namespace vgt
 // [12] longest merge walk (max)
 __device__ unsigned long long g_hull_stats[32];  // [0..15] Y pass, [16..31] X pass
 __device__ int g_hull_stats_base;
-#define VGT_STAT_ADD(i, v) \
+#define VGT_CLK_ADD(i, v) \
   atomicAdd(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
+#if VGT_HULL_STATS > 1  // event counters perturb the timings: separate level
+#define VGT_STAT_ADD(i, v) VGT_CLK_ADD(i, v)
 #define VGT_STAT_MAX(i, v) \
   atomicMax(&g_hull_stats[g_hull_stats_base + (i)], static_cast<unsigned long long>(v))
+#else
+#define VGT_STAT_ADD(i, v)
+#define VGT_STAT_MAX(i, v)
+#endif
 #else
 #define VGT_STAT_ADD(i, v)
 #define VGT_STAT_MAX(i, v)
@@ -440,51 +446,110 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int lo = max((band - half) * kBandRows, t.PrevOpp(R, neg) + 1);
         const int hi = min(min((band + half) * kBandRows, n), t.NextOpp(R - 1, neg));
-        int i = t.PrevBit(t.A, t.sumA, R, lo);
-        int j = t.NextBit(t.A, t.sumA, R - 1, hi);
+        int i = t.PrevBit(t.A, t.sumA, R, lo);      // last hull member of the left block
+        int j = t.NextBit(t.A, t.sumA, R - 1, hi);  // first hull member of the right block
         if (i >= 0 && j >= 0)
         {
-#ifdef VGT_HULL_STATS
-          unsigned int walk = 0;
-#endif
+          // Common tangent of the two hulls.  For a fixed j the members of the left hull that
+          // die are a prefix (seen from the boundary) of the hull, and "member p is dominated by
+          // its predecessor and j" is monotone along it; likewise on the right for a fixed i.
+          // So each side is found by a galloping + binary search over row positions and the
+          // dead members are cleared word-wise; the two sides alternate until neither moves.
           int32_t Gi = t.Mag(i) + i * i;
           int32_t Gj = t.Mag(j) + j * j;
-          int a = t.PrevBit(t.A, t.sumA, i, lo);
-          int32_t Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
-          int c = t.NextBit(t.A, t.sumA, j, hi);
-          int32_t Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
-          for (;;)
+          // is the highest member at or below x dominated by (its predecessor, j)?
+          auto left_dead = [&](int x, int& site) -> bool {
+            site = t.PrevBit(t.A, t.sumA, x + 1, lo);
+            if (site < 0) return false;
+            const int a = t.PrevBit(t.A, t.sumA, site, lo);
+            if (a < 0) return false;
+            return Dominated(t.Mag(a) + a * a, a, t.Mag(site) + site * site, site, Gj, j);
+          };
+          // is the lowest member at or above x dominated by (i, its successor)?
+          auto right_dead = [&](int x, int& site) -> bool {
+            site = t.NextBit(t.A, t.sumA, x - 1, hi);
+            if (site < 0) return false;
+            const int c = t.NextBit(t.A, t.sumA, site, hi);
+            if (c < 0) return false;
+            return Dominated(Gi, i, t.Mag(site) + site * site, site, t.Mag(c) + c * c, c);
+          };
+          auto clear_rows = [&](int x0, int x1) {  // inclusive range
+            for (int jw = x0 >> 5; jw <= (x1 >> 5); jw++)
+            {
+              uint32_t m = ~0u;
+              if (jw == (x0 >> 5)) m &= ~LowMask(x0 & 31);
+              if (jw == (x1 >> 5)) m &= LowMask((x1 & 31) + 1);
+              t.A[jw * W + t.w] &= ~m;
+            }
+          };
+          bool moved = true;
+          while (moved)
           {
-            if (a >= 0 && Dominated(Ga, a, Gi, i, Gj, j))
+            moved = false;
+            int site;
+            if (left_dead(i, site))
             {
-              t.A[(i >> 5) * W + t.w] &= ~(1u << (i & 31));
-              i = a;
-              Gi = Ga;
-              a = t.PrevBit(t.A, t.sumA, i, lo);
-              Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
-#ifdef VGT_HULL_STATS
-              walk++;
-#endif
-              continue;
+              int dead_lo = i;  // lowest row known to hold a dead member
+              int live = lo - 1;  // highest row known not to
+              for (int step = 1;; step <<= 1)
+              {
+                const int x = i - step;
+                if (x < lo) break;
+                if (left_dead(x, site))
+                  dead_lo = site;
+                else
+                {
+                  live = x;
+                  break;
+                }
+              }
+              while (dead_lo - live > 1)
+              {
+                const int mid = (dead_lo + live) >> 1;
+                if (left_dead(mid, site))
+                  dead_lo = site;
+                else
+                  live = mid;
+              }
+              const int new_top = t.PrevBit(t.A, t.sumA, dead_lo, lo);
+              clear_rows(dead_lo, i);
+              VGT_STAT_ADD(9, 1);
+              i = new_top;
+              Gi = t.Mag(i) + i * i;
+              moved = true;
             }
-            if (c >= 0 && Dominated(Gi, i, Gj, j, Gc, c))
+            if (right_dead(j, site))
             {
-              t.A[(j >> 5) * W + t.w] &= ~(1u << (j & 31));
-              j = c;
-              Gj = Gc;
-              c = t.NextBit(t.A, t.sumA, j, hi);
-              Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
-#ifdef VGT_HULL_STATS
-              walk++;
-#endif
-              continue;
+              int dead_hi = j;
+              int live = hi;
+              for (int step = 1;; step <<= 1)
+              {
+                const int x = j + step;
+                if (x >= hi) break;
+                if (right_dead(x, site))
+                  dead_hi = site;
+                else
+                {
+                  live = x;
+                  break;
+                }
+              }
+              while (live - dead_hi > 1)
+              {
+                const int mid = (dead_hi + live) >> 1;
+                if (right_dead(mid, site))
+                  dead_hi = site;
+                else
+                  live = mid;
+              }
+              const int new_first = t.NextBit(t.A, t.sumA, dead_hi, hi);
+              clear_rows(j, dead_hi);
+              VGT_STAT_ADD(9, 1);
+              j = new_first;
+              Gj = t.Mag(j) + j * j;
+              moved = true;
             }
-            break;
           }
-#ifdef VGT_HULL_STATS
-          VGT_STAT_ADD(9, walk);
-          VGT_STAT_MAX(12, walk);
-#endif
         }
       }
     }
@@ -667,13 +732,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   if (threadIdx.x == 0)
   {
     const long long clk5 = clock64();
-    VGT_STAT_ADD(0, clk1 - clk0);
-    VGT_STAT_ADD(1, clk2 - clk1);
-    VGT_STAT_ADD(2, clk3 - clk2);
-    VGT_STAT_ADD(3, clk4 - clk3);
-    VGT_STAT_ADD(4, clk5 - clk4);
-    VGT_STAT_ADD(5, 1);
-    VGT_STAT_ADD(6, clk5 - clk0);
+    VGT_CLK_ADD(0, clk1 - clk0);
+    VGT_CLK_ADD(1, clk2 - clk1);
+    VGT_CLK_ADD(2, clk3 - clk2);
+    VGT_CLK_ADD(3, clk4 - clk3);
+    VGT_CLK_ADD(4, clk5 - clk4);
+    VGT_CLK_ADD(5, 1);
+    VGT_CLK_ADD(6, clk5 - clk0);
   }
 #endif
 }
@@ -720,7 +785,9 @@ template <typename InT, typename OutT, bool kFinal>
 hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom g,
                         int64_t outer_count, hipStream_t stream, bool* handled)
 {
-  const int W = LinesPerTile(g.n);
+  static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
+  int W = LinesPerTile(g.n);
+  if (W == 32 && force_w == 16) W = 16;  // experiment: half-width tiles, two workgroups per CU
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
