@@ -174,8 +174,9 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
-/* Selects the EDT line-pass implementation: 0 = default (fastest exact path),
- * 1 = pruned brute force (simple reference kernel, any size). Testing knob. */
+/* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
+ * 0 = default (LDS-tiled lower envelope: stack + merge), 1 = pruned outward search from HBM
+ * (any size), 2 = LDS-tiled monotone-argmin search. */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 
 #ifdef __cplusplus

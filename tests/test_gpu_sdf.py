@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1]  # default (fast) path and the pruned-search reference kernels
+VARIANTS = [0, 1, 2]  # tiled envelope (default), pruned search from HBM, tiled argmin search
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

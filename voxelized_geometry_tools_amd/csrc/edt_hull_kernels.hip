@@ -28,7 +28,7 @@
 //   3  each thread evaluates its 32 rows: the owner of a row is the k-th survivor, k = number of
 //      start bits at or below the row (rank / select), then advances at every start bit.
 // All predicates are integer-exact (64-bit cross multiplication / exact floor of a quotient).
-#include "edt_device.hpp"
+#include "edt_tile.hpp"
 
 #include <cstdlib>
 
@@ -57,13 +57,6 @@ __device__ int g_hull_stats_base;
 #endif
 namespace
 {
-constexpr int kBandRows = 32;
-
-__device__ __forceinline__ uint32_t LowMask(int bits)  // bits in [0, 32]
-{
-  return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
-}
-
 template <int W>
 struct Tile
 {
@@ -183,20 +176,7 @@ __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int 
   return static_cast<int>(fmin(fmax(q, -2.0), 1.0e6)) + 1;
 }
 
-struct HullGeom
-{
-  int n;                 // rows along the pass axis
-  int nz;                // extent of the contiguous axis
-  int ztiles;            // tiles along Z
-  int64_t row_stride;    // elements between consecutive rows
-  int64_t outer_stride;  // elements between consecutive outer indices
-  int nx, ny;            // full grid (finalize)
-  int pass_axis;         // 0 = X pass (outer = y), 1 = Y pass (outer = x)
-  double resolution;
-  int add_virtual_border;
-  int vector_io;         // rows and base pointers are 16-byte aligned
-  int debug_skip;        // timing experiments only (VGT_HULL_SKIP): 1 merges, 2 evaluation, 4 pops
-};
+using HullGeom = TileGeom;
 
 // Bytes of dynamic LDS for a tile of n rows x W lines.
 template <int W>
@@ -247,81 +227,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const long long clk0 = clock64();
 #endif
 
-  // ---- 0. load: rows are contiguous 4*W-byte (2*W for int16) segments; 16-byte chunks per
-  // lane when the tile is full and aligned, several loads in flight per lane either way ----
-  {
-    constexpr int kVec = 16 / static_cast<int>(sizeof(InT));  // elements per 16-byte chunk
-    constexpr int kChunksPerRow = W / kVec;
-    constexpr int kBatch = 4;
-    if (g.vector_io && (z0 + W <= g.nz))
-    {
-      using Chunk = __attribute__((__vector_size__(16))) int;
-      const int total = n * kChunksPerRow;
-      for (int c0 = threadIdx.x; c0 < total; c0 += blockDim.x * kBatch)
-      {
-        Chunk buf[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; k++)
-        {
-          const int c = c0 + k * blockDim.x;
-          if (c < total)
-          {
-            const int row = c / kChunksPerRow;
-            const int part = c % kChunksPerRow;
-            buf[k] = *reinterpret_cast<const Chunk*>(
-                in + base + static_cast<int64_t>(row) * g.row_stride + part * kVec);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < kBatch; k++)
-        {
-          const int c = c0 + k * blockDim.x;
-          if (c < total)
-          {
-            const int row = c / kChunksPerRow;
-            const int part = c % kChunksPerRow;
-            const InT* vals = reinterpret_cast<const InT*>(&buf[k]);
-            int32_t* dst = t.F + row * W + part * kVec;
-#pragma unroll
-            for (int u = 0; u < kVec; u += 4)
-            {
-              int4 q;
-              q.x = ToSignedSquare(vals[u + 0]);
-              q.y = ToSignedSquare(vals[u + 1]);
-              q.z = ToSignedSquare(vals[u + 2]);
-              q.w = ToSignedSquare(vals[u + 3]);
-              *reinterpret_cast<int4*>(dst + u) = q;
-            }
-          }
-        }
-      }
-    }
-    else
-    {
-      constexpr int kScalarBatch = 8;
-      const int total = n * W;
-      for (int e0 = threadIdx.x; e0 < total; e0 += blockDim.x * kScalarBatch)
-      {
-        InT buf[kScalarBatch];
-#pragma unroll
-        for (int k = 0; k < kScalarBatch; k++)
-        {
-          const int e = e0 + k * blockDim.x;
-          const int row = e / W;
-          const int ww = e % W;
-          buf[k] = InT(0);
-          if (e < total && z0 + ww < g.nz)
-            buf[k] = in[base + static_cast<int64_t>(row) * g.row_stride + ww];
-        }
-#pragma unroll
-        for (int k = 0; k < kScalarBatch; k++)
-        {
-          const int e = e0 + k * blockDim.x;
-          if (e < total) t.F[e] = (z0 + (e % W) < g.nz) ? ToSignedSquare(buf[k]) : kInf32;
-        }
-      }
-    }
-  }
+  // ---- 0. load the tile (coalesced rows, 16-byte chunks when aligned) ----
+  LoadTile<InT, W>(in, t.F, n, base, z0, g);
   __syncthreads();
 #ifdef VGT_HULL_STATS
   const long long clk1 = clock64();

@@ -15,9 +15,10 @@
 //     pass 2  Y: lower envelope of parabolas over the squared pass-1 distances
 //     pass 3  X: same, fused with sqrt / resolution / sign / virtual border / min-max.
 //
-// This file currently holds the Z scan and the simple pruned-search line pass
-// (EdtVariant::kBruteForce, exact for any size); the LDS-tiled envelope pass lives in
-// edt_hull_kernels.hip.
+// This file holds the Z scan and the simple pruned-search line pass (EdtVariant::kBruteForce,
+// exact for any size, the fallback for axes longer than the tiled kernels support).  The
+// LDS-tiled line passes live in edt_hull_kernels.hip (default: lower envelope) and
+// edt_dc_kernels.hip (monotone-argmin search, cross-check variant).
 #include "edt_device.hpp"
 
 namespace vgt
@@ -227,7 +228,11 @@ int GridFor(int64_t work_items, int block)
 }
 }  // namespace
 
-// Declared in edt_hull_kernels.hip.
+// Defined in edt_dc_kernels.hip / edt_hull_kernels.hip.
+hipError_t LaunchPassYDc(const int16_t* in16, int32_t* out32, const SdfParams& p,
+                         hipStream_t stream, bool* handled);
+hipError_t LaunchPassXDcFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                 const SdfParams& p, hipStream_t stream, bool* handled);
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -256,10 +261,12 @@ hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfPar
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
                        hipStream_t stream)
 {
-  if (variant == EdtVariant::kDefault)
+  if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err = LaunchPassYHull(in16, out32, p, stream, &handled);
+    const hipError_t err = (variant == EdtVariant::kSearch)
+                               ? LaunchPassYDc(in16, out32, p, stream, &handled)
+                               : LaunchPassYHull(in16, out32, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;
@@ -271,10 +278,13 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, 
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                const SdfParams& p, EdtVariant variant, hipStream_t stream)
 {
-  if (variant == EdtVariant::kDefault)
+  if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err = LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
+    const hipError_t err =
+        (variant == EdtVariant::kSearch)
+            ? LaunchPassXDcFinalize(in32, sdf, minmax_enc, p, stream, &handled)
+            : LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;
