@@ -130,6 +130,81 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
   }
 }
 
+// Fast path for nz <= 64 * NCHUNK: all loads of a line are issued before the first ballot (NCHUNK
+// independent 256-byte wave loads in flight), the chunk masks and carries live in scalar registers.
+template <typename InT, int NCHUNK>
+__global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(const InT* __restrict__ in,
+                                                                  int16_t* __restrict__ out,
+                                                                  int64_t num_lines, int nz,
+                                                                  int unknown_is_filled)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  for (int64_t line = static_cast<int64_t>(blockIdx.x) * kScanWaves + wave; line < num_lines;
+       line += static_cast<int64_t>(gridDim.x) * kScanWaves)
+  {
+    const InT* src = in + line * nz;
+    int16_t* dst = out + line * nz;
+    InT v[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+    {
+      const int z = c * kWave + lane;
+      v[c] = (z < nz) ? src[z] : InT(0);
+    }
+    uint64_t F[NCHUNK], E[NCHUNK];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+    {
+      const int z = c * kWave + lane;
+      F[c] = __ballot((z < nz) && IsFilled(v[c], unknown_is_filled));
+      const int rem = nz - c * kWave;
+      const uint64_t valid = (rem >= kWave) ? ~0ull : ((rem <= 0) ? 0ull : ((1ull << rem) - 1ull));
+      E[c] = ~F[c] & valid;
+    }
+    int32_t next_filled[NCHUNK], next_free[NCHUNK];
+    {
+      int32_t nf = -1, ne = -1;
+#pragma unroll
+      for (int c = NCHUNK - 1; c >= 0; c--)
+      {
+        next_filled[c] = nf;
+        next_free[c] = ne;
+        if (F[c]) nf = c * kWave + (__ffsll(static_cast<long long>(F[c])) - 1);
+        if (E[c]) ne = c * kWave + (__ffsll(static_cast<long long>(E[c])) - 1);
+      }
+    }
+    int32_t prev_filled = -1, prev_free = -1;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+    {
+      const int z = c * kWave + lane;
+      if (z < nz)
+      {
+        const bool is_filled = (F[c] >> lane) & 1ull;
+        const uint64_t other = is_filled ? E[c] : F[c];
+        const int32_t prev_other = is_filled ? prev_free : prev_filled;
+        const int32_t next_other = is_filled ? next_free[c] : next_filled[c];
+        const uint64_t below = other & ((1ull << lane) - 1ull);
+        const uint64_t above = (lane == kWave - 1) ? 0ull : (other >> (lane + 1));
+        int32_t d_below = kInf16, d_above = kInf16;
+        if (below)
+          d_below = lane - (63 - __clzll(static_cast<long long>(below)));
+        else if (prev_other >= 0)
+          d_below = z - prev_other;
+        if (above)
+          d_above = __ffsll(static_cast<long long>(above));
+        else if (next_other >= 0)
+          d_above = next_other - z;
+        const int32_t d = min(d_below, d_above);
+        dst[z] = static_cast<int16_t>(is_filled ? -d : d);
+      }
+      if (F[c]) prev_filled = c * kWave + (63 - __clzll(static_cast<long long>(F[c])));
+      if (E[c]) prev_free = c * kWave + (63 - __clzll(static_cast<long long>(E[c])));
+    }
+  }
+}
+
 // Exact 1-D lower-envelope value at position q by outward search with pruning: a site at
 // offset k can only improve the answer while k*k < best, and the first voxel of the other
 // class (a zero-valued site) ends the search on both sides.  O(sqrt(answer)) per voxel.
@@ -238,24 +313,46 @@ hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams&
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    const SdfParams& p, hipStream_t stream, bool* handled);
 
+namespace
+{
+template <typename InT>
+hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int unknown_is_filled,
+                       hipStream_t stream)
+{
+  const int64_t lines = p.nx * p.ny;
+  const int nz = static_cast<int>(p.nz);
+  const int grid = GridFor(lines, kScanWaves);
+#define VGT_SCAN_CASE(N)                                                                        \
+  hipLaunchKernelGGL((ScanZUnrolledKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
+                     out16, lines, nz, unknown_is_filled)
+  if (nz <= 64)
+    VGT_SCAN_CASE(1);
+  else if (nz <= 128)
+    VGT_SCAN_CASE(2);
+  else if (nz <= 256)
+    VGT_SCAN_CASE(4);
+  else if (nz <= 512)
+    VGT_SCAN_CASE(8);
+  else if (nz <= 1024)
+    VGT_SCAN_CASE(16);
+  else
+    hipLaunchKernelGGL(ScanZKernel<InT>, dim3(grid), dim3(kScanBlock), 0, stream, in, out16, lines,
+                       nz, unknown_is_filled);
+#undef VGT_SCAN_CASE
+  return hipGetLastError();
+}
+}  // namespace
+
 hipError_t LaunchScanZFromOccupancy(const float* occupancy, int16_t* out16, const SdfParams& p,
                                     hipStream_t stream)
 {
-  const int64_t lines = p.nx * p.ny;
-  const int grid = GridFor(lines, kScanWaves);
-  hipLaunchKernelGGL(ScanZKernel<float>, dim3(grid), dim3(kScanBlock), 0, stream, occupancy, out16,
-                     lines, static_cast<int>(p.nz), p.unknown_is_filled);
-  return hipGetLastError();
+  return LaunchScanZ<float>(occupancy, out16, p, p.unknown_is_filled, stream);
 }
 
 hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfParams& p,
                                hipStream_t stream)
 {
-  const int64_t lines = p.nx * p.ny;
-  const int grid = GridFor(lines, kScanWaves);
-  hipLaunchKernelGGL(ScanZKernel<uint8_t>, dim3(grid), dim3(kScanBlock), 0, stream, mask, out16,
-                     lines, static_cast<int>(p.nz), 0);
-  return hipGetLastError();
+  return LaunchScanZ<uint8_t>(mask, out16, p, 0, stream);
 }
 
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
