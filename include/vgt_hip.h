@@ -179,6 +179,31 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
  * (any size), 2 = LDS-tiled monotone-argmin search. */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 
+/* ---- multi-GPU: the grid is cut into Z slabs, one device per slab (BASELINE.json config 5).
+ * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
+ * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest
+ * filled / free voxel below and above.  So:
+ *   1. vgt_hip_sdf_slab_begin_dev   local Z scan + per-line summary of this slab
+ *                                    (4 x int16 per line: global z of the first / last filled and
+ *                                    first / last free voxel, -1 when absent)
+ *   2. the caller exchanges the summaries (one RCCL all-gather; torch.distributed in
+ *      voxelized_geometry_tools_amd/multi_gpu.py) and reduces them to per-line carries
+ *      (4 x int16: prev_filled, next_filled, prev_free, next_free as global z, -1 when absent)
+ *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
+ * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
+ * in both calls.  kernel_ms (optional): begin -> [scan]; finish -> [fix-up, Y pass, X pass];
+ * when given, the call blocks until the work has finished. */
+size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny);
+int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
+                               int64_t nz_local, int64_t z_offset, int unknown_is_filled,
+                               void* workspace_dev, size_t workspace_bytes, void* summary_dev,
+                               float* kernel_ms);
+int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_t nz_local,
+                                int64_t z_offset, int64_t nz_global, double resolution,
+                                int add_virtual_border, const void* carries_dev, float* sdf_dev,
+                                void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
+                                float* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

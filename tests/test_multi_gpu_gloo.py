@@ -1,0 +1,109 @@
+"""(not gpu) The N > 1 host path on CPU: two gloo ranks exchange slab summaries and derive the
+carries; the result must reproduce the full-grid nearest-other-class distance along Z."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _z_distance_reference(filled):
+    """Signed distance along Z to the nearest voxel of the other class (32767 = none)."""
+    nx, ny, nz = filled.shape
+    z = np.arange(nz)
+    out = np.empty(filled.shape, dtype=np.int32)
+    for cls in (True, False):
+        other = filled != cls  # voxels of the other class
+        # nearest other-class position below / above every z, per line
+        below = np.maximum.accumulate(np.where(other, z, -10 ** 6), axis=2)
+        above = np.minimum.accumulate(np.where(other, z, 10 ** 6)[:, :, ::-1], axis=2)[:, :, ::-1]
+        d = np.minimum(z - below, above - z)
+        d = np.where(d > 30000, 32767, d)
+        sel = filled == cls
+        out[sel] = np.where(cls, -d, d)[sel]
+    return out
+
+
+def _worker(rank, world, port, shape, seed, queue):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from voxelized_geometry_tools_amd import multi_gpu
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)
+        filled = rng.random(shape) < 0.03
+        filled[0, 0, :] = True           # a line with no free voxel anywhere
+        filled[1, 1, :] = False          # a line with no filled voxel anywhere
+        local_shape, z0 = multi_gpu.slab_of(shape, rank, world)
+        local = filled[:, :, z0:z0 + local_shape[2]]
+        summary = torch.from_numpy(multi_gpu.summary_reference(local, z0))
+        carries = multi_gpu.exchange_carries(torch, dist, summary, rank, world).numpy()
+        # fold the carries into the slab-local distances exactly as SlabFixupKernel does
+        d_local = _z_distance_reference(local)
+        zg = np.arange(z0, z0 + local_shape[2])[None, None, :]
+        c = carries.reshape(shape[0], shape[1], 4).astype(np.int32)
+        mag = np.abs(d_local)
+        for cls, prev_col, next_col in ((True, multi_gpu.PREV_FREE, multi_gpu.NEXT_FREE),
+                                        (False, multi_gpu.PREV_FILLED, multi_gpu.NEXT_FILLED)):
+            prev_o, next_o = c[..., prev_col][..., None], c[..., next_col][..., None]
+            cand = np.minimum(np.where(prev_o >= 0, zg - prev_o, 32767),
+                              np.where(next_o >= 0, next_o - zg, 32767))
+            sel = local == cls
+            mag = np.where(sel, np.minimum(mag, cand), mag)
+        got = np.where(local, -mag, mag)
+        want = _z_distance_reference(filled)[:, :, z0:z0 + local_shape[2]]
+        queue.put((rank, bool(np.array_equal(got, want)), None))
+    except Exception as exc:  # pragma: no cover
+        queue.put((rank, False, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (6, 7, 40)), (3, (5, 4, 31))])
+def test_slab_exchange_over_gloo(world, shape):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, 123, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [queue.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in results:
+        assert err is None, "rank %d: %s" % (rank, err)
+        assert ok, "rank %d: slab distances differ from the full-grid scan" % rank
+
+
+def test_slab_bounds_and_carries():
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    assert multi_gpu.slab_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert multi_gpu.slab_of((2, 3, 1024), 5, 8) == ((2, 3, 128), 640)
+    with pytest.raises(ValueError):
+        multi_gpu.slab_of((2, 2, 2), 2, 3)
+    # two lines, three slabs: [first_filled, last_filled, first_free, last_free]
+    g = torch.tensor([[[3, 5, 0, 9], [-1, -1, 0, 9]],
+                      [[-1, -1, 10, 19], [12, 12, 10, 19]],
+                      [[25, 29, 20, 28], [-1, -1, 20, 29]]], dtype=torch.int16)
+    c1 = multi_gpu.carries_from_summaries(torch, g, 1).tolist()
+    assert c1 == [[5, 25, 9, 20], [-1, -1, 9, 20]]
+    c0 = multi_gpu.carries_from_summaries(torch, g, 0).tolist()
+    assert c0 == [[-1, 25, -1, 10], [-1, 12, -1, 10]]
+    c2 = multi_gpu.carries_from_summaries(torch, g, 2).tolist()
+    assert c2 == [[5, -1, 19, -1], [12, -1, 19, -1]]

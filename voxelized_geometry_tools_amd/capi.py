@@ -59,6 +59,10 @@ SIGNATURES = {
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
+    "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
+    "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
+    "vgt_hip_sdf_slab_finish_dev": (_int, [_p, _i64, _i64, _i64, _i64, _i64, _f64, _int, _p, _p, _p,
+                                           _sz, _p, _p]),
 }
 
 
@@ -201,6 +205,23 @@ class Context:
                 self.handle, _ptr(occ_ptr), nx, ny, nz, float(resolution),
                 int(bool(unknown_is_filled)), int(bool(add_virtual_border)), _ptr(sdf_ptr),
                 _ptr(ws_ptr), ws_bytes, _ptr(minmax_ptr), _ptr(kernel_ms)))
+
+    # ---- multi-GPU Z slabs ----
+    def sdf_slab_begin(self, occ_ptr, local_shape, z_offset, ws_ptr, ws_bytes, summary_ptr,
+                       unknown_is_filled=True, kernel_ms=None):
+        nx, ny, nz = local_shape
+        check(self._lib.vgt_hip_sdf_slab_begin_dev(
+            self.handle, _ptr(occ_ptr), nx, ny, nz, int(z_offset), int(bool(unknown_is_filled)),
+            _ptr(ws_ptr), ws_bytes, _ptr(summary_ptr), _ptr(kernel_ms)))
+
+    def sdf_slab_finish(self, local_shape, z_offset, nz_global, resolution, carries_ptr, sdf_ptr,
+                        ws_ptr, ws_bytes, minmax_ptr=None, add_virtual_border=False,
+                        kernel_ms=None):
+        nx, ny, nz = local_shape
+        check(self._lib.vgt_hip_sdf_slab_finish_dev(
+            self.handle, nx, ny, nz, int(z_offset), int(nz_global), float(resolution),
+            int(bool(add_virtual_border)), _ptr(carries_ptr), _ptr(sdf_ptr), _ptr(ws_ptr), ws_bytes,
+            _ptr(minmax_ptr), _ptr(kernel_ms)))
 
     # ---- voxelizer ----
     def tracking_grids(self, num_cells, num_grids):

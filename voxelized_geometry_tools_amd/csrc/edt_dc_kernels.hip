@@ -378,7 +378,7 @@ __global__ __launch_bounds__(1024) void DcPassKernel(const InT* __restrict__ in,
       {
         const int x = (g.pass_axis == 0) ? q : outer;
         const int y = (g.pass_axis == 0) ? outer : q;
-        const float v = FinalizeSdf(best, neg, x, y, z, g.nx, g.ny, g.nz, g.resolution,
+        const float v = FinalizeSdf(best, neg, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global, g.resolution,
                                     g.add_virtual_border);
         out[idx] = v;
         const uint32_t enc = EncodeOrdered(v);
@@ -486,6 +486,8 @@ hipError_t LaunchPassYDc(const int16_t* in16, int32_t* out32, const SdfParams& p
   g.pass_axis = 1;
   g.resolution = p.resolution;
   g.add_virtual_border = p.add_virtual_border;
+  g.z_offset = static_cast<int>(p.z_offset);
+  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
   return DispatchDc<int16_t, int32_t, false>(in16, out32, nullptr, g, p.nx, stream, handled);
 }
 
@@ -502,6 +504,8 @@ hipError_t LaunchPassXDcFinalize(const int32_t* in32, float* sdf, uint32_t* minm
   g.pass_axis = 0;
   g.resolution = p.resolution;
   g.add_virtual_border = p.add_virtual_border;
+  g.z_offset = static_cast<int>(p.z_offset);
+  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
   return DispatchDc<int32_t, float, true>(in32, sdf, minmax_enc, g, p.ny, stream, handled);
 }
 }  // namespace vgt

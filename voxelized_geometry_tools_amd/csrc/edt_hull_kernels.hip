@@ -620,7 +620,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int x = (g.pass_axis == 0) ? r : outer;
         const int y = (g.pass_axis == 0) ? outer : r;
-        const float v = FinalizeSdf(best, neg, x, y, z, g.nx, g.ny, g.nz, g.resolution,
+        const float v = FinalizeSdf(best, neg, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global, g.resolution,
                                     g.add_virtual_border);
         out[idx] = v;
         const uint32_t e = EncodeOrdered(v);
@@ -729,6 +729,8 @@ hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams&
   g.pass_axis = 1;
   g.resolution = p.resolution;
   g.add_virtual_border = p.add_virtual_border;
+  g.z_offset = static_cast<int>(p.z_offset);
+  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
   return DispatchHull<int16_t, int32_t, false>(in16, out32, nullptr, g, p.nx, stream, handled);
 }
 
@@ -745,6 +747,8 @@ hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* mi
   g.pass_axis = 0;
   g.resolution = p.resolution;
   g.add_virtual_border = p.add_virtual_border;
+  g.z_offset = static_cast<int>(p.z_offset);
+  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
   return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, p.ny, stream, handled);
 }
 }  // namespace vgt

@@ -46,7 +46,9 @@ template <typename InT>
 __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict__ in,
                                                          int16_t* __restrict__ out,
                                                          int64_t num_lines, int nz,
-                                                         int unknown_is_filled)
+                                                         int unknown_is_filled,
+                                                         SlabLineSummary* __restrict__ summary,
+                                                         int z_offset)
 {
   // [wave][chunk]: ballot of "filled", then first position >= chunk end holding a filled /
   // free voxel (or -1).  Written and read by the same wave only.
@@ -91,6 +93,11 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
         if (F) nf = c * kWave + (__ffsll(static_cast<long long>(F)) - 1);
         if (E) ne = c * kWave + (__ffsll(static_cast<long long>(E)) - 1);
       }
+      if (summary)
+      {
+        summary[line].first_filled = static_cast<int16_t>(nf < 0 ? -1 : nf + z_offset);
+        summary[line].first_free = static_cast<int16_t>(ne < 0 ? -1 : ne + z_offset);
+      }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -126,6 +133,11 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
       if (F) prev_filled = c * kWave + (63 - __clzll(static_cast<long long>(F)));
       if (E) prev_free = c * kWave + (63 - __clzll(static_cast<long long>(E)));
     }
+    if (summary && lane == 0)
+    {
+      summary[line].last_filled = static_cast<int16_t>(prev_filled < 0 ? -1 : prev_filled + z_offset);
+      summary[line].last_free = static_cast<int16_t>(prev_free < 0 ? -1 : prev_free + z_offset);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -133,10 +145,9 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
 // Fast path for nz <= 64 * NCHUNK: all loads of a line are issued before the first ballot (NCHUNK
 // independent 256-byte wave loads in flight), the chunk masks and carries live in scalar registers.
 template <typename InT, int NCHUNK>
-__global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(const InT* __restrict__ in,
-                                                                  int16_t* __restrict__ out,
-                                                                  int64_t num_lines, int nz,
-                                                                  int unknown_is_filled)
+__global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(
+    const InT* __restrict__ in, int16_t* __restrict__ out, int64_t num_lines, int nz,
+    int unknown_is_filled, SlabLineSummary* __restrict__ summary, int z_offset)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -163,16 +174,14 @@ __global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(const InT* __r
       E[c] = ~F[c] & valid;
     }
     int32_t next_filled[NCHUNK], next_free[NCHUNK];
-    {
-      int32_t nf = -1, ne = -1;
+    int32_t nf = -1, ne = -1;
 #pragma unroll
-      for (int c = NCHUNK - 1; c >= 0; c--)
-      {
-        next_filled[c] = nf;
-        next_free[c] = ne;
-        if (F[c]) nf = c * kWave + (__ffsll(static_cast<long long>(F[c])) - 1);
-        if (E[c]) ne = c * kWave + (__ffsll(static_cast<long long>(E[c])) - 1);
-      }
+    for (int c = NCHUNK - 1; c >= 0; c--)
+    {
+      next_filled[c] = nf;
+      next_free[c] = ne;
+      if (F[c]) nf = c * kWave + (__ffsll(static_cast<long long>(F[c])) - 1);
+      if (E[c]) ne = c * kWave + (__ffsll(static_cast<long long>(E[c])) - 1);
     }
     int32_t prev_filled = -1, prev_free = -1;
 #pragma unroll
@@ -202,6 +211,38 @@ __global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(const InT* __r
       if (F[c]) prev_filled = c * kWave + (63 - __clzll(static_cast<long long>(F[c])));
       if (E[c]) prev_free = c * kWave + (63 - __clzll(static_cast<long long>(E[c])));
     }
+    if (summary && lane == 0)
+    {
+      SlabLineSummary out_summary;
+      out_summary.first_filled = static_cast<int16_t>(nf < 0 ? -1 : nf + z_offset);
+      out_summary.last_filled = static_cast<int16_t>(prev_filled < 0 ? -1 : prev_filled + z_offset);
+      out_summary.first_free = static_cast<int16_t>(ne < 0 ? -1 : ne + z_offset);
+      out_summary.last_free = static_cast<int16_t>(prev_free < 0 ? -1 : prev_free + z_offset);
+      summary[line] = out_summary;
+    }
+  }
+}
+
+// Multi-GPU: a voxel's distance along Z to the other class is the minimum of the slab-local
+// distance and the distances to the nearest such voxel in the slabs below / above.
+__global__ __launch_bounds__(256) void SlabFixupKernel(int16_t* __restrict__ io,
+                                                      const SlabLineCarry* __restrict__ carries,
+                                                      int64_t total, int nz, int z_offset)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int64_t line = i / nz;
+    const int z = static_cast<int>(i - line * nz) + z_offset;
+    const SlabLineCarry c = carries[line];
+    const int16_t v = io[i];
+    const bool filled = v < 0;
+    int32_t d = filled ? -static_cast<int32_t>(v) : static_cast<int32_t>(v);
+    const int prev_other = filled ? c.prev_free : c.prev_filled;
+    const int next_other = filled ? c.next_free : c.next_filled;
+    if (prev_other >= 0) d = min(d, z - prev_other);
+    if (next_other >= 0) d = min(d, next_other - z);
+    io[i] = static_cast<int16_t>(filled ? -d : d);
   }
 }
 
@@ -258,7 +299,8 @@ __global__ __launch_bounds__(256) void PassYBruteKernel(const int16_t* __restric
 
 __global__ __launch_bounds__(256) void PassXBruteFinalizeKernel(
     const int32_t* __restrict__ in, float* __restrict__ sdf, uint32_t* __restrict__ minmax_enc,
-    int64_t total, int nx, int ny, int nz, double resolution, int add_virtual_border)
+    int64_t total, int nx, int ny, int nz, double resolution, int add_virtual_border, int z_offset,
+    int nz_global)
 {
   uint32_t lo = 0xffffffffu, hi = 0u;
   const int64_t plane = static_cast<int64_t>(ny) * nz;
@@ -273,7 +315,7 @@ __global__ __launch_bounds__(256) void PassXBruteFinalizeKernel(
     int32_t own;
     Decode(in[i], negative, own);
     const int32_t best = LineSearch(in + i, plane, x, nx, negative, own);
-    const float v = FinalizeSdf(best, negative, x, y, z, nx, ny, nz, resolution,
+    const float v = FinalizeSdf(best, negative, x, y, z + z_offset, nx, ny, nz_global, resolution,
                                 add_virtual_border);
     sdf[i] = v;
     const uint32_t e = EncodeOrdered(v);
@@ -317,14 +359,15 @@ namespace
 {
 template <typename InT>
 hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int unknown_is_filled,
-                       hipStream_t stream)
+                       SlabLineSummary* summary, hipStream_t stream)
 {
+  const int z_offset = static_cast<int>(p.z_offset);
   const int64_t lines = p.nx * p.ny;
   const int nz = static_cast<int>(p.nz);
   const int grid = GridFor(lines, kScanWaves);
 #define VGT_SCAN_CASE(N)                                                                        \
   hipLaunchKernelGGL((ScanZUnrolledKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
-                     out16, lines, nz, unknown_is_filled)
+                     out16, lines, nz, unknown_is_filled, summary, z_offset)
   if (nz <= 64)
     VGT_SCAN_CASE(1);
   else if (nz <= 128)
@@ -337,22 +380,31 @@ hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int un
     VGT_SCAN_CASE(16);
   else
     hipLaunchKernelGGL(ScanZKernel<InT>, dim3(grid), dim3(kScanBlock), 0, stream, in, out16, lines,
-                       nz, unknown_is_filled);
+                       nz, unknown_is_filled, summary, z_offset);
 #undef VGT_SCAN_CASE
   return hipGetLastError();
 }
 }  // namespace
 
 hipError_t LaunchScanZFromOccupancy(const float* occupancy, int16_t* out16, const SdfParams& p,
-                                    hipStream_t stream)
+                                    SlabLineSummary* summary, hipStream_t stream)
 {
-  return LaunchScanZ<float>(occupancy, out16, p, p.unknown_is_filled, stream);
+  return LaunchScanZ<float>(occupancy, out16, p, p.unknown_is_filled, summary, stream);
 }
 
 hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfParams& p,
-                               hipStream_t stream)
+                               SlabLineSummary* summary, hipStream_t stream)
 {
-  return LaunchScanZ<uint8_t>(mask, out16, p, 0, stream);
+  return LaunchScanZ<uint8_t>(mask, out16, p, 0, summary, stream);
+}
+
+hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
+                           hipStream_t stream)
+{
+  const int64_t total = p.nx * p.ny * p.nz;
+  hipLaunchKernelGGL(SlabFixupKernel, dim3(GridFor(total, 256)), dim3(256), 0, stream, io16,
+                     carries, total, static_cast<int>(p.nz), static_cast<int>(p.z_offset));
+  return hipGetLastError();
 }
 
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
@@ -387,7 +439,9 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
   const int64_t total = p.nx * p.ny * p.nz;
   hipLaunchKernelGGL(PassXBruteFinalizeKernel, dim3(GridFor(total, 256)), dim3(256), 0, stream,
                      in32, sdf, minmax_enc, total, static_cast<int>(p.nx), static_cast<int>(p.ny),
-                     static_cast<int>(p.nz), p.resolution, p.add_virtual_border);
+                     static_cast<int>(p.nz), p.resolution, p.add_virtual_border,
+                     static_cast<int>(p.z_offset),
+                     static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz));
   return hipGetLastError();
 }
 

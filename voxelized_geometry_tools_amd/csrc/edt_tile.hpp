@@ -26,6 +26,8 @@ struct TileGeom
   int add_virtual_border;
   int vector_io;         // rows and base pointers are 16-byte aligned
   int debug_skip;        // timing experiments only (VGT_HULL_SKIP)
+  int z_offset;          // Z slab (multi-GPU): global z of local z = 0
+  int nz_global;         // Z extent of the whole grid (virtual border)
 };
 
 // Cooperative load of a tile into LDS as signed squared int32, F[row * W + line].  Rows are

@@ -111,9 +111,9 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
   VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
   if (events) VGT_TRY_HIP(hipEventRecord(events[0], s), "event record");
   if constexpr (std::is_same<InT, float>::value)
-    VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(input_dev, ws.t16, p, s), "Z scan");
+    VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(input_dev, ws.t16, p, nullptr, s), "Z scan");
   else
-    VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, s), "Z scan");
+    VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, nullptr, s), "Z scan");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
   VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, p, ctx->variant, s), "Y pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
@@ -695,6 +695,116 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
   for (int i = 0; i < 4; i++)
     if (ev[i]) (void)hipEventDestroy(ev[i]);
   return result;
+}
+
+/* ------------------------------ multi-GPU Z slabs ----------------------------- */
+
+size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny)
+{
+  if (nx <= 0 || ny <= 0) return 0;
+  return static_cast<size_t>(nx) * static_cast<size_t>(ny) * sizeof(vgt::SlabLineSummary);
+}
+
+namespace
+{
+// Times `count` consecutive kernel groups with events when kernel_ms is requested.
+struct StageTimer
+{
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n = 0;
+  bool enabled = false;
+  int Init(bool on, int stages)
+  {
+    enabled = on;
+    if (!on) return VGT_HIP_OK;
+    for (int i = 0; i <= stages; i++)
+    {
+      const hipError_t err = hipEventCreate(&ev[i]);
+      if (err != hipSuccess) return FailHip("create event", err);
+      n = i + 1;
+    }
+    return VGT_HIP_OK;
+  }
+  hipError_t Mark(int i, hipStream_t s) { return enabled ? hipEventRecord(ev[i], s) : hipSuccess; }
+  int Finish(hipStream_t s, float* out, int stages)
+  {
+    if (!enabled) return VGT_HIP_OK;
+    hipError_t err = hipStreamSynchronize(s);
+    for (int i = 0; i < stages && err == hipSuccess; i++)
+      err = hipEventElapsedTime(&out[i], ev[i], ev[i + 1]);
+    return err == hipSuccess ? VGT_HIP_OK : FailHip("stage timing", err);
+  }
+  ~StageTimer()
+  {
+    for (int i = 0; i < n; i++)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+  }
+};
+}  // namespace
+
+int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
+                               int64_t nz_local, int64_t z_offset, int unknown_is_filled,
+                               void* workspace_dev, size_t workspace_bytes, void* summary_dev,
+                               float* kernel_ms)
+{
+  if (!ctx || !occupancy_dev || !workspace_dev || !summary_dev)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz_local, 1.0);
+  if (rc != VGT_HIP_OK) return rc;
+  if (z_offset < 0 || z_offset + nz_local > vgt::kMaxExtent)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "slab lies outside the supported Z extent");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::SdfParams p{nx, ny, nz_local, 1.0, unknown_is_filled ? 1 : 0, 0};
+  p.z_offset = z_offset;
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx * ny * nz_local);
+  if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
+  StageTimer timer;
+  const int trc = timer.Init(kernel_ms != nullptr, 1);
+  if (trc != VGT_HIP_OK) return trc;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(timer.Mark(0, ctx->stream), "event record");
+  VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(occupancy_dev, ws.t16, p,
+                                            static_cast<vgt::SlabLineSummary*>(summary_dev),
+                                            ctx->stream),
+              "Z scan");
+  VGT_TRY_HIP(timer.Mark(1, ctx->stream), "event record");
+  return timer.Finish(ctx->stream, kernel_ms, 1);
+}
+
+int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_t nz_local,
+                                int64_t z_offset, int64_t nz_global, double resolution,
+                                int add_virtual_border, const void* carries_dev, float* sdf_dev,
+                                void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
+                                float* kernel_ms)
+{
+  if (!ctx || !carries_dev || !sdf_dev || !workspace_dev)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz_local, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  if (z_offset < 0 || nz_global < z_offset + nz_local || nz_global > vgt::kMaxExtent)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "slab lies outside the global Z extent");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::SdfParams p{nx, ny, nz_local, resolution, 0, add_virtual_border ? 1 : 0};
+  p.z_offset = z_offset;
+  p.nz_global = nz_global;
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx * ny * nz_local);
+  if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
+  StageTimer timer;
+  const int trc = timer.Init(kernel_ms != nullptr, 3);
+  if (trc != VGT_HIP_OK) return trc;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  hipStream_t s = ctx->stream;
+  VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
+  VGT_TRY_HIP(timer.Mark(0, s), "event record");
+  VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
+              "slab fix-up");
+  VGT_TRY_HIP(timer.Mark(1, s), "event record");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(timer.Mark(2, s), "event record");
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, p, ctx->variant, s), "X pass");
+  VGT_TRY_HIP(timer.Mark(3, s), "event record");
+  if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
+  return timer.Finish(s, kernel_ms, 3);
 }
 
 }  // extern "C"

@@ -23,10 +23,27 @@ constexpr int64_t kMaxExtent = 16384;
 
 struct SdfParams
 {
-  int64_t nx, ny, nz;
+  int64_t nx, ny, nz;  // extents of the grid held by this device (a Z slab when partitioned)
   double resolution;
   int unknown_is_filled;
   int add_virtual_border;
+  // Z-slab partitioning (multi-GPU): this device holds global z in [z_offset, z_offset + nz) of a
+  // grid with nz_global voxels along Z.  Single device: z_offset = 0, nz_global = nz.
+  int64_t z_offset = 0;
+  int64_t nz_global = 0;
+};
+
+// Per-line summary of a Z slab, exchanged between devices: global z of the first / last filled
+// voxel and of the first / last free voxel of the line inside the slab, -1 when absent.
+struct SlabLineSummary
+{
+  int16_t first_filled, last_filled, first_free, last_free;
+};
+// Per-line carries derived from the other slabs' summaries: nearest filled / free voxel of the
+// line below this slab (largest global z) and above it (smallest global z), -1 when absent.
+struct SlabLineCarry
+{
+  int16_t prev_filled, next_filled, prev_free, next_free;
 };
 
 // kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
@@ -36,10 +53,14 @@ enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kSearch = 2 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
+// `summary` (optional) receives one SlabLineSummary per (x, y) line.
 hipError_t LaunchScanZFromOccupancy(const float* occupancy, int16_t* out16, const SdfParams& p,
-                                    hipStream_t stream);
+                                    SlabLineSummary* summary, hipStream_t stream);
 hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfParams& p,
-                                hipStream_t stream);
+                                SlabLineSummary* summary, hipStream_t stream);
+// Multi-GPU: folds the carries of the other slabs into the slab-local pass-1 distances, in place.
+hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
+                           hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
                        hipStream_t stream);

@@ -1,0 +1,163 @@
+"""Z-slab partitioned SDF extraction: one process (rank) per GPU, one RCCL exchange.
+
+The grid (nx, ny, nz) is cut along Z into `world` slabs.  Lines along Y and X are local to a
+slab, so the two envelope passes need no communication.  Only pass 1 -- distance along Z to the
+nearest voxel of the other class -- crosses slabs, and all it needs from the other slabs is, per
+(x, y) line, the nearest filled / free voxel below and above the slab.  Each rank therefore
+publishes 4 x int16 per line (global z of its first / last filled and first / last free voxel),
+the ranks all-gather these summaries once (torch.distributed: backend "nccl" is RCCL over xGMI;
+"gloo" in the CPU tests), and every rank reduces them to per-line carries for its own slab.
+Exact for any slab count: the first pass is a nearest-site scan, not a k-voxel halo.
+
+The exchange helpers are plain torch code and run on CPU tensors too (tests/test_multi_gpu_gloo.py).
+"""
+import numpy as np
+
+NONE = -1
+_BIG = 32767
+
+# column layout of the per-line records (must match SlabLineSummary / SlabLineCarry in
+# csrc/vgt_internal.hpp)
+FIRST_FILLED, LAST_FILLED, FIRST_FREE, LAST_FREE = 0, 1, 2, 3
+PREV_FILLED, NEXT_FILLED, PREV_FREE, NEXT_FREE = 0, 1, 2, 3
+
+
+def slab_bounds(nz, world):
+    """Global z ranges [z0, z1) of the slabs: as equal as possible, earlier ranks get the extras."""
+    base, extra = divmod(nz, world)
+    bounds, z = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        bounds.append((z, z + n))
+        z += n
+    return bounds
+
+
+def slab_of(full_shape, rank, world):
+    """(local_shape, z_offset) of `rank`'s slab."""
+    nx, ny, nz = full_shape
+    z0, z1 = slab_bounds(nz, world)[rank]
+    if z1 <= z0:
+        raise ValueError("more slabs than Z voxels")
+    return (nx, ny, z1 - z0), z0
+
+
+def carries_from_summaries(torch, gathered, rank):
+    """gathered: int16 tensor [world, lines, 4] of slab summaries -> int16 [lines, 4] carries
+    (prev_filled, next_filled, prev_free, next_free as global z, -1 = none) for `rank`."""
+    world, lines, _ = gathered.shape
+    out = torch.full((lines, 4), NONE, dtype=torch.int16, device=gathered.device)
+    if rank > 0:
+        below = gathered[:rank]
+        out[:, PREV_FILLED] = below[:, :, LAST_FILLED].max(dim=0).values
+        out[:, PREV_FREE] = below[:, :, LAST_FREE].max(dim=0).values
+    if rank + 1 < world:
+        above = gathered[rank + 1:]
+        for dst, src in ((NEXT_FILLED, FIRST_FILLED), (NEXT_FREE, FIRST_FREE)):
+            v = above[:, :, src]
+            v = torch.where(v < 0, torch.full_like(v, _BIG), v).min(dim=0).values
+            out[:, dst] = torch.where(v == _BIG, torch.full_like(v, NONE), v)
+    return out
+
+
+def exchange_carries(torch, dist, summary, rank, world, gathered=None):
+    """All-gathers the [lines, 4] int16 summaries of every rank and returns this rank's carries."""
+    if gathered is None:
+        gathered = torch.empty((world,) + tuple(summary.shape), dtype=summary.dtype,
+                               device=summary.device)
+    # the records are 8 bytes per line; move them as int32 words (gloo has no int16 collectives)
+    dist.all_gather_into_tensor(gathered.view(torch.int32).view(-1),
+                                summary.contiguous().view(torch.int32).view(-1))
+    return carries_from_summaries(torch, gathered, rank)
+
+
+def summary_reference(filled, z_offset):
+    """numpy restatement of the per-line slab summary (tests): filled = bool (nx, ny, nzl)."""
+    nx, ny, nzl = filled.shape
+    z = np.arange(nzl)
+    out = np.full((nx, ny, 4), NONE, dtype=np.int16)
+    for col, mask in ((FIRST_FILLED, filled), (FIRST_FREE, ~filled)):
+        has = mask.any(axis=2)
+        first = np.where(mask, z, nzl).min(axis=2)
+        out[..., col] = np.where(has, first + z_offset, NONE)
+    for col, mask in ((LAST_FILLED, filled), (LAST_FREE, ~filled)):
+        has = mask.any(axis=2)
+        last = np.where(mask, z, -1).max(axis=2)
+        out[..., col] = np.where(has, last + z_offset, NONE)
+    return out.reshape(nx * ny, 4)
+
+
+class SlabSdf:
+    """One rank's share of a Z-slab partitioned SDF extraction (device-resident)."""
+
+    def __init__(self, ctx, torch, dist, full_shape, rank, world, device):
+        from . import capi
+        self.ctx, self.torch, self.dist = ctx, torch, dist
+        self.full_shape = tuple(int(s) for s in full_shape)
+        self.rank, self.world = rank, world
+        self.local_shape, self.z_offset = slab_of(self.full_shape, rank, world)
+        lines = self.local_shape[0] * self.local_shape[1]
+        assert capi.load().vgt_hip_sdf_slab_summary_bytes(*self.local_shape[:2]) == lines * 8
+        self.summary = torch.empty((lines, 4), dtype=torch.int16, device=device)
+        self.gathered = torch.empty((world, lines, 4), dtype=torch.int16, device=device)
+        self.ms_begin = np.zeros(1, dtype=np.float32)
+        self.ms_finish = np.zeros(3, dtype=np.float32)
+
+    def run(self, occ, sdf, ws, minmax, resolution, kernel_ms=None, unknown_is_filled=True,
+            add_virtual_border=False):
+        torch = self.torch
+        timed = kernel_ms is not None
+        self.ctx.sdf_slab_begin(occ.data_ptr(), self.local_shape, self.z_offset, ws.data_ptr(),
+                                ws.numel(), self.summary.data_ptr(), unknown_is_filled,
+                                self.ms_begin if timed else None)
+        carries = exchange_carries(torch, self.dist, self.summary, self.rank, self.world,
+                                   self.gathered)
+        self.ctx.sdf_slab_finish(self.local_shape, self.z_offset, self.full_shape[2], resolution,
+                                 carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 minmax.data_ptr(), add_virtual_border,
+                                 self.ms_finish if timed else None)
+        # the field's extrema are those of all slabs
+        lo, hi = minmax[0:1].clone(), minmax[1:2].clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        minmax[0:1] = lo
+        minmax[1:2] = hi
+        if timed:
+            kernel_ms[0] = self.ms_begin[0] + self.ms_finish[0]
+            kernel_ms[1] = self.ms_finish[1]
+            kernel_ms[2] = self.ms_finish[2]
+        return carries
+
+
+def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_filled=True,
+                            add_virtual_border=False):
+    """Runs the slab pipeline for every slab on ONE device, exchanging in-process.  Used by the
+    GPU parity tests to exercise the multi-GPU kernels where only one GPU is available."""
+    from . import capi
+    nx, ny, nz = occ.shape
+    dev = occ.device
+    parts = []
+    for r in range(nslabs):
+        local_shape, z0 = slab_of((nx, ny, nz), r, nslabs)
+        local = occ[:, :, z0:z0 + local_shape[2]].contiguous()
+        nbytes = capi.sdf_workspace_bytes(local_shape)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        summary = torch.empty((nx * ny, 4), dtype=torch.int16, device=dev)
+        ctx.sdf_slab_begin(local.data_ptr(), local_shape, z0, ws.data_ptr(), nbytes,
+                           summary.data_ptr(), unknown_is_filled)
+        parts.append((local_shape, z0, local, ws, nbytes, summary))
+    ctx.synchronize()
+    gathered = torch.stack([p[5] for p in parts])
+    out = torch.empty((nx, ny, nz), dtype=torch.float32, device=dev)
+    extrema = []
+    for r, (local_shape, z0, local, ws, nbytes, summary) in enumerate(parts):
+        carries = carries_from_summaries(torch, gathered, r)
+        sdf = torch.empty(local_shape, dtype=torch.float32, device=dev)
+        mm = torch.zeros(2, dtype=torch.float32, device=dev)
+        ctx.sdf_slab_finish(local_shape, z0, nz, resolution, carries.data_ptr(), sdf.data_ptr(),
+                            ws.data_ptr(), nbytes, mm.data_ptr(), add_virtual_border)
+        ctx.synchronize()
+        out[:, :, z0:z0 + local_shape[2]] = sdf
+        extrema.append(mm.cpu().numpy())
+    extrema = np.array(extrema)
+    return out, float(extrema[:, 0].min()), float(extrema[:, 1].max())
