@@ -163,3 +163,20 @@ def test_z_slab_pipeline_matches_single_device(ctx, oracle, nslabs):
         got, lo, hi = multi_gpu.sdf_slabs_single_device(ctx, torch, occ_dev, nslabs, 0.02, True, vb)
         assert bits_equal(got.cpu().numpy(), want), (dist, nslabs)
         assert (lo, hi) == (wlo, whi), (dist, nslabs)
+
+
+@pytest.mark.parametrize("shape", [(1100, 6, 40), (5, 1500, 33), (2048, 4, 16), (3, 2049, 20),
+                                   (2100, 3, 8), (4, 5, 1100), (2, 3, 2500)])
+def test_long_axes(ctx, oracle, shape):
+    """Axes in (1024, 2048] use the 16-line tiles (64 mask words per line); longer ones fall back
+    to the pruned search; Z lines beyond 1024 use the generic scan."""
+    rng = np.random.default_rng(sum(shape))
+    occ = (rng.random(shape) < 0.01).astype(np.float32)
+    occ[rng.random(shape) < 0.005] = 0.5
+    want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.05)
+    for variant in VARIANTS:
+        ctx.set_edt_variant(variant)
+        got, lo, hi = ctx.sdf_from_occupancy(occ, 0.05)
+        assert bits_equal(got, want), (shape, variant)
+        assert (lo, hi) == (wlo, whi)
+    ctx.set_edt_variant(0)
