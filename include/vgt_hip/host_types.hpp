@@ -1,0 +1,246 @@
+// Stand-alone host-side value types for the HIP backend's C++ layer.
+//
+// Inside the reference tree these roles are played by Eigen::Isometry3d, OccupancyMap,
+// SignedDistanceField<float>, PointCloudWrapper, ... (none of which can be compiled here:
+// Eigen and common_robotics_utilities are not available).  The types below carry exactly what
+// the hot path needs, with the reference's names for the operations the hot path uses, so that
+// the C++ tests read like the reference's and the reference-side wiring in INTEGRATION.md is a
+// field-by-field substitution.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace vgt_hip
+{
+// Rigid transform, 4x4 column-major doubles (the layout of Eigen::Isometry3d::data()).
+struct Isometry3
+{
+  std::array<double, 16> m{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+
+  static Isometry3 Identity() { return Isometry3(); }
+  static Isometry3 Translation(double x, double y, double z)
+  {
+    Isometry3 t;
+    t.m[12] = x;
+    t.m[13] = y;
+    t.m[14] = z;
+    return t;
+  }
+  // Rotation from a unit quaternion (w, x, y, z) + translation.
+  static Isometry3 FromQuaternion(double w, double x, double y, double z, double tx, double ty,
+                                  double tz)
+  {
+    Isometry3 t;
+    const double x2 = 2 * x, y2 = 2 * y, z2 = 2 * z;
+    t.m[0] = 1 - (y2 * y + z2 * z);
+    t.m[4] = y2 * x - z2 * w;
+    t.m[8] = z2 * x + y2 * w;
+    t.m[1] = y2 * x + z2 * w;
+    t.m[5] = 1 - (x2 * x + z2 * z);
+    t.m[9] = z2 * y - x2 * w;
+    t.m[2] = z2 * x - y2 * w;
+    t.m[6] = z2 * y + x2 * w;
+    t.m[10] = 1 - (x2 * x + y2 * y);
+    t.m[12] = tx;
+    t.m[13] = ty;
+    t.m[14] = tz;
+    return t;
+  }
+  double operator()(int r, int c) const { return m[static_cast<size_t>(c * 4 + r)]; }
+  double& operator()(int r, int c) { return m[static_cast<size_t>(c * 4 + r)]; }
+
+  Isometry3 operator*(const Isometry3& o) const  // affine product
+  {
+    Isometry3 out;
+    for (int r = 0; r < 3; r++)
+    {
+      for (int c = 0; c < 3; c++)
+        out(r, c) = (*this)(r, 0) * o(0, c) + (*this)(r, 1) * o(1, c) + (*this)(r, 2) * o(2, c);
+      out(r, 3) = (*this)(r, 0) * o(0, 3) + (*this)(r, 1) * o(1, 3) + (*this)(r, 2) * o(2, 3) +
+                  (*this)(r, 3);
+    }
+    return out;
+  }
+  Isometry3 Inverse() const  // rigid: R^T, -R^T t
+  {
+    Isometry3 out;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) out(r, c) = (*this)(c, r);
+    for (int r = 0; r < 3; r++)
+      out(r, 3) = -(out(r, 0) * (*this)(0, 3) + out(r, 1) * (*this)(1, 3) +
+                    out(r, 2) * (*this)(2, 3));
+    return out;
+  }
+  std::array<float, 16> CastFloat() const
+  {
+    std::array<float, 16> f{};
+    for (size_t i = 0; i < 16; i++) f[i] = static_cast<float>(m[i]);
+    return f;
+  }
+};
+
+// Dense X-major / Z-fastest grid of floats with a uniform voxel size: the part of
+// OccupancyMap (occupancy_map.hpp:65-217) and SignedDistanceField<float>
+// (signed_distance_field.hpp:193-789) that the hot path touches.
+class DenseGrid
+{
+public:
+  DenseGrid() = default;
+  DenseGrid(const Isometry3& origin_transform, const std::string& frame, double resolution,
+            int64_t num_x, int64_t num_y, int64_t num_z, float default_value)
+      : origin_(origin_transform), inverse_origin_(origin_transform.Inverse()), frame_(frame),
+        resolution_(resolution), nx_(num_x), ny_(num_y), nz_(num_z)
+  {
+    if (!(resolution > 0.0) || num_x <= 0 || num_y <= 0 || num_z <= 0)
+      throw std::invalid_argument("Grid must have positive resolution and voxel counts");
+    data_.assign(static_cast<size_t>(num_x * num_y * num_z), default_value);
+  }
+  // VoxelGridSizes::FromGridSizes: counts = size / resolution
+  static DenseGrid FromGridSizes(const Isometry3& origin_transform, const std::string& frame,
+                                 double resolution, double x_size, double y_size, double z_size,
+                                 float default_value)
+  {
+    return DenseGrid(origin_transform, frame, resolution,
+                     static_cast<int64_t>(std::ceil(x_size / resolution)),
+                     static_cast<int64_t>(std::ceil(y_size / resolution)),
+                     static_cast<int64_t>(std::ceil(z_size / resolution)), default_value);
+  }
+
+  bool IsInitialized() const { return !data_.empty(); }
+  int64_t NumXVoxels() const { return nx_; }
+  int64_t NumYVoxels() const { return ny_; }
+  int64_t NumZVoxels() const { return nz_; }
+  int64_t NumTotalVoxels() const { return nx_ * ny_ * nz_; }
+  double Resolution() const { return resolution_; }
+  double VoxelXSize() const { return resolution_; }
+  double GridXSize() const { return static_cast<double>(nx_) * resolution_; }
+  double GridYSize() const { return static_cast<double>(ny_) * resolution_; }
+  double GridZSize() const { return static_cast<double>(nz_) * resolution_; }
+  const Isometry3& OriginTransform() const { return origin_; }
+  const Isometry3& InverseOriginTransform() const { return inverse_origin_; }
+  const std::string& Frame() const { return frame_; }
+  bool SameSizes(const DenseGrid& o) const
+  {
+    return nx_ == o.nx_ && ny_ == o.ny_ && nz_ == o.nz_ && resolution_ == o.resolution_;
+  }
+
+  bool IndexInBounds(int64_t x, int64_t y, int64_t z) const
+  {
+    return x >= 0 && x < nx_ && y >= 0 && y < ny_ && z >= 0 && z < nz_;
+  }
+  float GetIndexImmutable(int64_t x, int64_t y, int64_t z) const
+  {
+    if (!IndexInBounds(x, y, z)) throw std::runtime_error("index out of grid bounds");
+    return data_[static_cast<size_t>((x * ny_ + y) * nz_ + z)];
+  }
+  void SetIndex(int64_t x, int64_t y, int64_t z, float value)
+  {
+    if (!IndexInBounds(x, y, z)) throw std::runtime_error("index out of grid bounds");
+    data_[static_cast<size_t>((x * ny_ + y) * nz_ + z)] = value;
+  }
+  const std::vector<float>& GetImmutableRawData() const { return data_; }
+  std::vector<float>& GetMutableRawData() { return data_; }
+
+private:
+  Isometry3 origin_, inverse_origin_;
+  std::string frame_;
+  double resolution_ = 0.0;
+  int64_t nx_ = 0, ny_ = 0, nz_ = 0;
+  std::vector<float> data_;
+};
+
+using OccupancyMap = DenseGrid;
+
+// SignedDistanceFieldGenerationParameters<float> (signed_distance_field.hpp:1234-1264), minus
+// the CPU parallelism knob, plus the device to run on.
+struct SignedDistanceFieldGenerationParameters
+{
+  float oob_value = std::numeric_limits<float>::infinity();
+  bool unknown_is_filled = true;
+  bool add_virtual_border = false;
+  int hip_device = 0;
+};
+
+// SignedDistanceField<float>: values + the minimum / maximum cached by Lock()
+// (signed_distance_field.hpp:765-789).
+struct SignedDistanceField
+{
+  DenseGrid grid;
+  float oob_value = std::numeric_limits<float>::infinity();
+  float minimum = 0.0f, maximum = 0.0f;
+  bool locked = false;
+  bool IsLocked() const { return locked; }
+  float GetIndexImmutable(int64_t x, int64_t y, int64_t z) const
+  {
+    return grid.GetIndexImmutable(x, y, z);
+  }
+};
+
+// PointCloudVoxelizationFilterOptions (pointcloud_voxelization_interface.hpp:20-92).
+class PointCloudVoxelizationFilterOptions
+{
+public:
+  PointCloudVoxelizationFilterOptions() = default;
+  PointCloudVoxelizationFilterOptions(double percent_seen_free, int32_t outlier_points_threshold,
+                                      int32_t num_cameras_seen_free)
+      : percent_seen_free_(percent_seen_free), outlier_points_threshold_(outlier_points_threshold),
+        num_cameras_seen_free_(num_cameras_seen_free)
+  {
+    if (percent_seen_free_ <= 0.0 || percent_seen_free_ > 1.0)
+      throw std::invalid_argument("0 < percent_seen_free_ <= 1 must be true");
+    if (outlier_points_threshold_ <= 0) throw std::invalid_argument("outlier_points_threshold_ <= 0");
+    if (num_cameras_seen_free_ <= 0) throw std::invalid_argument("num_cameras_seen_free_ <= 0");
+  }
+  double PercentSeenFree() const { return percent_seen_free_; }
+  int32_t OutlierPointsThreshold() const { return outlier_points_threshold_; }
+  int32_t NumCamerasSeenFree() const { return num_cameras_seen_free_; }
+
+private:
+  double percent_seen_free_ = 1.0;
+  int32_t outlier_points_threshold_ = 1;
+  int32_t num_cameras_seen_free_ = 1;
+};
+
+// PointCloudWrapper (pointcloud_voxelization_interface.hpp:94-202): abstract point source.
+class PointCloudWrapper
+{
+public:
+  virtual ~PointCloudWrapper() {}
+  virtual double MaxRange() const = 0;
+  virtual int64_t Size() const = 0;
+  virtual const Isometry3& PointCloudOriginTransform() const = 0;
+  void CopyPointLocationIntoFloatPtr(int64_t point_index, float* destination) const
+  {
+    if (point_index < 0 || point_index >= Size()) throw std::out_of_range("point_index out of range");
+    CopyPointLocationIntoFloatPtrImpl(point_index, destination);
+  }
+
+protected:
+  virtual void CopyPointLocationIntoFloatPtrImpl(int64_t point_index, float* destination) const = 0;
+};
+using PointCloudWrapperSharedPtr = std::shared_ptr<PointCloudWrapper>;
+
+// VoxelizerRuntime (pointcloud_voxelization_interface.hpp:206-229).
+class VoxelizerRuntime
+{
+public:
+  VoxelizerRuntime(double raycasting_time, double filtering_time)
+      : raycasting_time_(raycasting_time), filtering_time_(filtering_time)
+  {
+    if (raycasting_time_ < 0.0) throw std::invalid_argument("raycasting_time < 0.0");
+    if (filtering_time_ < 0.0) throw std::invalid_argument("filtering_time < 0.0");
+  }
+  double RaycastingTime() const { return raycasting_time_; }
+  double FilteringTime() const { return filtering_time_; }
+
+private:
+  double raycasting_time_ = 0.0, filtering_time_ = 0.0;
+};
+}  // namespace vgt_hip

@@ -1,0 +1,253 @@
+// C++ parity tests through the host layer (include/vgt_hip/), written after the reference's
+// own gtest suites: test/sdf_generation_test.cpp and test/pointcloud_voxelization_test.cpp.
+// No gtest in this image: a tiny EXPECT macro set; exit code = number of failures.
+//   test_hip_host            all tests (needs a HIP device)
+//   test_hip_host --no-device  only the "backend unavailable" behaviour (CPU box)
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <limits>
+
+#include "../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
+
+using namespace vgt_hip;
+namespace hip_helpers = voxelized_geometry_tools::pointcloud_voxelization::hip_helpers;
+
+static int g_failures = 0;
+#define EXPECT_TRUE(cond)                                                              \
+  do {                                                                                 \
+    if (!(cond)) { g_failures++; std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+#define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
+#define EXPECT_FLOAT_EQ(a, b) EXPECT_TRUE(AlmostEqualUlps((a), (b)))
+
+static bool AlmostEqualUlps(float a, float b)  // gtest's EXPECT_FLOAT_EQ: within 4 ULPs
+{
+  if (a == b) return true;
+  int32_t ia, ib;
+  std::memcpy(&ia, &a, 4);
+  std::memcpy(&ib, &b, 4);
+  if ((ia < 0) != (ib < 0)) return false;
+  return std::abs(ia - ib) <= 4;
+}
+
+static bool CloseEnough(float a, float b) { return a == b || std::abs(a - b) <= 0.0001f; }
+
+static OccupancyMap MakeMap(double res, double xs, double ys, double zs, float fill)
+{
+  return OccupancyMap::FromGridSizes(Isometry3::Translation(-5.0, -5.0, -5.0), "test_frame", res,
+                                     xs, ys, zs, fill);
+}
+
+static void FillBox(OccupancyMap& m, int x0, int x1, int y0, int y1, int z0, int z1)
+{
+  for (int x = x0; x < x1; x++)
+    for (int y = y0; y < y1; y++)
+      for (int z = z0; z < z1; z++) m.SetIndex(x, y, z, 1.0f);
+}
+
+// TestSDFGeneration (test/sdf_generation_test.cpp:140-260): extrema + sign of every voxel.
+static void CheckSdf(const OccupancyMap& map, float expected_min, float expected_max)
+{
+  const SignedDistanceField sdf = ExtractSignedDistanceField(map, {});
+  EXPECT_TRUE(sdf.IsLocked());
+  EXPECT_TRUE(CloseEnough(sdf.minimum, expected_min));
+  EXPECT_TRUE(CloseEnough(sdf.maximum, expected_max));
+  EXPECT_EQ(sdf.grid.NumXVoxels(), map.NumXVoxels());
+  for (int64_t x = 0; x < map.NumXVoxels(); x++)
+    for (int64_t y = 0; y < map.NumYVoxels(); y++)
+      for (int64_t z = 0; z < map.NumZVoxels(); z++)
+      {
+        if (map.GetIndexImmutable(x, y, z) >= 0.5f)
+          EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) < 0.0f);
+        else
+          EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) > 0.0f);
+      }
+}
+
+static void SdfGenerationTests()
+{
+  const float inf = std::numeric_limits<float>::infinity();
+  CheckSdf(MakeMap(0.25, 1, 2, 3, 1.0f), -inf, -inf);  // FullyFilledTest
+  CheckSdf(MakeMap(0.25, 1, 2, 3, 0.0f), inf, inf);    // FullyEmptyTest
+  {                                                     // CenterObstacleTest
+    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
+    EXPECT_EQ(m.NumXVoxels(), 4);
+    EXPECT_EQ(m.NumYVoxels(), 8);
+    EXPECT_EQ(m.NumZVoxels(), 12);
+    FillBox(m, 1, 3, 2, 6, 3, 9);
+    CheckSdf(m, -0.25f, static_cast<float>(std::sqrt(0.25 * 0.25 + 0.5 * 0.5 + 0.75 * 0.75)));
+  }
+  {  // CornerObstacleTest
+    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
+    FillBox(m, 0, 2, 0, 4, 0, 6);
+    CheckSdf(m, -0.5f, 1.8708f);
+  }
+  {  // FaceObstacleTest
+    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
+    FillBox(m, 0, 4, 0, 8, 0, 1);
+    CheckSdf(m, -0.25f, 2.75f);
+  }
+  {  // LinearExactTest
+    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 1, 1, 4, 0.0f);
+    FillBox(m, 0, 1, 0, 1, 0, 2);
+    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+    const float want[4] = {-2.0f, -1.0f, 1.0f, 2.0f};
+    for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
+  }
+  {  // PlanarExactTest
+    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 1, 4, 4, 0.0f);
+    FillBox(m, 0, 1, 0, 2, 0, 2);
+    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+    const float s2 = std::sqrt(2.0f), s5 = std::sqrt(5.0f), s8 = std::sqrt(8.0f);
+    const float want[4][4] = {{-2, -1, 1, 2}, {-1, -1, 1, 2}, {1, 1, s2, s5}, {2, 2, s5, s8}};
+    for (int y = 0; y < 4; y++)
+      for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, y, z), want[y][z]);
+  }
+  {  // CubeExactTest
+    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 2, 2, 2, 0.0f);
+    m.SetIndex(0, 0, 0, 1.0f);
+    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+    const float s2 = std::sqrt(2.0f), s3 = std::sqrt(3.0f);
+    const float want[8] = {-1, 1, 1, s2, 1, s2, s2, s3};
+    for (int i = 0; i < 8; i++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(i >> 2, (i >> 1) & 1, i & 1), want[i]);
+  }
+}
+
+// ---- test/pointcloud_voxelization_test.cpp ----
+class VectorPointCloudWrapper : public PointCloudWrapper
+{
+public:
+  void PushBack(double x, double y, double z) { points_.push_back({x, y, z}); }
+  double MaxRange() const override { return std::numeric_limits<double>::infinity(); }
+  int64_t Size() const override { return static_cast<int64_t>(points_.size()); }
+  const Isometry3& PointCloudOriginTransform() const override { return origin_; }
+  void SetPointCloudOriginTransform(const Isometry3& t) { origin_ = t; }
+
+private:
+  void CopyPointLocationIntoFloatPtrImpl(int64_t i, float* dst) const override
+  {
+    for (int a = 0; a < 3; a++) dst[a] = static_cast<float>(points_[static_cast<size_t>(i)][a]);
+  }
+  std::vector<std::array<double, 3>> points_;
+  Isometry3 origin_;
+};
+
+static void check_empty_voxelization(const OccupancyMap& occupancy)
+{
+  for (int64_t x = 0; x < occupancy.NumXVoxels(); x++)
+    for (int64_t y = 0; y < occupancy.NumYVoxels(); y++)
+      for (int64_t z = 0; z < occupancy.NumZVoxels(); z++)
+        EXPECT_EQ(occupancy.GetIndexImmutable(x, y, z), (z == 0) ? 1.0f : 0.5f);
+}
+
+static void check_voxelization(const OccupancyMap& occupancy)
+{
+  for (int64_t x = 0; x < occupancy.NumXVoxels(); x++)
+    for (int64_t y = 0; y < occupancy.NumYVoxels(); y++)
+      for (int64_t z = 0; z < occupancy.NumZVoxels(); z++)
+      {
+        const float occ = occupancy.GetIndexImmutable(x, y, z);
+        if (z == 0) EXPECT_EQ(occ, 1.0f);
+        if ((x == 3) && (y >= 3) && (z >= 1)) EXPECT_EQ(occ, 0.0f);
+        if ((x >= 3) && (y == 3) && (z >= 1)) EXPECT_EQ(occ, 0.0f);
+        if ((x == 4) && (y >= 4) && (z >= 1)) EXPECT_EQ(occ, 1.0f);
+        if ((x >= 4) && (y == 4) && (z >= 1)) EXPECT_EQ(occ, 1.0f);
+        if ((x > 4) && (y > 4) && (z >= 1)) EXPECT_EQ(occ, 0.5f);
+      }
+}
+
+static Isometry3 QuatZ_then_X(double az, double ax, double tx, double ty, double tz)
+{
+  // Quaternion(AngleAxis(az, Z) * AngleAxis(ax, X))
+  const double wz = std::cos(az / 2), sz = std::sin(az / 2);
+  const double wx = std::cos(ax / 2), sx = std::sin(ax / 2);
+  const double w = wz * wx, x = wz * sx, y = sz * sx, z = sz * wx;
+  return Isometry3::FromQuaternion(w, x, y, z, tx, ty, tz);
+}
+
+static void PointCloudVoxelizationTests(int dispatch_threads)
+{
+  OccupancyMap static_environment = OccupancyMap::FromGridSizes(
+      Isometry3::Translation(-1.0, -1.0, -1.0), "world", 0.25, 2.0, 2.0, 2.0, 0.0f);
+  for (int64_t x = 0; x < static_environment.NumXVoxels(); x++)
+    for (int64_t y = 0; y < static_environment.NumYVoxels(); y++)
+      static_environment.SetIndex(x, y, 0, 1.0f);
+
+  const Isometry3 X_CO = QuatZ_then_X(-M_PI_2, -M_PI_2, 0, 0, 0);
+  auto cam1 = std::make_shared<VectorPointCloudWrapper>();
+  cam1->SetPointCloudOriginTransform(Isometry3::Translation(-2.0, 0.0, 0.0) * X_CO);
+  auto cam2 = std::make_shared<VectorPointCloudWrapper>();
+  cam2->SetPointCloudOriginTransform(QuatZ_then_X(M_PI_2, 0.0, 0.0, -2.0, 0.0) * X_CO);
+  for (double x = -2.0; x <= 2.0; x += 0.03125)
+    for (double y = -2.0; y <= 2.0; y += 0.03125)
+    {
+      cam1->PushBack(x, y, (x <= 0.0) ? 2.125 : 4.0);
+      cam2->PushBack(x, y, (x >= 0.0) ? 2.125 : 4.0);
+    }
+  auto cam3 = std::make_shared<VectorPointCloudWrapper>();  // empty cloud
+  cam3->SetPointCloudOriginTransform(X_CO);
+
+  const PointCloudVoxelizationFilterOptions filter_options(1.0, 1, 1);
+  std::map<std::string, int32_t> options;
+  options["DISPATCH_PARALLELIZE"] = dispatch_threads > 1 ? 1 : 0;
+  options["DISPATCH_NUM_THREADS"] = dispatch_threads;
+  const auto logging_fn = [](const std::string& msg) { std::cout << msg << std::endl; };
+
+  for (const auto& device : hip_helpers::GetAvailableDevices())
+  {
+    std::map<std::string, int32_t> merged = device.DeviceOptions();
+    for (const auto& kv : options) merged[kv.first] = kv.second;
+    std::cout << "Trying voxelizer " << device.DeviceName() << std::endl;
+    const HipPointCloudVoxelizer voxelizer(merged, logging_fn);
+    check_empty_voxelization(voxelizer.VoxelizePointClouds(static_environment, filter_options, {}));
+    double raycast_s = -1.0;
+    const OccupancyMap voxelized = voxelizer.VoxelizePointClouds(
+        static_environment, filter_options, {cam1, cam2, cam3},
+        [&](const VoxelizerRuntime& rt) { raycast_s = rt.RaycastingTime(); });
+    check_voxelization(voxelized);
+    EXPECT_TRUE(raycast_s >= 0.0);
+    // argument validation of the public entry point (pointcloud_voxelization_interface.hpp:267-289)
+    bool threw = false;
+    try { voxelizer.VoxelizePointClouds(static_environment, filter_options, {nullptr}); }
+    catch (const std::invalid_argument&) { threw = true; }
+    EXPECT_TRUE(threw);
+    // null logging function must be accepted
+    const HipPointCloudVoxelizer quiet(merged, {});
+  }
+  EXPECT_TRUE(!hip_helpers::GetAvailableDevices().empty());
+}
+
+static void UnavailableBackendTests()
+{
+  // a device index that cannot exist: the helper constructs but is unavailable, the voxelizer
+  // constructor throws std::runtime_error (device_pointcloud_voxelization.hpp:34-46)
+  std::map<std::string, int32_t> options;
+  options["HIP_DEVICE"] = 4096;
+  const auto helper = hip_helpers::MakeHipVoxelizationHelper(options, {});
+  EXPECT_TRUE(helper != nullptr);
+  EXPECT_TRUE(!helper->IsAvailable());
+  bool threw = false;
+  try { HipPointCloudVoxelizer v(options); }
+  catch (const std::runtime_error& ex) { threw = std::string(ex.what()).find("not available") != std::string::npos; }
+  EXPECT_TRUE(threw);
+  threw = false;
+  try { PointCloudVoxelizationFilterOptions bad(0.0, 1, 1); }
+  catch (const std::invalid_argument&) { threw = true; }
+  EXPECT_TRUE(threw);
+}
+
+int main(int argc, char** argv)
+{
+  const bool no_device = (argc > 1 && std::strcmp(argv[1], "--no-device") == 0);
+  UnavailableBackendTests();
+  if (!no_device)
+  {
+    SdfGenerationTests();
+    PointCloudVoxelizationTests(1);
+    PointCloudVoxelizationTests(4);
+  }
+  std::printf("%s: %d failure(s)\n", g_failures ? "FAILED" : "PASSED", g_failures);
+  return g_failures ? 1 : 0;
+}

@@ -1,0 +1,185 @@
+// HipPointCloudVoxelizer / ExtractSignedDistanceField: host orchestration over the HIP helper
+// and the C ABI.  Mirrors src/voxelized_geometry_tools/device_pointcloud_voxelization.cpp:65-181.
+#include "../../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <mutex>
+#include <thread>
+
+#include "../../../include/vgt_hip.h"
+
+namespace vgt_hip
+{
+using voxelized_geometry_tools::pointcloud_voxelization::FilterGridHandle;
+using voxelized_geometry_tools::pointcloud_voxelization::RetrieveOptionOrDefault;
+using voxelized_geometry_tools::pointcloud_voxelization::TrackingGridsHandle;
+namespace hip_helpers = voxelized_geometry_tools::pointcloud_voxelization::hip_helpers;
+
+HipPointCloudVoxelizer::HipPointCloudVoxelizer(const std::map<std::string, int32_t>& options,
+                                               const LoggingFunction& logging_fn)
+{
+  const int32_t parallelize = RetrieveOptionOrDefault(options, "DISPATCH_PARALLELIZE", 1, logging_fn);
+  const int32_t num_threads = RetrieveOptionOrDefault(options, "DISPATCH_NUM_THREADS", -1, logging_fn);
+  if (parallelize > 0 && num_threads >= 1)
+    dispatch_threads_ = num_threads;
+  else if (parallelize > 0)
+    dispatch_threads_ = std::max(1u, std::thread::hardware_concurrency());
+  else
+    dispatch_threads_ = 1;
+  helper_interface_ = hip_helpers::MakeHipVoxelizationHelper(options, logging_fn);
+  EnforceAvailable();
+}
+
+void HipPointCloudVoxelizer::EnforceAvailable() const
+{
+  if (!helper_interface_)
+    throw std::runtime_error(device_name_ + " is not available (feature was not built)");
+  if (!helper_interface_->IsAvailable())
+    throw std::runtime_error(device_name_ + " is not available (device cannot be used)");
+}
+
+OccupancyMap HipPointCloudVoxelizer::VoxelizePointClouds(
+    const OccupancyMap& static_environment,
+    const PointCloudVoxelizationFilterOptions& filter_options,
+    const std::vector<PointCloudWrapperSharedPtr>& pointclouds,
+    const std::function<void(const VoxelizerRuntime&)>& runtime_log_fn) const
+{
+  OccupancyMap output_environment = static_environment;
+  const VoxelizerRuntime runtime =
+      VoxelizePointClouds(static_environment, filter_options, pointclouds, output_environment);
+  if (runtime_log_fn) runtime_log_fn(runtime);
+  return output_environment;
+}
+
+VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
+    const OccupancyMap& static_environment,
+    const PointCloudVoxelizationFilterOptions& filter_options,
+    const std::vector<PointCloudWrapperSharedPtr>& pointclouds,
+    OccupancyMap& output_environment) const
+{
+  if (!static_environment.IsInitialized())
+    throw std::invalid_argument("!static_environment.IsInitialized()");
+  if (!output_environment.IsInitialized())
+    throw std::invalid_argument("!output_environment.IsInitialized()");
+  if (!static_environment.SameSizes(output_environment))
+    throw std::invalid_argument(
+        "static_environment.ControlSizes() != output_environment.ControlSizes()");
+  for (size_t idx = 0; idx < pointclouds.size(); idx++)
+    if (!pointclouds[idx])
+      throw std::invalid_argument("pointclouds[" + std::to_string(idx) + "] is null");
+  EnforceAvailable();
+
+  const auto start_time = std::chrono::steady_clock::now();
+
+  // at least one tracking grid so that filtering is uniform when there are no clouds
+  const size_t num_tracking_grids = std::max(pointclouds.size(), static_cast<size_t>(1));
+  std::unique_ptr<TrackingGridsHandle> tracking_grids = helper_interface_->PrepareTrackingGrids(
+      static_environment.NumTotalVoxels(), static_cast<int32_t>(num_tracking_grids));
+  if (tracking_grids->GetNumTrackingGrids() != num_tracking_grids)
+    throw std::runtime_error("Failed to allocate device tracking grid");
+
+  const Isometry3& X_GW = static_environment.InverseOriginTransform();
+  const float voxel_size = static_cast<float>(static_environment.VoxelXSize());
+  const float inverse_voxel_size = static_cast<float>(1.0 / static_environment.VoxelXSize());
+  const float grid_x_size = static_cast<float>(static_environment.GridXSize());
+  const float grid_y_size = static_cast<float>(static_environment.GridYSize());
+  const float grid_z_size = static_cast<float>(static_environment.GridZSize());
+  const int32_t num_x_voxels = static_cast<int32_t>(static_environment.NumXVoxels());
+  const int32_t num_y_voxels = static_cast<int32_t>(static_environment.NumYVoxels());
+  const int32_t num_z_voxels = static_cast<int32_t>(static_environment.NumZVoxels());
+
+  const auto raycast_cloud = [&](const size_t cloud_index)
+  {
+    const PointCloudWrapperSharedPtr& cloud = pointclouds[cloud_index];
+    if (cloud->Size() <= 0) return;  // empty arrays never reach the device interface
+    const std::array<float, 16> X_GC = (X_GW * cloud->PointCloudOriginTransform()).CastFloat();
+    const float max_range = static_cast<float>(cloud->MaxRange());
+    std::vector<float> raw_points(static_cast<size_t>(cloud->Size()) * 3, 0.0f);
+    for (int64_t point = 0; point < cloud->Size(); point++)
+      cloud->CopyPointLocationIntoFloatPtr(point, raw_points.data() + point * 3);
+    helper_interface_->RaycastPoints(raw_points, max_range, X_GC.data(), voxel_size,
+                                     inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size,
+                                     num_x_voxels, num_y_voxels, num_z_voxels, *tracking_grids,
+                                     cloud_index);
+  };
+
+  // dynamic dispatch over clouds from several host threads, like DynamicParallelForIndexLoop
+  const int workers =
+      std::max(1, std::min(dispatch_threads_, static_cast<int>(pointclouds.size())));
+  if (workers <= 1)
+  {
+    for (size_t idx = 0; idx < pointclouds.size(); idx++) raycast_cloud(idx);
+  }
+  else
+  {
+    std::atomic<size_t> next{0};
+    std::exception_ptr failure;
+    std::mutex failure_mutex;
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; w++)
+    {
+      pool.emplace_back([&]()
+      {
+        for (;;)
+        {
+          const size_t idx = next.fetch_add(1);
+          if (idx >= pointclouds.size()) return;
+          try
+          {
+            raycast_cloud(idx);
+          }
+          catch (...)
+          {
+            std::lock_guard<std::mutex> lock(failure_mutex);
+            if (!failure) failure = std::current_exception();
+          }
+        }
+      });
+    }
+    for (auto& th : pool) th.join();
+    if (failure) std::rethrow_exception(failure);
+  }
+
+  const auto raycasted_time = std::chrono::steady_clock::now();
+
+  std::unique_ptr<FilterGridHandle> filter_grid = helper_interface_->PrepareFilterGrid(
+      static_environment.NumTotalVoxels(), static_environment.GetImmutableRawData().data());
+  helper_interface_->FilterTrackingGrids(
+      *tracking_grids, static_cast<float>(filter_options.PercentSeenFree()),
+      filter_options.OutlierPointsThreshold(), filter_options.NumCamerasSeenFree(), *filter_grid);
+  helper_interface_->RetrieveFilteredGrid(*filter_grid,
+                                          output_environment.GetMutableRawData().data());
+
+  const auto done_time = std::chrono::steady_clock::now();
+  return VoxelizerRuntime(std::chrono::duration<double>(raycasted_time - start_time).count(),
+                          std::chrono::duration<double>(done_time - raycasted_time).count());
+}
+
+SignedDistanceField ExtractSignedDistanceField(
+    const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters)
+{
+  if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
+  vgt_hip_ctx* ctx = nullptr;
+  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
+    throw std::runtime_error(std::string("HIP SDF backend is not available: ") +
+                             vgt_hip_last_error());
+  SignedDistanceField sdf;
+  sdf.oob_value = parameters.oob_value;
+  sdf.grid = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                       map.NumYVoxels(), map.NumZVoxels(), parameters.oob_value);
+  const int rc = vgt_hip_sdf_from_occupancy_f32(
+      ctx, map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(), map.NumZVoxels(),
+      map.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+      parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(), &sdf.minimum,
+      &sdf.maximum);
+  const std::string msg = (rc == VGT_HIP_OK) ? std::string() : std::string(vgt_hip_last_error());
+  vgt_hip_destroy(ctx);
+  if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+  if (rc != VGT_HIP_OK) throw std::runtime_error(msg);
+  sdf.locked = true;  // min / max were computed on the device: Lock() has nothing left to scan
+  return sdf;
+}
+}  // namespace vgt_hip
