@@ -71,6 +71,8 @@ struct Tile
   int16_t* next_pos;
   uint16_t* cumA;      // [nwords][W] survivors in lower words
   uint16_t* cumT;      // [nwords][W] start bits in lower words
+  uint8_t* min_first;  // [nwords][W] offset of the smallest member of the band's first run portion
+  uint8_t* min_last;   //             ... of its last run portion (255 = none)
   uint64_t* sumA;      // [W] words of A that may be non-empty (superset)
   uint64_t* sumA2;     // [W] words of A2 that are non-empty
   int n;
@@ -185,7 +187,7 @@ size_t TileBytes(int n)
   const size_t nwords = static_cast<size_t>((n + kBandRows - 1) / kBandRows);
   return static_cast<size_t>(n) * W * sizeof(int32_t) + 4 * nwords * W * sizeof(uint32_t) +
          4 * nwords * W * sizeof(int16_t) + 2 * nwords * W * sizeof(uint16_t) +
-         2 * W * sizeof(uint64_t);
+         2 * nwords * W * sizeof(uint8_t) + 2 * W * sizeof(uint64_t);
 }
 
 // SW = lanes used per line in the transposed scans (32 when a line has <= 32 words, else 64).
@@ -213,6 +215,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   t.next_pos = t.next_neg + mw;
   t.cumA = reinterpret_cast<uint16_t*>(t.next_pos + mw);
   t.cumT = t.cumA + mw;
+  t.min_first = reinterpret_cast<uint8_t*>(t.cumT + mw);
+  t.min_last = t.min_first + mw;
   t.n = n;
   t.nwords = nwords;
   t.w = threadIdx.x % W;
@@ -238,61 +242,49 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int r1 = min(r0 + kBandRows, n);
   uint32_t sbits = 0;
 
-  // ---- 1. hull of this band, members only; the stack restarts at every class change ----
+  // ---- 1a. sign word of this band; strongest member (smallest value) of the band's first and
+  // last run portion, published for the neighbouring bands ----
   if (band < nwords)
   {
-    uint32_t abits = 0;
+    int best_first = 255, best_last = 255;  // row offsets inside the band, 255 = none
     if (z < g.nz)
     {
-      bool neg = false, have_run = false;
-      int top = -1, sec = -1, run_bit0 = 0;
-      int32_t Gtop = 0, Gsec = 0;
+      int32_t min_first = kInf32, min_last = kInf32;
+      bool first_portion = true;
+      bool neg = false;
       for (int r = r0; r < r1; r++)
       {
         const int32_t v = t.Raw(r);
         const bool sneg = v < 0;
         const int32_t f = sneg ? -v : v;
         if (sneg) sbits |= 1u << (r - r0);
-        if (!have_run || sneg != neg)
+        if (r > r0 && sneg != neg)
         {
-          neg = sneg;
-          have_run = true;
-          top = sec = -1;
-          run_bit0 = r - r0;
+          first_portion = false;
+          min_last = kInf32;
+          best_last = 255;
         }
-        if (f != kInf32)
+        neg = sneg;
+        if (f < min_last)
         {
-          const int32_t Gc = f + r * r;
-          while (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
-          {
-            VGT_STAT_ADD(8, 1);
-            abits &= ~(1u << (top - r0));
-            top = sec;
-            Gtop = Gsec;
-            const uint32_t m = abits & LowMask(top - r0) & ~LowMask(run_bit0);
-            if (m)
-            {
-              sec = r0 + 31 - __clz(static_cast<int>(m));
-              Gsec = t.Mag(sec) + sec * sec;
-            }
-            else
-              sec = -1;
-          }
-          sec = top;
-          Gsec = Gtop;
-          top = r;
-          Gtop = Gc;
-          abits |= 1u << (r - r0);
+          min_last = f;
+          best_last = r - r0;
+        }
+        if (first_portion && f < min_first)
+        {
+          min_first = f;
+          best_first = r - r0;
         }
       }
     }
     t.S[band * W + t.w] = sbits;
-    t.A[band * W + t.w] = abits;
+    t.min_first[band * W + t.w] = static_cast<uint8_t>(best_first);
+    t.min_last[band * W + t.w] = static_cast<uint8_t>(best_last);
     t.T[band * W + t.w] = 0u;
   }
   __syncthreads();
 
-  // ---- 1b. per word: nearest row of either class below / above, and the summary of A ----
+  // ---- 1b. per word: nearest row of either class below / above ----
   for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
   {
     const int line = tt / SW;
@@ -300,7 +292,6 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     const bool ok = j < nwords;
     const uint32_t s = ok ? t.S[j * W + line] : 0u;
     const uint32_t p = ok ? (~s & LowMask(n - (j << 5))) : 0u;
-    const uint32_t a = ok ? t.A[j * W + line] : 0u;
     int hi_neg = s ? (j << 5) + 31 - __clz(static_cast<int>(s)) : -1;
     int hi_pos = p ? (j << 5) + 31 - __clz(static_cast<int>(p)) : -1;
     int lo_neg = s ? (j << 5) + __ffs(static_cast<int>(s)) - 1 : n;
@@ -320,10 +311,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         lo_pos = min(lo_pos, dp);
       }
     }
-    // exclusive: shift by one word
     const int ex_hn = __shfl_up(hi_neg, 1, SW), ex_hp = __shfl_up(hi_pos, 1, SW);
     const int ex_ln = __shfl_down(lo_neg, 1, SW), ex_lp = __shfl_down(lo_pos, 1, SW);
-    const uint64_t any = __ballot(a != 0u);
     if (ok)
     {
       t.last_neg[j * W + line] = static_cast<int16_t>(j == 0 ? -1 : ex_hn);
@@ -331,6 +320,146 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       t.next_neg[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_ln);
       t.next_pos[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_lp);
     }
+  }
+  __syncthreads();
+
+  // ---- 1c. hull of this band, members only; the stack restarts at every class change.
+  // The run portions that continue into the neighbouring bands are seeded with the most
+  // competitive published member on that side (a real site of the same run): most members that
+  // only a far, strong site removes die here, in parallel, instead of in the merge levels. ----
+  if (band < nwords)
+  {
+    uint32_t abits = 0;
+    if (z < g.nz && !(g.debug_skip & 8))
+    {
+      const int nrows = r1 - r0;
+      // seeds
+      int seed_l = -1, seed_r = -1;
+      int32_t Gseed_l = 0, Gseed_r = 0;
+      if (!(g.debug_skip & 16))
+      {
+        const bool neg0 = sbits & 1u;
+        const int run_a = t.PrevOpp(r0, neg0) + 1;
+        int32_t best = kInf32;
+        for (int alpha = band - 1; alpha >= 0 && ((alpha << 5) + 31) >= run_a; alpha--)
+        {
+          const int off = t.min_last[alpha * W + t.w];
+          const int row = (alpha << 5) + off;
+          if (off == 255 || row < run_a) continue;
+          const int32_t f = t.Mag(row);
+          if (f == kInf32) continue;
+          const int32_t val = (r0 - row) * (r0 - row) + f;
+          if (val < best)
+          {
+            best = val;
+            seed_l = row;
+            Gseed_l = f + row * row;
+          }
+        }
+        const int q_last = r1 - 1;
+        const bool neg1 = (sbits >> (nrows - 1)) & 1u;
+        const int run_b = t.NextOpp(q_last, neg1) - 1;
+        best = kInf32;
+        for (int beta = band + 1; beta < nwords && (beta << 5) <= run_b; beta++)
+        {
+          const int off = t.min_first[beta * W + t.w];
+          const int row = (beta << 5) + off;
+          if (off == 255 || row > run_b) continue;
+          const int32_t f = t.Mag(row);
+          if (f == kInf32) continue;
+          const int32_t val = (q_last - row) * (q_last - row) + f;
+          if (val < best)
+          {
+            best = val;
+            seed_r = row;
+            Gseed_r = f + row * row;
+          }
+        }
+      }
+
+      // one predicate test or one push per iteration (lanes never wait for each other's pops)
+      bool neg = false, have_run = false;
+      int top = -1, sec = -1, run_bit0 = 0, bottom_seed = -1;
+      int32_t Gtop = 0, Gsec = 0;
+      auto pop = [&]() {
+        VGT_STAT_ADD(8, 1);
+        abits &= ~(1u << (top - r0));
+        top = sec;
+        Gtop = Gsec;
+        sec = -1;
+        if (top != bottom_seed)
+        {
+          const uint32_t m = abits & LowMask(top - r0) & ~LowMask(run_bit0);
+          if (m)
+          {
+            sec = r0 + 31 - __clz(static_cast<int>(m));
+            Gsec = t.Mag(sec) + sec * sec;
+          }
+          else if (bottom_seed >= 0)
+          {
+            sec = bottom_seed;
+            Gsec = Gseed_l;
+          }
+        }
+      };
+      int k = 0;
+      int32_t vcur = t.Raw(r0);
+      while (k < nrows)
+      {
+        const int r = r0 + k;
+        const bool sneg = vcur < 0;
+        const int32_t f = sneg ? -vcur : vcur;
+        if (!have_run || sneg != neg)
+        {
+          neg = sneg;
+          have_run = true;
+          run_bit0 = k;
+          top = sec = -1;
+          bottom_seed = -1;
+          if (k == 0 && seed_l >= 0)
+          {
+            top = seed_l;
+            Gtop = Gseed_l;
+            bottom_seed = seed_l;
+          }
+        }
+        if (f != kInf32)
+        {
+          const int32_t Gc = f + r * r;
+          if (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
+          {
+            pop();
+            continue;  // same row again
+          }
+          sec = top;
+          Gsec = Gtop;
+          top = r;
+          Gtop = Gc;
+          abits |= 1u << k;
+        }
+        k++;
+        if (k < nrows) vcur = t.Raw(r0 + k);
+      }
+      if (seed_r >= 0)
+        while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gseed_r, seed_r)) pop();
+    }
+    else if (z < g.nz)
+    {
+      // debug: every finite member survives the band phase
+      for (int r = r0; r < r1; r++)
+        if (t.Mag(r) != kInf32) abits |= 1u << (r - r0);
+    }
+    t.A[band * W + t.w] = abits;
+  }
+  __syncthreads();
+
+  // ---- 1d. summary of A: which mask words of a line are non-empty ----
+  for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
+  {
+    const int line = tt / SW;
+    const int j = tt % SW;
+    const uint32_t a = (j < nwords) ? t.A[j * W + line] : 0u;
+    const uint64_t any = __ballot(a != 0u);
     if (j == 0)
     {
       const int sh = (threadIdx.x & 63) / SW * SW;  // 0 or 32 when SW == 32
