@@ -50,6 +50,9 @@ def main():
         for i in range(7, 11):
             print("  %-14s %14d  %8.3f per voxel" % (NAMES[i], vals[i], vals[i] / vox))
         print("  %-14s %14d" % (NAMES[12], vals[12]))
+        sub = [out[base + i] for i in (11, 13, 14, 15)]
+        print("  local split (thread 0): rows->regs %d, carries %d, seeds %d, prefilter %d cycles/WG" %
+              tuple(v / wg for v in sub))
 
 
 if __name__ == "__main__":

@@ -242,39 +242,39 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int r1 = min(r0 + kBandRows, n);
   uint32_t sbits = 0;
 
-  // ---- 1a. sign word of this band; strongest member (smallest value) of the band's first and
-  // last run portion, published for the neighbouring bands ----
+  // ---- 1a. this band's rows into registers; sign word; strongest member (smallest value) of
+  // the band's first and last run portion, published for the neighbouring bands ----
+  int32_t fr[kBandRows];  // magnitudes, kInf32 = not a site (also rows past the end)
+  uint32_t finite = 0;
   if (band < nwords)
   {
-    int best_first = 255, best_last = 255;  // row offsets inside the band, 255 = none
-    if (z < g.nz)
+#pragma unroll
+    for (int k = 0; k < kBandRows; k++)
     {
-      int32_t min_first = kInf32, min_last = kInf32;
-      bool first_portion = true;
-      bool neg = false;
-      for (int r = r0; r < r1; r++)
+      int32_t v = kInf32;
+      if (z < g.nz && r0 + k < n) v = t.Raw(r0 + k);
+      if (v < 0) sbits |= 1u << k;
+      fr[k] = v < 0 ? -v : v;
+      if (fr[k] != kInf32) finite |= 1u << k;
+    }
+    // flips: bit k set when row k starts a new run portion inside the band
+    const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(r1 - r0);
+    const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;  // first portion = [0, first_end)
+    const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;     // last portion = [last_begin, ..)
+    int32_t min_first = kInf32, min_last = kInf32;
+    int best_first = 255, best_last = 255;
+#pragma unroll
+    for (int k = 0; k < kBandRows; k++)
+    {
+      if (k < first_end && fr[k] < min_first)
       {
-        const int32_t v = t.Raw(r);
-        const bool sneg = v < 0;
-        const int32_t f = sneg ? -v : v;
-        if (sneg) sbits |= 1u << (r - r0);
-        if (r > r0 && sneg != neg)
-        {
-          first_portion = false;
-          min_last = kInf32;
-          best_last = 255;
-        }
-        neg = sneg;
-        if (f < min_last)
-        {
-          min_last = f;
-          best_last = r - r0;
-        }
-        if (first_portion && f < min_first)
-        {
-          min_first = f;
-          best_first = r - r0;
-        }
+        min_first = fr[k];
+        best_first = k;
+      }
+      if (k >= last_begin && fr[k] < min_last)
+      {
+        min_last = fr[k];
+        best_last = k;
       }
     }
     t.S[band * W + t.w] = sbits;
@@ -284,6 +284,9 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   }
   __syncthreads();
 
+#ifdef VGT_HULL_STATS
+  const long long clk1a = clock64();
+#endif
   // ---- 1b. per word: nearest row of either class below / above ----
   for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
   {
@@ -323,6 +326,9 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   }
   __syncthreads();
 
+#ifdef VGT_HULL_STATS
+  const long long clk1b = clock64();
+#endif
   // ---- 1c. hull of this band, members only; the stack restarts at every class change.
   // The run portions that continue into the neighbouring bands are seeded with the most
   // competitive published member on that side (a real site of the same run): most members that
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   if (band < nwords)
   {
     uint32_t abits = 0;
-    if (z < g.nz && !(g.debug_skip & 8))
+    if (z < g.nz && !(g.debug_skip & 8) && finite)
     {
       const int nrows = r1 - r0;
       // seeds
@@ -377,7 +383,58 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         }
       }
 
-      // one predicate test or one push per iteration (lanes never wait for each other's pops)
+#ifdef VGT_HULL_STATS
+      const long long clk_seeds = clock64();
+#endif
+      // Prefilter, branch-free over the register-resident rows: a member that is matched or
+      // beaten AT ITS OWN ROW by a site on its left and by a site on its right never owns a row
+      // (the left one wins everywhere below, the right one everywhere above), so it need not
+      // enter the stack.  Sites tried: the seeds and the members 1, 2 and 4 rows away in the
+      // same run portion.
+      uint32_t cand = finite;
+      if (!(g.debug_skip & 32))
+      {
+        const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(nrows);
+        const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;
+        const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;
+        const int32_t fseed_l = (seed_l >= 0) ? Gseed_l - seed_l * seed_l : kInf32;
+        const int32_t fseed_r = (seed_r >= 0) ? Gseed_r - seed_r * seed_r : kInf32;
+        uint32_t dead = 0;
+#pragma unroll
+        for (int k = 0; k < kBandRows; k++)
+        {
+          const int32_t f = fr[k];
+          int32_t left = kInf32, right = kInf32;
+          if (seed_l >= 0 && k < first_end) left = fseed_l + (r0 + k - seed_l) * (r0 + k - seed_l);
+          if (seed_r >= 0 && k >= last_begin) right = fseed_r + (seed_r - r0 - k) * (seed_r - r0 - k);
+#pragma unroll
+          for (int d = 1; d <= 4; d <<= 1)
+          {
+            if (k - d >= 0)
+            {
+              // same portion: no flip in (k-d, k]
+              const bool same = ((flips >> (k - d + 1)) & LowMask(d)) == 0u;
+              const int32_t u = fr[k - d];
+              if (same && u != kInf32) left = min(left, u + d * d);
+            }
+            if (k + d < kBandRows)
+            {
+              const bool same = ((flips >> (k + 1)) & LowMask(d)) == 0u;
+              const int32_t u = fr[k + d];
+              if (same && u != kInf32) right = min(right, u + d * d);
+            }
+          }
+          if (left <= f && right <= f) dead |= 1u << k;
+        }
+        cand &= ~dead;
+      }
+
+#ifdef VGT_HULL_STATS
+      const long long clk_pref = clock64();
+      if (threadIdx.x == 0) { VGT_CLK_ADD(14, clk_seeds - clk1b); VGT_CLK_ADD(15, clk_pref - clk_seeds); }
+#endif
+      // stack over the remaining candidates: one predicate test or one push per iteration
+      // (lanes never wait for each other's pops)
       bool neg = false, have_run = false;
       int top = -1, sec = -1, run_bit0 = 0, bottom_seed = -1;
       int32_t Gtop = 0, Gsec = 0;
@@ -402,48 +459,60 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           }
         }
       };
-      int k = 0;
-      int32_t vcur = t.Raw(r0);
-      while (k < nrows)
+      VGT_STAT_ADD(11, __popc(finite));
+      VGT_STAT_ADD(13, __popc(cand));
+      uint32_t todo = cand;
+      int k = todo ? __ffs(static_cast<int>(todo)) - 1 : kBandRows;
+      int32_t fcur = (k < kBandRows) ? t.Mag(r0 + k) : 0;
+      while (k < kBandRows)
       {
         const int r = r0 + k;
-        const bool sneg = vcur < 0;
-        const int32_t f = sneg ? -vcur : vcur;
-        if (!have_run || sneg != neg)
+        const bool sneg = (sbits >> k) & 1u;
+        // a new run portion begins when the class differs from the previous candidate's or a
+        // row of the other class lies in between
+        const uint32_t flips_between =
+            have_run ? ((sbits ^ (neg ? ~0u : 0u)) & LowMask(k + 1) & ~LowMask(run_bit0)) : 1u;
+        if (flips_between)
         {
           neg = sneg;
           have_run = true;
-          run_bit0 = k;
+          // first row of the portion that holds k
+          const uint32_t other_below = (sneg ? ~sbits : sbits) & LowMask(k);
+          run_bit0 = other_below ? 32 - __clz(static_cast<int>(other_below)) : 0;
           top = sec = -1;
           bottom_seed = -1;
-          if (k == 0 && seed_l >= 0)
+          if (run_bit0 == 0 && seed_l >= 0)
           {
             top = seed_l;
             Gtop = Gseed_l;
             bottom_seed = seed_l;
           }
         }
-        if (f != kInf32)
+        const int32_t Gc = fcur + r * r;
+        if (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
         {
-          const int32_t Gc = f + r * r;
-          if (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
-          {
-            pop();
-            continue;  // same row again
-          }
-          sec = top;
-          Gsec = Gtop;
-          top = r;
-          Gtop = Gc;
-          abits |= 1u << k;
+          pop();
+          continue;  // same candidate again
         }
-        k++;
-        if (k < nrows) vcur = t.Raw(r0 + k);
+        sec = top;
+        Gsec = Gtop;
+        top = r;
+        Gtop = Gc;
+        abits |= 1u << k;
+        todo &= todo - 1u;
+        k = todo ? __ffs(static_cast<int>(todo)) - 1 : kBandRows;
+        if (k < kBandRows) fcur = t.Mag(r0 + k);
+      }
+      // the right seed closes the portion that reaches the end of the band
+      if (seed_r >= 0 && have_run)
+      {
+        const uint32_t other_after = (neg ? ~sbits : sbits) & LowMask(nrows) & ~LowMask(run_bit0);
+        if (other_after) seed_r = -1;  // the last candidate's portion ends inside the band
       }
       if (seed_r >= 0)
         while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gseed_r, seed_r)) pop();
     }
-    else if (z < g.nz)
+    else if (z < g.nz && (g.debug_skip & 8))
     {
       // debug: every finite member survives the band phase
       for (int r = r0; r < r1; r++)
@@ -769,6 +838,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   {
     const long long clk5 = clock64();
     VGT_CLK_ADD(0, clk1 - clk0);
+    VGT_CLK_ADD(11, clk1a - clk1);
+    VGT_CLK_ADD(13, clk1b - clk1a);
     VGT_CLK_ADD(1, clk2 - clk1);
     VGT_CLK_ADD(2, clk3 - clk2);
     VGT_CLK_ADD(3, clk4 - clk3);
@@ -779,12 +850,14 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 }
 
-// Lines per tile for n rows: the tile must fit in LDS and the (line, band) threads in one
-// workgroup; a line may have at most 64 mask words (one wave-wide scan).
+// Lines per tile for n rows.  32 lines (128-byte int32 rows) while two workgroups still fit in
+// one CU's LDS (tile <= 64 KiB); otherwise 16 lines: half the row width but twice the resident
+// workgroups up to n = 1024 (measured 15 % faster than 32 x 1024 with one workgroup per CU).  A
+// line may have at most 64 mask words (one wave-wide scan), i.e. n <= 2048.
 int LinesPerTile(int64_t n)
 {
   const int64_t rows = (n + kBandRows - 1) / kBandRows * kBandRows;
-  if (rows * 32 <= 32768) return 32;
+  if (rows * 32 <= 16384) return 32;
   if (rows * 16 <= 32768) return 16;
   return 0;
 }
@@ -823,7 +896,7 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
 {
   static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
   int W = LinesPerTile(g.n);
-  if (W == 32 && force_w == 16) W = 16;  // experiment: half-width tiles, two workgroups per CU
+  if (force_w == 32 && g.n <= 1024) W = 32;  // experiment knob: full-width tiles
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
