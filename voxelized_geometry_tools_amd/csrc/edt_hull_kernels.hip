@@ -21,7 +21,8 @@
 // between them):
 //   1  each thread builds the hull of its band (stack algorithm, exact integer predicate)
 //   1b per-word carries of the nearest row of either class below/above (wave scans)
-//   2  hulls of adjacent blocks are merged pairwise (log2(bands) levels, tangent walk)
+//   2  the band hulls are joined at every band boundary at once (tangent walks with atomic bit
+//      clears), in rounds, until a round changes nothing
 //   2b every surviving member computes the first row it owns (exact floor division); members
 //      that own no row are dropped, the others set a "start" bit at that row
 //   2c per-word prefix counts of survivors and of start bits (wave scans)
@@ -540,125 +541,64 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const long long clk2 = clock64();
 #endif
 
-  // ---- 2. merge hulls of adjacent blocks, doubling the block size each level ----
-  for (int half = 1; half < nwords; half <<= 1)
+  // ---- 2. join the band hulls.  Every band boundary inside a run is a junction; its thread
+  // removes, from the two hull ends that meet there, every member that the members across the
+  // junction dominate (walking outwards as far as needed, across bands).  All junctions work at
+  // once; removals only clear bits (LDS atomics) and a removal justified by ANY real site is
+  // valid, so concurrent walks cannot corrupt the hull.  Rounds repeat until a whole round
+  // removes nothing, at which point every junction has been verified convex on a stable state:
+  // band hulls convex + every junction convex = the line's lower envelope. ----
+  for (int round = 0; round < 4 * nwords + 8; round++)
   {
-    if (active && !(g.debug_skip & 1) && (band % (2 * half)) == half)
+    int changed = 0;
+    if (active && band > 0 && !(g.debug_skip & 1))
     {
-      const int R = r0;  // first row of the right block
+      const int R = r0;  // first row above the junction
       const bool neg = (sbits & 1u) != 0u;
-      if (t.Neg(R - 1) == neg)  // the run continues across the block boundary
+      if (t.Neg(R - 1) == neg)  // the run continues across the junction
       {
-        const int lo = max((band - half) * kBandRows, t.PrevOpp(R, neg) + 1);
-        const int hi = min(min((band + half) * kBandRows, n), t.NextOpp(R - 1, neg));
-        int i = t.PrevBit(t.A, t.sumA, R, lo);      // last hull member of the left block
-        int j = t.NextBit(t.A, t.sumA, R - 1, hi);  // first hull member of the right block
+        const int lo = t.PrevOpp(R, neg) + 1;
+        const int hi = t.NextOpp(R - 1, neg);
+        int i = t.PrevBit(t.A, t.sumA, R, lo);
+        int j = t.NextBit(t.A, t.sumA, R - 1, hi);
         if (i >= 0 && j >= 0)
         {
-          // Common tangent of the two hulls.  For a fixed j the members of the left hull that
-          // die are a prefix (seen from the boundary) of the hull, and "member p is dominated by
-          // its predecessor and j" is monotone along it; likewise on the right for a fixed i.
-          // So each side is found by a galloping + binary search over row positions and the
-          // dead members are cleared word-wise; the two sides alternate until neither moves.
           int32_t Gi = t.Mag(i) + i * i;
           int32_t Gj = t.Mag(j) + j * j;
-          // is the highest member at or below x dominated by (its predecessor, j)?
-          auto left_dead = [&](int x, int& site) -> bool {
-            site = t.PrevBit(t.A, t.sumA, x + 1, lo);
-            if (site < 0) return false;
-            const int a = t.PrevBit(t.A, t.sumA, site, lo);
-            if (a < 0) return false;
-            return Dominated(t.Mag(a) + a * a, a, t.Mag(site) + site * site, site, Gj, j);
-          };
-          // is the lowest member at or above x dominated by (i, its successor)?
-          auto right_dead = [&](int x, int& site) -> bool {
-            site = t.NextBit(t.A, t.sumA, x - 1, hi);
-            if (site < 0) return false;
-            const int c = t.NextBit(t.A, t.sumA, site, hi);
-            if (c < 0) return false;
-            return Dominated(Gi, i, t.Mag(site) + site * site, site, t.Mag(c) + c * c, c);
-          };
-          auto clear_rows = [&](int x0, int x1) {  // inclusive range
-            for (int jw = x0 >> 5; jw <= (x1 >> 5); jw++)
-            {
-              uint32_t m = ~0u;
-              if (jw == (x0 >> 5)) m &= ~LowMask(x0 & 31);
-              if (jw == (x1 >> 5)) m &= LowMask((x1 & 31) + 1);
-              t.A[jw * W + t.w] &= ~m;
-            }
-          };
-          bool moved = true;
-          while (moved)
+          int a = t.PrevBit(t.A, t.sumA, i, lo);
+          int32_t Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+          int c = t.NextBit(t.A, t.sumA, j, hi);
+          int32_t Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
+          for (;;)
           {
-            moved = false;
-            int site;
-            if (left_dead(i, site))
+            if (a >= 0 && Dominated(Ga, a, Gi, i, Gj, j))
             {
-              int dead_lo = i;  // lowest row known to hold a dead member
-              int live = lo - 1;  // highest row known not to
-              for (int step = 1;; step <<= 1)
-              {
-                const int x = i - step;
-                if (x < lo) break;
-                if (left_dead(x, site))
-                  dead_lo = site;
-                else
-                {
-                  live = x;
-                  break;
-                }
-              }
-              while (dead_lo - live > 1)
-              {
-                const int mid = (dead_lo + live) >> 1;
-                if (left_dead(mid, site))
-                  dead_lo = site;
-                else
-                  live = mid;
-              }
-              const int new_top = t.PrevBit(t.A, t.sumA, dead_lo, lo);
-              clear_rows(dead_lo, i);
+              atomicAnd(&t.A[(i >> 5) * W + t.w], ~(1u << (i & 31)));
               VGT_STAT_ADD(9, 1);
-              i = new_top;
-              Gi = t.Mag(i) + i * i;
-              moved = true;
+              changed = 1;
+              i = a;
+              Gi = Ga;
+              a = t.PrevBit(t.A, t.sumA, i, lo);
+              Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+              continue;
             }
-            if (right_dead(j, site))
+            if (c >= 0 && Dominated(Gi, i, Gj, j, Gc, c))
             {
-              int dead_hi = j;
-              int live = hi;
-              for (int step = 1;; step <<= 1)
-              {
-                const int x = j + step;
-                if (x >= hi) break;
-                if (right_dead(x, site))
-                  dead_hi = site;
-                else
-                {
-                  live = x;
-                  break;
-                }
-              }
-              while (live - dead_hi > 1)
-              {
-                const int mid = (dead_hi + live) >> 1;
-                if (right_dead(mid, site))
-                  dead_hi = site;
-                else
-                  live = mid;
-              }
-              const int new_first = t.NextBit(t.A, t.sumA, dead_hi, hi);
-              clear_rows(j, dead_hi);
+              atomicAnd(&t.A[(j >> 5) * W + t.w], ~(1u << (j & 31)));
               VGT_STAT_ADD(9, 1);
-              j = new_first;
-              Gj = t.Mag(j) + j * j;
-              moved = true;
+              changed = 1;
+              j = c;
+              Gj = Gc;
+              c = t.NextBit(t.A, t.sumA, j, hi);
+              Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
+              continue;
             }
+            break;
           }
         }
       }
     }
-    __syncthreads();
+    if (!__syncthreads_or(changed)) break;
   }
 #ifdef VGT_HULL_STATS
   const long long clk3 = clock64();
