@@ -58,8 +58,10 @@ int vgt_hip_device_name(int device, char* buffer, size_t buffer_size);
 int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx);
 void vgt_hip_destroy(vgt_hip_ctx* ctx);
 /* Run all work of this context on an externally owned hipStream_t (e.g. the caller's
- * framework stream); pass NULL to go back to the context's own stream. */
+ * framework stream); NULL is HIP's legacy default stream.  vgt_hip_reset_stream goes back to the
+ * context's own (non-blocking) stream.  Both drain the stream in use first. */
 int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream);
+int vgt_hip_reset_stream(vgt_hip_ctx* ctx);
 int vgt_hip_synchronize(vgt_hip_ctx* ctx);
 int vgt_hip_device_of(const vgt_hip_ctx* ctx);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "vgt_hip_create": (_int, [_int, _int, ctypes.POINTER(_p)]),
     "vgt_hip_destroy": (None, [_p]),
     "vgt_hip_set_stream": (_int, [_p, _p]),
+    "vgt_hip_reset_stream": (_int, [_p]),
     "vgt_hip_synchronize": (_int, [_p]),
     "vgt_hip_device_of": (_int, [_p]),
     "vgt_hip_tracking_grids_create": (_int, [_p, _i64, _i32, ctypes.POINTER(_p)]),
@@ -160,7 +161,11 @@ class Context:
         self.close()
 
     def set_stream(self, stream_ptr):
-        check(self._lib.vgt_hip_set_stream(self.handle, _ptr(stream_ptr)))
+        """Run on an external hipStream_t; 0 / None = HIP's legacy default stream (torch's default)."""
+        check(self._lib.vgt_hip_set_stream(self.handle, _ptr(stream_ptr) if stream_ptr else None))
+
+    def reset_stream(self):
+        check(self._lib.vgt_hip_reset_stream(self.handle))
 
     def synchronize(self):
         check(self._lib.vgt_hip_synchronize(self.handle))

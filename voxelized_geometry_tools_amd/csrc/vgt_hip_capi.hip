@@ -296,7 +296,17 @@ int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream)
   std::lock_guard<std::mutex> lock(ctx->mutex);
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->stream = static_cast<hipStream_t>(hip_stream);  // NULL = HIP's legacy default stream
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_reset_stream(vgt_hip_ctx* ctx)
+{
+  if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
+  ctx->stream = ctx->own_stream;
   return VGT_HIP_OK;
 }
 

@@ -55,6 +55,35 @@ __device__ __forceinline__ int64_t CellIndex(const int32_t idx[3], const int32_t
   return (static_cast<int64_t>(idx[0]) * counts[1] + idx[1]) * counts[2] + idx[2];
 }
 
+// Rays of one cloud all leave from the same voxel, so during the first steps of the walk the
+// lanes of a wave hit a handful of addresses (1M rays -> 1M increments of ONE counter; a single
+// address retires roughly one atomic per 11-13 ns, MI355X_MICROARCH.md "fanin").  For those
+// steps the wave combines equal addresses first: the leader of each group adds the group's
+// population count.  Integer adds commute, so the counts stay bit-exact.  After kMaxRounds
+// distinct addresses the remaining lanes fall back to one atomic each.
+constexpr int kAggregatedSteps = 12;
+constexpr int kMaxRounds = 8;
+
+__device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracking, int64_t index)
+{
+  uint64_t pending = __ballot(1);
+  const int lane = static_cast<int>(__lane_id());
+  bool mine = true;
+  for (int round = 0; round < kMaxRounds && pending; round++)
+  {
+    const int leader = __ffsll(static_cast<long long>(pending)) - 1;
+    const int lo = __builtin_amdgcn_readlane(static_cast<int>(index), leader);
+    const int hi = __builtin_amdgcn_readlane(static_cast<int>(index >> 32), leader);
+    const int64_t group = (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+    const bool member = mine && (index == group);
+    const uint64_t same = __ballot(member);
+    if (lane == leader) atomicAdd(&tracking[group], static_cast<int32_t>(__popcll(same)));
+    if (member) mine = false;
+    pending &= ~same;
+  }
+  if (mine) atomicAdd(&tracking[index], 1);
+}
+
 // One thread per point.  Real = float reproduces the reference device kernels, Real = double
 // the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
 template <typename Real>
@@ -138,10 +167,14 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
   if (InGrid(end, g.counts))
     atomicAdd(&tracking[CellIndex(end, g.counts) * 2 + (clipped ? 0 : 1)], 1);
 
-  while (cur[0] != end[0] || cur[1] != end[1] || cur[2] != end[2])
+  for (int walked = 0; cur[0] != end[0] || cur[1] != end[1] || cur[2] != end[2]; walked++)
   {
     if (!InGrid(cur, g.counts)) break;
-    atomicAdd(&tracking[CellIndex(cur, g.counts) * 2], 1);
+    // `walked` is the same for every lane still in the loop
+    if (walked < kAggregatedSteps)
+      AggregatedIncrement(tracking, CellIndex(cur, g.counts) * 2);
+    else
+      atomicAdd(&tracking[CellIndex(cur, g.counts) * 2], 1);
     int a;
     if (t[0] <= t[1] && t[0] <= t[2])
       a = 0;

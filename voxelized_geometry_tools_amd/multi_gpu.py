@@ -88,7 +88,11 @@ def summary_reference(filled, z_offset):
 
 
 class SlabSdf:
-    """One rank's share of a Z-slab partitioned SDF extraction (device-resident)."""
+    """One rank's share of a Z-slab partitioned SDF extraction (device-resident).
+
+    The context must run on torch's current stream (ctx.set_stream(torch.cuda.current_stream()
+    .cuda_stream)) so that the library's kernels, the torch reductions and the collective are
+    stream-ordered."""
 
     def __init__(self, ctx, torch, dist, full_shape, rank, world, device):
         from . import capi
@@ -136,6 +140,8 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
     from . import capi
     nx, ny, nz = occ.shape
     dev = occ.device
+    # torch ops and the library's kernels must be ordered: run both on torch's current stream
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     parts = []
     for r in range(nslabs):
         local_shape, z0 = slab_of((nx, ny, nz), r, nslabs)
@@ -160,4 +166,5 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
         out[:, :, z0:z0 + local_shape[2]] = sdf
         extrema.append(mm.cpu().numpy())
     extrema = np.array(extrema)
+    ctx.reset_stream()
     return out, float(extrema[:, 0].min()), float(extrema[:, 1].max())
