@@ -837,6 +837,7 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
   int W = LinesPerTile(g.n);
   if (force_w == 32 && g.n <= 1024) W = 32;  // experiment knob: full-width tiles
+  if (force_w == 8 && g.n <= 1024) W = 8;    // experiment knob: quarter-width tiles
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
@@ -852,6 +853,8 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
   if (W == 32)
     return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 8)
+    return LaunchHull<InT, OutT, kFinal, 8, 32>(in, out, minmax_enc, g, outer_count, stream);
   if (nwords <= 32)
     return LaunchHull<InT, OutT, kFinal, 16, 32>(in, out, minmax_enc, g, outer_count, stream);
   return LaunchHull<InT, OutT, kFinal, 16, 64>(in, out, minmax_enc, g, outer_count, stream);
