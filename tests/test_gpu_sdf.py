@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 2]  # tiled envelope (default), pruned search from HBM, tiled argmin search
+VARIANTS = [0, 1, 2, 3]  # tiled envelope, pruned search from HBM, tiled argmin search, line sweep
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -350,6 +350,10 @@ hipError_t LaunchPassYDc(const int16_t* in16, int32_t* out32, const SdfParams& p
                          hipStream_t stream, bool* handled);
 hipError_t LaunchPassXDcFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                  const SdfParams& p, hipStream_t stream, bool* handled);
+hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+                           hipStream_t stream);
+hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                   void* scratch, const SdfParams& p, hipStream_t stream);
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -407,9 +411,11 @@ hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const Sd
   return hipGetLastError();
 }
 
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
-                       hipStream_t stream)
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, const SdfParams& p,
+                       EdtVariant variant, hipStream_t stream)
 {
+  if (variant == EdtVariant::kLine && line_scratch)
+    return LaunchPassYLine(in16, out32, line_scratch, p, stream);
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
@@ -425,8 +431,11 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, 
 }
 
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               const SdfParams& p, EdtVariant variant, hipStream_t stream)
+                               void* line_scratch, const SdfParams& p, EdtVariant variant,
+                               hipStream_t stream)
 {
+  if (variant == EdtVariant::kLine && line_scratch)
+    return LaunchPassXLineFinalize(in32, sdf, minmax_enc, line_scratch, p, stream);
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;

@@ -1,0 +1,299 @@
+// Line-sweep passes (Y and X) of the exact signed EDT for gfx950: one lane per line, all lanes
+// of a wave walking the pass axis in lockstep.
+//
+// Lanes of a wave are neighbouring Z positions, so every row access of the wave is one
+// contiguous segment (256 B of int32, 128 B of int16) for both axes -- no tile, no LDS, no
+// workgroup barrier, full occupancy.  Each lane runs the Felzenszwalb-Huttenlocher stack
+// algorithm (signed_distance_field_generation.cpp:124-226) on its own line, with two changes
+// that keep it exact in integers and cheap:
+//   * stack entries carry the FIRST ROW the site owns (an integer) instead of the real-valued
+//     intersection z[k]; "site c overtakes the top before the top's first row" is then the
+//     division-free test  num < start(top) * den  with  num = G(c) - G(top), den = 2 (c - top),
+//     and sites that would own no integer row are dropped at once;
+//   * the stack lives in an HBM scratch array shaped like the grid (entry k of the run that
+//     starts at row a sits at row a + k <= current row), 8 bytes per entry.  Only the top entry
+//     is kept in registers; pushes write through, pops re-read.  Neighbouring lanes have similar
+//     stack depths, so these accesses fall into a few cache lines, and entries that are popped
+//     soon never leave L2.
+// A line splits at class changes into runs (see edt_hull_kernels.hip): the envelope is built per
+// run over its members; the voxels of the other class that bound the run are separate
+// candidates.  Sweep 1 builds the stacks and leaves, per run, (end row, stack depth) in the
+// output slot of the run's first row plus one sign bit per row; sweep 2 walks rows again, reads
+// that record when a run starts, advances along the stack whenever the next entry's first row is
+// reached, and writes the result (fused sqrt / resolution / sign / virtual border / min-max in
+// the X pass).
+#include "edt_device.hpp"
+
+namespace vgt
+{
+namespace
+{
+struct __attribute__((aligned(8))) StackEntry
+{
+  int32_t f;       // value of the site
+  uint16_t v;      // row of the site
+  uint16_t start;  // first row the site owns
+};
+
+struct LineGeom
+{
+  int n;                 // rows along the pass axis
+  int nz;                // lines per outer index (= extent of the contiguous axis)
+  int64_t num_lines;
+  int64_t row_stride;    // elements between consecutive rows
+  int64_t outer_stride;  // elements between consecutive outer indices
+  int nx, ny;
+  int pass_axis;         // 0 = X pass (outer = y), 1 = Y pass (outer = x)
+  double resolution;
+  int add_virtual_border;
+  int z_offset, nz_global;
+};
+
+constexpr int kLineBlock = 256;
+constexpr int kRowChunk = 8;  // rows whose loads are issued together
+
+template <typename InT, typename OutT, bool kFinal>
+__global__ __launch_bounds__(kLineBlock) void LinePassKernel(const InT* __restrict__ in,
+                                                            OutT* __restrict__ out,
+                                                            StackEntry* __restrict__ stack,
+                                                            uint32_t* __restrict__ signw,
+                                                            uint32_t* __restrict__ minmax_enc,
+                                                            const LineGeom g)
+{
+  const int64_t line = static_cast<int64_t>(blockIdx.x) * kLineBlock + threadIdx.x;
+  const int n = g.n;
+  uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
+  if (line < g.num_lines)
+  {
+    const int outer = static_cast<int>(line / g.nz);
+    const int z = static_cast<int>(line - static_cast<int64_t>(outer) * g.nz);
+    const int64_t base = static_cast<int64_t>(outer) * g.outer_stride + z;
+    const int64_t rs = g.row_stride;
+    uint32_t* out_raw = reinterpret_cast<uint32_t*>(out);
+
+    // ---- sweep 1: build the stacks ----
+    {
+      bool neg = false;
+      int run_a = 0, depth = 0;
+      int vt = 0, st = 0;  // top of the stack: row, first owned row
+      int32_t ft = 0;      //                   value
+      uint32_t sw = 0;
+      for (int q0 = 0; q0 < n; q0 += kRowChunk)
+      {
+        int32_t vbuf[kRowChunk];
+#pragma unroll
+        for (int j = 0; j < kRowChunk; j++)
+        {
+          const int q = q0 + j;
+          vbuf[j] = (q < n) ? ToSignedSquare(in[base + static_cast<int64_t>(q) * rs]) : kInf32;
+        }
+#pragma unroll
+        for (int j = 0; j < kRowChunk; j++)
+        {
+          const int q = q0 + j;
+          if (q >= n) break;
+          const int32_t v = vbuf[j];
+          const bool sneg = v < 0;
+          const int32_t f = sneg ? -v : v;
+          if (sneg) sw |= 1u << (q & 31);
+          if ((q & 31) == 31 || q == n - 1)
+          {
+            signw[static_cast<int64_t>(q >> 5) * g.num_lines + line] = sw;
+            sw = 0;
+          }
+          if (q == 0 || sneg != neg)
+          {
+            // the run [run_a, q) is complete: leave (end row, depth) at its first row
+            if (q > 0)
+              out_raw[base + static_cast<int64_t>(run_a) * rs] =
+                  static_cast<uint32_t>(q) | (static_cast<uint32_t>(depth) << 16);
+            neg = sneg;
+            run_a = q;
+            depth = 0;
+          }
+          if (f != kInf32)
+          {
+            int32_t num = 0, den = 1;
+            while (depth > 0)
+            {
+              const int dq = q - vt;
+              num = (f - ft) + dq * (q + vt);  // G(q) - G(vt)
+              den = 2 * dq;
+              if (num >= st * den) break;  // the top keeps its first row
+              depth--;
+              if (depth > 0)
+              {
+                const StackEntry e = stack[base + static_cast<int64_t>(run_a + depth - 1) * rs];
+                vt = e.v;
+                ft = e.f;
+                st = e.start;
+              }
+            }
+            int start = run_a;
+            bool push = true;
+            if (depth > 0)
+            {
+              if (num >= n * den)
+                push = false;  // would take over beyond the last row: owns nothing
+              else
+              {
+                // exact floor(num / den): 0 <= num < n * den <= 2^29, quotient < 2^14, so the
+                // float estimate is off by at most one
+                int quo = static_cast<int>(__fdividef(static_cast<float>(num), static_cast<float>(den)));
+                const int rem = num - quo * den;
+                quo += (rem >= den) ? 1 : ((rem < 0) ? -1 : 0);
+                start = quo + 1;  // > st because num >= st * den
+              }
+            }
+            if (push)
+            {
+              StackEntry e;
+              e.f = f;
+              e.v = static_cast<uint16_t>(q);
+              e.start = static_cast<uint16_t>(start);
+              stack[base + static_cast<int64_t>(run_a + depth) * rs] = e;
+              depth++;
+              vt = q;
+              ft = f;
+              st = start;
+            }
+          }
+        }
+      }
+      out_raw[base + static_cast<int64_t>(run_a) * rs] =
+          static_cast<uint32_t>(n) | (static_cast<uint32_t>(depth) << 16);
+    }
+
+    // ---- sweep 2: evaluate ----
+    {
+      bool neg = false;
+      int prev_opp = -1, next_opp = n;
+      int k = 0, kend = 0;  // stack entries of the current run: rows [k, kend)
+      int vc = 0, vn = 0, sn = 0;
+      int32_t fc = 0, fn = 0;
+      bool have_cur = false;
+      uint32_t sw = 0;
+      for (int q = 0; q < n; q++)
+      {
+        if ((q & 31) == 0) sw = signw[static_cast<int64_t>(q >> 5) * g.num_lines + line];
+        const bool sneg = (sw >> (q & 31)) & 1u;
+        const int64_t idx = base + static_cast<int64_t>(q) * rs;
+        if (q == 0 || sneg != neg)
+        {
+          neg = sneg;
+          prev_opp = q - 1;
+          const uint32_t info = out_raw[idx];
+          next_opp = static_cast<int>(info & 0xffffu);
+          const int depth = static_cast<int>(info >> 16);
+          k = q;
+          kend = q + depth;
+          have_cur = depth > 0;
+          if (depth > 0)
+          {
+            const StackEntry e = stack[idx];
+            vc = e.v;
+            fc = e.f;
+          }
+          if (depth > 1)
+          {
+            const StackEntry e = stack[idx + rs];
+            vn = e.v;
+            fn = e.f;
+            sn = e.start;
+          }
+        }
+        while (k + 1 < kend && sn <= q)
+        {
+          k++;
+          vc = vn;
+          fc = fn;
+          if (k + 1 < kend)
+          {
+            const StackEntry e = stack[base + static_cast<int64_t>(k + 1) * rs];
+            vn = e.v;
+            fn = e.f;
+            sn = e.start;
+          }
+        }
+        int32_t best = kInf32;
+        if (have_cur) best = (q - vc) * (q - vc) + fc;
+        if (prev_opp >= 0) best = min(best, (q - prev_opp) * (q - prev_opp));
+        if (next_opp < n) best = min(best, (next_opp - q) * (next_opp - q));
+        if constexpr (kFinal)
+        {
+          const int x = (g.pass_axis == 0) ? q : outer;
+          const int y = (g.pass_axis == 0) ? outer : q;
+          const float val = FinalizeSdf(best, neg, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global,
+                                        g.resolution, g.add_virtual_border);
+          out[idx] = val;
+          const uint32_t enc = EncodeOrdered(val);
+          lo_enc = min(lo_enc, enc);
+          hi_enc = max(hi_enc, enc);
+        }
+        else
+        {
+          out[idx] = neg ? -best : best;
+        }
+      }
+    }
+  }
+  if constexpr (kFinal) BlockMinMax(lo_enc, hi_enc, minmax_enc);
+}
+
+template <typename InT, typename OutT, bool kFinal>
+hipError_t LaunchLine(const InT* in, OutT* out, void* scratch, uint32_t* minmax_enc, LineGeom g,
+                      const SdfParams& p, hipStream_t stream)
+{
+  const int64_t nvox = p.nx * p.ny * p.nz;
+  StackEntry* stack = static_cast<StackEntry*>(scratch);
+  uint32_t* signw = reinterpret_cast<uint32_t*>(stack + nvox);
+  g.resolution = p.resolution;
+  g.add_virtual_border = p.add_virtual_border;
+  g.nx = static_cast<int>(p.nx);
+  g.ny = static_cast<int>(p.ny);
+  g.z_offset = static_cast<int>(p.z_offset);
+  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
+  const int64_t blocks = (g.num_lines + kLineBlock - 1) / kLineBlock;
+  hipLaunchKernelGGL((LinePassKernel<InT, OutT, kFinal>), dim3(static_cast<unsigned>(blocks)),
+                     dim3(kLineBlock), 0, stream, in, out, stack, signw, minmax_enc, g);
+  return hipGetLastError();
+}
+}  // namespace
+
+// Scratch needed by the line-sweep passes: one 8-byte stack entry per voxel plus one sign bit per
+// voxel rounded up to whole words per line.
+size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz)
+{
+  const int64_t nvox = nx * ny * nz;
+  const int64_t words_y = ((ny + 31) / 32) * (nx * nz);
+  const int64_t words_x = ((nx + 31) / 32) * (ny * nz);
+  const int64_t words = words_y > words_x ? words_y : words_x;
+  return static_cast<size_t>(nvox) * sizeof(StackEntry) + static_cast<size_t>(words) * 4 + 256;
+}
+
+hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+                           hipStream_t stream)
+{
+  LineGeom g{};
+  g.n = static_cast<int>(p.ny);
+  g.nz = static_cast<int>(p.nz);
+  g.num_lines = p.nx * p.nz;
+  g.row_stride = p.nz;
+  g.outer_stride = p.ny * p.nz;
+  g.pass_axis = 1;
+  return LaunchLine<int16_t, int32_t, false>(in16, out32, scratch, nullptr, g, p, stream);
+}
+
+hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                   void* scratch, const SdfParams& p, hipStream_t stream)
+{
+  LineGeom g{};
+  g.n = static_cast<int>(p.nx);
+  g.nz = static_cast<int>(p.nz);
+  g.num_lines = p.ny * p.nz;
+  g.row_stride = p.ny * p.nz;
+  g.outer_stride = p.nz;
+  g.pass_axis = 0;
+  return LaunchLine<int32_t, float, true>(in32, sdf, scratch, minmax_enc, g, p, stream);
+}
+}  // namespace vgt

@@ -68,13 +68,14 @@ struct SdfWorkspace
   int16_t* t16;
   int32_t* t32;
   uint32_t* minmax_enc;
+  void* line_scratch;  // stacks + sign words of the line-sweep passes
   size_t bytes;
 };
 
-SdfWorkspace CarveWorkspace(void* base, int64_t nvox)
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
 {
   SdfWorkspace ws;
-  const size_t n = static_cast<size_t>(nvox);
+  const size_t n = static_cast<size_t>(nx * ny * nz);
   size_t off = 0;
   ws.t16 = reinterpret_cast<int16_t*>(static_cast<char*>(base) + off);
   off = AlignUp(off + n * sizeof(int16_t), 256);
@@ -82,6 +83,8 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nvox)
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
   off += 256;
+  ws.line_scratch = static_cast<char*>(base) + off;
+  off = AlignUp(off + vgt::LinePassScratchBytes(nx, ny, nz), 256);
   ws.bytes = off;
   return ws;
 }
@@ -103,8 +106,7 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
                    void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                    hipEvent_t* events)
 {
-  const int64_t nvox = p.nx * p.ny * p.nz;
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nvox);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   hipStream_t s = ctx->stream;
@@ -115,9 +117,9 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
   else
     VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, nullptr, s), "Z scan");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.line_scratch, p, ctx->variant, s), "Y pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, p, ctx->variant, s),
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.line_scratch, p, ctx->variant, s),
               "X pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
@@ -322,7 +324,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 2)
+  if (!ctx || variant < 0 || variant > 3)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
@@ -633,7 +635,7 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  return CarveWorkspace(nullptr, nx * ny * nz).bytes;
+  return CarveWorkspace(nullptr, nx, ny, nz).bytes;
 }
 
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,
@@ -766,7 +768,7 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   vgt::SdfParams p{nx, ny, nz_local, 1.0, unknown_is_filled ? 1 : 0, 0};
   p.z_offset = z_offset;
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx * ny * nz_local);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local);
   if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   StageTimer timer;
   const int trc = timer.Init(kernel_ms != nullptr, 1);
@@ -797,7 +799,7 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   vgt::SdfParams p{nx, ny, nz_local, resolution, 0, add_virtual_border ? 1 : 0};
   p.z_offset = z_offset;
   p.nz_global = nz_global;
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx * ny * nz_local);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local);
   if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   StageTimer timer;
   const int trc = timer.Init(kernel_ms != nullptr, 3);
@@ -809,9 +811,9 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
               "slab fix-up");
   VGT_TRY_HIP(timer.Mark(1, s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.line_scratch, p, ctx->variant, s), "Y pass");
   VGT_TRY_HIP(timer.Mark(2, s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, p, ctx->variant, s), "X pass");
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.line_scratch, p, ctx->variant, s), "X pass");
   VGT_TRY_HIP(timer.Mark(3, s), "event record");
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
   return timer.Finish(s, kernel_ms, 3);

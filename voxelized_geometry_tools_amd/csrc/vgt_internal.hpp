@@ -49,7 +49,7 @@ struct SlabLineCarry
 // kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
 // straight from HBM; kSearch: LDS-tiled monotone-argmin search.  All three are exact; 1 and 2
 // exist for cross-checking and as the fallback for axes the tiled kernels do not cover.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kSearch = 2 };
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kSearch = 2, kLine = 3 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -62,12 +62,15 @@ hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfPar
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, const SdfParams& p, EdtVariant variant,
-                       hipStream_t stream);
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, const SdfParams& p,
+                       EdtVariant variant, hipStream_t stream);
 // X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
 // order-preserving encoding, must be pre-initialised by InitMinMax).
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               const SdfParams& p, EdtVariant variant, hipStream_t stream);
+                               void* line_scratch, const SdfParams& p, EdtVariant variant,
+                               hipStream_t stream);
+// Scratch for the line-sweep passes (edt_line_kernels.hip).
+size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
 hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
 
