@@ -72,27 +72,62 @@ __global__ __launch_bounds__(kLineBlock) void LinePassKernel(const InT* __restri
     uint32_t* out_raw = reinterpret_cast<uint32_t*>(out);
 
     // ---- sweep 1: build the stacks ----
+    // The two topmost entries live in registers and are written to the scratch array only when
+    // they sink to third place (or when the run closes), so an entry that is popped again soon
+    // never touches memory; a pop refills the second register from memory while the next test
+    // already runs on the old second entry.  A member that is matched or beaten at its own row
+    // by the current top (a site on its left) and by a member 1, 2 or 4 rows ahead (a site on
+    // its right, same run) can never own a row and is not pushed at all.
     {
       bool neg = false;
       int run_a = 0, depth = 0;
-      int vt = 0, st = 0;  // top of the stack: row, first owned row
-      int32_t ft = 0;      //                   value
+      int v1 = 0, s1 = 0, v2 = 0, s2 = 0;  // top / second: row, first owned row
+      int32_t f1 = 0, f2 = 0;              //               value
+      bool dirty2 = false;                 // the second entry has not been written yet
       uint32_t sw = 0;
+      int32_t cur[kRowChunk], nxt[kRowChunk];
+#pragma unroll
+      for (int j = 0; j < kRowChunk; j++)
+        nxt[j] = (j < n) ? ToSignedSquare(in[base + static_cast<int64_t>(j) * rs]) : kInf32;
+
+      auto store_entry = [&](int index, int32_t f, int v, int st) {
+        StackEntry e;
+        e.f = f;
+        e.v = static_cast<uint16_t>(v);
+        e.start = static_cast<uint16_t>(st);
+        stack[base + static_cast<int64_t>(run_a + index) * rs] = e;
+      };
+      auto close_run = [&](int end_row) {
+        if (depth >= 2 && dirty2) store_entry(depth - 2, f2, v2, s2);
+        if (depth >= 1) store_entry(depth - 1, f1, v1, s1);
+        out_raw[base + static_cast<int64_t>(run_a) * rs] =
+            static_cast<uint32_t>(end_row) | (static_cast<uint32_t>(depth) << 16);
+      };
+
       for (int q0 = 0; q0 < n; q0 += kRowChunk)
       {
-        int32_t vbuf[kRowChunk];
+#pragma unroll
+        for (int j = 0; j < kRowChunk; j++) cur[j] = nxt[j];
 #pragma unroll
         for (int j = 0; j < kRowChunk; j++)
         {
-          const int q = q0 + j;
-          vbuf[j] = (q < n) ? ToSignedSquare(in[base + static_cast<int64_t>(q) * rs]) : kInf32;
+          const int q = q0 + kRowChunk + j;
+          nxt[j] = (q < n) ? ToSignedSquare(in[base + static_cast<int64_t>(q) * rs]) : kInf32;
+        }
+        // class bits of the 16-row window [q0, q0 + 16)
+        uint32_t sgn = 0;
+#pragma unroll
+        for (int j = 0; j < kRowChunk; j++)
+        {
+          if (cur[j] < 0) sgn |= 1u << j;
+          if (nxt[j] < 0) sgn |= 1u << (j + kRowChunk);
         }
 #pragma unroll
         for (int j = 0; j < kRowChunk; j++)
         {
           const int q = q0 + j;
           if (q >= n) break;
-          const int32_t v = vbuf[j];
+          const int32_t v = cur[j];
           const bool sneg = v < 0;
           const int32_t f = sneg ? -v : v;
           if (sneg) sw |= 1u << (q & 31);
@@ -103,65 +138,71 @@ __global__ __launch_bounds__(kLineBlock) void LinePassKernel(const InT* __restri
           }
           if (q == 0 || sneg != neg)
           {
-            // the run [run_a, q) is complete: leave (end row, depth) at its first row
-            if (q > 0)
-              out_raw[base + static_cast<int64_t>(run_a) * rs] =
-                  static_cast<uint32_t>(q) | (static_cast<uint32_t>(depth) << 16);
+            if (q > 0) close_run(q);  // the run [run_a, q) is complete
             neg = sneg;
             run_a = q;
             depth = 0;
+            dirty2 = false;
           }
-          if (f != kInf32)
+          if (f == kInf32) continue;
+          // own-row test
+          bool right_beaten = false;
+          const uint32_t other = (sneg ? ~sgn : sgn) >> j;  // bit d set: row q+d is of the other class
+#pragma unroll
+          for (int d = 1; d <= 4; d <<= 1)
           {
-            int32_t num = 0, den = 1;
-            while (depth > 0)
+            const int32_t u = (j + d < kRowChunk) ? cur[j + d] : nxt[j + d - kRowChunk];
+            const int32_t fu = u < 0 ? -u : u;
+            const bool same_run = (other & ((2u << d) - 1u)) == 0u;
+            if (same_run && fu != kInf32 && fu + d * d <= f) right_beaten = true;
+          }
+          if (right_beaten && depth > 0 && (q - v1) * (q - v1) + f1 <= f) continue;
+
+          int32_t num = 0, den = 1;
+          while (depth > 0)
+          {
+            const int dq = q - v1;
+            num = (f - f1) + dq * (q + v1);  // G(q) - G(v1)
+            den = 2 * dq;
+            if (num >= s1 * den) break;  // the top keeps its first row
+            // pop: the second entry becomes the top; refill the second from memory
+            depth--;
+            v1 = v2;
+            f1 = f2;
+            s1 = s2;
+            dirty2 = false;
+            if (depth >= 2)
             {
-              const int dq = q - vt;
-              num = (f - ft) + dq * (q + vt);  // G(q) - G(vt)
-              den = 2 * dq;
-              if (num >= st * den) break;  // the top keeps its first row
-              depth--;
-              if (depth > 0)
-              {
-                const StackEntry e = stack[base + static_cast<int64_t>(run_a + depth - 1) * rs];
-                vt = e.v;
-                ft = e.f;
-                st = e.start;
-              }
-            }
-            int start = run_a;
-            bool push = true;
-            if (depth > 0)
-            {
-              if (num >= n * den)
-                push = false;  // would take over beyond the last row: owns nothing
-              else
-              {
-                // exact floor(num / den): 0 <= num < n * den <= 2^29, quotient < 2^14, so the
-                // float estimate is off by at most one
-                int quo = static_cast<int>(__fdividef(static_cast<float>(num), static_cast<float>(den)));
-                const int rem = num - quo * den;
-                quo += (rem >= den) ? 1 : ((rem < 0) ? -1 : 0);
-                start = quo + 1;  // > st because num >= st * den
-              }
-            }
-            if (push)
-            {
-              StackEntry e;
-              e.f = f;
-              e.v = static_cast<uint16_t>(q);
-              e.start = static_cast<uint16_t>(start);
-              stack[base + static_cast<int64_t>(run_a + depth) * rs] = e;
-              depth++;
-              vt = q;
-              ft = f;
-              st = start;
+              const StackEntry e = stack[base + static_cast<int64_t>(run_a + depth - 2) * rs];
+              v2 = e.v;
+              f2 = e.f;
+              s2 = e.start;
             }
           }
+          int start = run_a;
+          if (depth > 0)
+          {
+            if (num >= n * den) continue;  // would take over beyond the last row: owns nothing
+            // exact floor(num / den): 0 <= num < n * den <= 2^29, quotient < 2^14, so the float
+            // estimate is off by at most one
+            int quo = static_cast<int>(__fdividef(static_cast<float>(num), static_cast<float>(den)));
+            const int rem = num - quo * den;
+            quo += (rem >= den) ? 1 : ((rem < 0) ? -1 : 0);
+            start = quo + 1;  // > s1 because num >= s1 * den
+          }
+          // push: the old second sinks to third place and must be in memory from now on
+          if (depth >= 2 && dirty2) store_entry(depth - 2, f2, v2, s2);
+          v2 = v1;
+          f2 = f1;
+          s2 = s1;
+          dirty2 = (depth >= 1);
+          v1 = q;
+          f1 = f;
+          s1 = start;
+          depth++;
         }
       }
-      out_raw[base + static_cast<int64_t>(run_a) * rs] =
-          static_cast<uint32_t>(n) | (static_cast<uint32_t>(depth) << 16);
+      close_run(n);
     }
 
     // ---- sweep 2: evaluate ----
