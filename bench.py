@@ -34,13 +34,14 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=0, help="cube edge for N=1 (default 1024)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
+    ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
     ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2, 3 cross-check implementations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
-def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=None):
+def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=None, salt_p=0.01):
     """Synthetic occupancy built directly in HBM; identical to synthetic.make_occupancy."""
     from voxelized_geometry_tools_amd import synthetic
     full_shape = full_shape or shape
@@ -68,7 +69,7 @@ def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=No
     elif dist == "salt":
         g = torch.Generator(device=device)
         g.manual_seed(seed)
-        occ = (torch.rand(shape, device=device, generator=g) < 0.01).to(torch.float32)
+        occ = (torch.rand(shape, device=device, generator=g) < salt_p).to(torch.float32)
     elif dist == "single":
         if z_offset == 0:
             occ[0, 0, 0] = 1.0
@@ -138,7 +139,7 @@ def main():
             full_shape + (args.dist, world))
         parallelism = "zslab%d" % world
 
-    occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape)
+    occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape, args.salt_p)
     sdf = torch.empty(local_shape, dtype=torch.float32, device=device)
     ws_bytes = capi.sdf_workspace_bytes(local_shape)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)

@@ -6,6 +6,11 @@
 namespace vgt
 {
 constexpr int kWaveSize = 64;
+constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, workgroup b of a launch goes to XCD b % 8
+
+// Square of a row / voxel offset (|v| <= 16384): 24-bit multiply, full rate on CDNA (the 32-bit
+// v_mul_lo is quarter rate).
+__device__ __forceinline__ int32_t Sq(int v) { return __mul24(v, v); }
 
 // Decoding of the intermediate encodings into (class, squared distance so far).
 __device__ __forceinline__ void Decode(int16_t v, bool& negative, int32_t& f)

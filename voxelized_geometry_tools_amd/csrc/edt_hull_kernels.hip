@@ -222,8 +222,21 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   t.nwords = nwords;
   t.w = threadIdx.x % W;
 
-  const int outer = blockIdx.x / g.ztiles;
-  const int z0 = (blockIdx.x % g.ztiles) * W;
+  // Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8).  Within every
+  // group of 8 tile rows give each XCD one whole row of z tiles, so that the tiles resident on
+  // one XCD at a time are neighbours along z and their short row segments add up to long
+  // contiguous rows in that XCD's L2 and in the DRAM pages behind it.
+  int tile_id = blockIdx.x;
+  {
+    const int group = kNumXcd * g.ztiles;
+    if (!(g.debug_skip & 64) && tile_id < static_cast<int>(gridDim.x) / group * group)
+    {
+      const int local = tile_id % group;
+      tile_id = tile_id - local + (local % kNumXcd) * g.ztiles + local / kNumXcd;
+    }
+  }
+  const int outer = tile_id / g.ztiles;
+  const int z0 = (tile_id % g.ztiles) * W;
   const int64_t base = static_cast<int64_t>(outer) * g.outer_stride + z0;
   const int band = threadIdx.x / W;
   const int z = z0 + t.w;
@@ -355,12 +368,12 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           if (off == 255 || row < run_a) continue;
           const int32_t f = t.Mag(row);
           if (f == kInf32) continue;
-          const int32_t val = (r0 - row) * (r0 - row) + f;
+          const int32_t val = Sq(r0 - row) + f;
           if (val < best)
           {
             best = val;
             seed_l = row;
-            Gseed_l = f + row * row;
+            Gseed_l = f + Sq(row);
           }
         }
         const int q_last = r1 - 1;
@@ -374,12 +387,12 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           if (off == 255 || row > run_b) continue;
           const int32_t f = t.Mag(row);
           if (f == kInf32) continue;
-          const int32_t val = (q_last - row) * (q_last - row) + f;
+          const int32_t val = Sq(q_last - row) + f;
           if (val < best)
           {
             best = val;
             seed_r = row;
-            Gseed_r = f + row * row;
+            Gseed_r = f + Sq(row);
           }
         }
       }
@@ -398,16 +411,16 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(nrows);
         const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;
         const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;
-        const int32_t fseed_l = (seed_l >= 0) ? Gseed_l - seed_l * seed_l : kInf32;
-        const int32_t fseed_r = (seed_r >= 0) ? Gseed_r - seed_r * seed_r : kInf32;
+        const int32_t fseed_l = (seed_l >= 0) ? Gseed_l - Sq(seed_l) : kInf32;
+        const int32_t fseed_r = (seed_r >= 0) ? Gseed_r - Sq(seed_r) : kInf32;
         uint32_t dead = 0;
 #pragma unroll
         for (int k = 0; k < kBandRows; k++)
         {
           const int32_t f = fr[k];
           int32_t left = kInf32, right = kInf32;
-          if (seed_l >= 0 && k < first_end) left = fseed_l + (r0 + k - seed_l) * (r0 + k - seed_l);
-          if (seed_r >= 0 && k >= last_begin) right = fseed_r + (seed_r - r0 - k) * (seed_r - r0 - k);
+          if (seed_l >= 0 && k < first_end) left = fseed_l + Sq(r0 + k - seed_l);
+          if (seed_r >= 0 && k >= last_begin) right = fseed_r + Sq(seed_r - r0 - k);
 #pragma unroll
           for (int d = 1; d <= 4; d <<= 1)
           {
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           if (m)
           {
             sec = r0 + 31 - __clz(static_cast<int>(m));
-            Gsec = t.Mag(sec) + sec * sec;
+            Gsec = t.Mag(sec) + Sq(sec);
           }
           else if (bottom_seed >= 0)
           {
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             bottom_seed = seed_l;
           }
         }
-        const int32_t Gc = fcur + r * r;
+        const int32_t Gc = fcur + Sq(r);
         if (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
         {
           pop();
@@ -563,12 +576,12 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         int j = t.NextBit(t.A, t.sumA, R - 1, hi);
         if (i >= 0 && j >= 0)
         {
-          int32_t Gi = t.Mag(i) + i * i;
-          int32_t Gj = t.Mag(j) + j * j;
+          int32_t Gi = t.Mag(i) + Sq(i);
+          int32_t Gj = t.Mag(j) + Sq(j);
           int a = t.PrevBit(t.A, t.sumA, i, lo);
-          int32_t Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+          int32_t Ga = (a >= 0) ? t.Mag(a) + Sq(a) : 0;
           int c = t.NextBit(t.A, t.sumA, j, hi);
-          int32_t Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
+          int32_t Gc = (c >= 0) ? t.Mag(c) + Sq(c) : 0;
           for (;;)
           {
             if (a >= 0 && Dominated(Ga, a, Gi, i, Gj, j))
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
               i = a;
               Gi = Ga;
               a = t.PrevBit(t.A, t.sumA, i, lo);
-              Ga = (a >= 0) ? t.Mag(a) + a * a : 0;
+              Ga = (a >= 0) ? t.Mag(a) + Sq(a) : 0;
               continue;
             }
             if (c >= 0 && Dominated(Gi, i, Gj, j, Gc, c))
@@ -590,7 +603,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
               j = c;
               Gj = Gc;
               c = t.NextBit(t.A, t.sumA, j, hi);
-              Gc = (c >= 0) ? t.Mag(c) + c * c : 0;
+              Gc = (c >= 0) ? t.Mag(c) + Sq(c) : 0;
               continue;
             }
             break;
@@ -634,16 +647,16 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         }
         else
         {
-          Gh = t.Mag(h) + h * h;
+          Gh = t.Mag(h) + Sq(h);
           const int p = t.PrevBit(t.A, t.sumA, h, run_a);
           start_h = run_a;
-          if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + p * p, p, Gh, h));
+          if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + Sq(p), p, Gh, h));
         }
         nxt = t.NextBit(t.A, t.sumA, h, run_b + 1);
         start_nxt = run_b + 1;
         if (nxt >= 0)
         {
-          Gnxt = t.Mag(nxt) + nxt * nxt;
+          Gnxt = t.Mag(nxt) + Sq(nxt);
           start_nxt = min(run_b + 1, max(run_a, FirstOwnedRow(Gh, h, Gnxt, nxt)));
         }
         if (start_h < start_nxt)
@@ -734,7 +747,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     }
     bool neg = false;
     int prev_opp = -1, next_opp = n, run_a = 0;
-    for (int r = r0; r < r1; r++)
+    OutT* dst = out + (base + static_cast<int64_t>(r0) * g.row_stride + t.w);
+    for (int r = r0; r < r1; r++, dst += g.row_stride)
     {
       if (r > r0 && ((tw >> (r - r0)) & 1u))
       {
@@ -750,24 +764,23 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         run_a = prev_opp + 1;
       }
       int32_t best = kInf32;
-      if (cur >= run_a) best = (r - cur) * (r - cur) + fcur;
-      if (prev_opp >= 0) best = min(best, (r - prev_opp) * (r - prev_opp));
-      if (next_opp < n) best = min(best, (next_opp - r) * (next_opp - r));
-      const int64_t idx = base + static_cast<int64_t>(r) * g.row_stride + t.w;
+      if (cur >= run_a) best = Sq(r - cur) + fcur;
+      if (prev_opp >= 0) best = min(best, Sq(r - prev_opp));
+      if (next_opp < n) best = min(best, Sq(next_opp - r));
       if constexpr (kFinal)
       {
         const int x = (g.pass_axis == 0) ? r : outer;
         const int y = (g.pass_axis == 0) ? outer : r;
         const float v = FinalizeSdf(best, neg, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global, g.resolution,
                                     g.add_virtual_border);
-        out[idx] = v;
+        *dst = v;
         const uint32_t e = EncodeOrdered(v);
         lo_enc = min(lo_enc, e);
         hi_enc = max(hi_enc, e);
       }
       else
       {
-        out[idx] = neg ? -best : best;
+        *dst = neg ? -best : best;
       }
     }
   }
