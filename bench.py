@@ -76,6 +76,20 @@ def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=No
     return occ
 
 
+def profiled_traffic(kernel, default_workload):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, tools/collect_profiles.sh): counters cannot be read from inside this process."""
+    if not default_workload:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_current.json")
+    try:
+        with open(path) as fh:
+            entry = json.load(fh)["kernels"][kernel]
+        return round(entry["hbm_bytes"] / 1e9, 3), "profiles/pmc_hbm_traffic_current.json (GB per launch)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(budget_s):
     """Times the CPU oracle (a port of the reference's OpenMP CPU path, NOT the reference
     binary -- unbuildable here) on a bounded sample of the same distribution."""
@@ -191,6 +205,8 @@ def main():
     mm = minmax.cpu().numpy()
 
     if rank == 0:
+        traffic, traffic_src = profiled_traffic(
+            KERNEL_NAMES[dom], world == 1 and not args.size and args.dist == "spheres" and args.variant == 0)
         line = {
             "metric": "Mvoxels/s for 1024^3 float SDF extract @1 GPU; % HBM roofline",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
@@ -200,7 +216,8 @@ def main():
                        "edt_variant": args.variant, "sdf_min_max": [float(mm[0]), float(mm[1])]},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNEL_NAMES, avg_ms)},
                          "whole_sdf_achieved": round(whole, 1),
                          "whole_sdf_frac": round(whole / HBM_PEAK_GBPS, 4),

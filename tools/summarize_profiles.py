@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condenses a tools/collect_profiles.sh output directory into the files kept under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = (("ScanZ", "ScanZ"), ("PassY", "false"), ("PassXFinalize", "true"))
+EXPECTED = {"ScanZ": "4 GiB read (float occupancy) + 2 GiB write (int16)",
+            "PassY": "2 GiB read (int16) + 4 GiB write (int32)",
+            "PassXFinalize": "4 GiB read (int32) + 4 GiB write (float)"}
+
+
+def classify(name):
+    if "ScanZ" in name:
+        return "ScanZ"
+    if "PassKernel" in name or "LinePass" in name or "Pass" in name:
+        # the bool template argument kFinal tells the X pass from the Y pass
+        return "PassXFinalize" if ("true" in name or "b1" in name) else "PassY"
+    return None
+
+
+def main():
+    out = sys.argv[1]
+    summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 "
+                          "--warmup 1 --no-cpu-baseline (1024^3 D1 spheres), separate passes",
+               "note": "MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide "
+                       "(16 B/lane) coalesced read (128-B requests tallied at 64 B), WRITE_SIZE is exact.  "
+                       "'fetch_bytes_corrected' doubles the raw value: all three kernels read 16 B per lane, and with "
+                       "the XCD-aware tile order the L2 also merges the Y pass's neighbouring 32-byte row segments "
+                       "into full requests (its raw value halved, 2.15 -> 1.07 GB, when that order went in).",
+               "kernels": {}}
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob(os.path.join(out, "pmc_" + counter, "*", "*counter_collection.csv"))
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                k = classify(row["Kernel_Name"])
+                if k and row["Counter_Name"] == counter:
+                    per[k][counter].append(float(row["Counter_Value"]))
+    for k, d in per.items():
+        fetch = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1) * 1024.0
+        write = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1) * 1024.0
+        wide = True
+        summary["kernels"][k] = {"launches": len(d["FETCH_SIZE"]), "fetch_bytes_raw": fetch,
+                                 "fetch_bytes_corrected": fetch * (2.0 if wide else 1.0), "write_bytes": write,
+                                 "hbm_bytes": fetch * (2.0 if wide else 1.0) + write,
+                                 "algorithmic": EXPECTED[k]}
+    json.dump(summary, open(os.path.join(out, "pmc_hbm_traffic.json"), "w"), indent=1)
+    stats = glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
+    if stats:
+        rows = list(csv.reader(open(stats[0])))
+        with open(os.path.join(out, "rocprof_kernel_stats.csv"), "w") as fh:
+            csv.writer(fh).writerows(rows[:12])
+    print(json.dumps(summary["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
