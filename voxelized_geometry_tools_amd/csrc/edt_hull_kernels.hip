@@ -72,6 +72,8 @@ struct Tile
   int16_t* next_pos;
   uint16_t* cumA;      // [nwords][W] survivors in lower words
   uint16_t* cumT;      // [nwords][W] start bits in lower words
+  int16_t* seed_lo;    // [nwords][W] seed row entering the band from below (-1 none); aliases cumA
+  int16_t* seed_hi;    //             ... from above; aliases cumT (both dead before 2c writes cumA/cumT)
   uint8_t* min_first;  // [nwords][W] offset of the smallest member of the band's first run portion
   uint8_t* min_last;   //             ... of its last run portion (255 = none)
   uint64_t* sumA;      // [W] words of A that may be non-empty (superset)
@@ -180,6 +182,7 @@ __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int 
 }
 
 using HullGeom = TileGeom;
+constexpr int kChordMaxSpacing = 1;  // 2 (spacings 1 and 2) measured the same
 
 // Bytes of dynamic LDS for a tile of n rows x W lines.
 template <int W>
@@ -216,6 +219,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   t.next_pos = t.next_neg + mw;
   t.cumA = reinterpret_cast<uint16_t*>(t.next_pos + mw);
   t.cumT = t.cumA + mw;
+  t.seed_lo = reinterpret_cast<int16_t*>(t.cumA);
+  t.seed_hi = reinterpret_cast<int16_t*>(t.cumT);
   t.min_first = reinterpret_cast<uint8_t*>(t.cumT + mw);
   t.min_last = t.min_first + mw;
   t.n = n;
@@ -337,6 +342,80 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       t.next_neg[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_ln);
       t.next_pos[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_lp);
     }
+    // Seeds.  Band j+1 gets, for the run portion that enters it from below, a strong member of
+    // the lower bands: doubling scan over the bands' published members, each step keeping the
+    // candidate with the smaller value at the first row of band j+1.  Any member of that run is a
+    // legal seed; the scan picks a good one, not necessarily the best.  Same from above.
+    {
+      const uint32_t s_above = __shfl_down(s, 1, SW);  // sign word of band j+1
+      const uint32_t s_below = __shfl_up(s, 1, SW);    // sign word of band j-1
+      // upwards: boundary row R = first row of band j+1
+      {
+        const int R = (j + 1) << 5;
+        const bool neg_r = s_above & 1u;
+        const int run_a = (neg_r ? hi_pos : hi_neg) + 1;  // inclusive scans: other class at or below band j
+        const int off = ok ? t.min_last[j * W + line] : 255;
+        int row = (off != 255) ? (j << 5) + off : -1;
+        int32_t f = 0;
+        if (row >= 0)
+        {
+          const int32_t v = t.F[row * W + line];
+          f = v < 0 ? -v : v;
+        }
+        if (row < run_a) row = -1;
+        int32_t val = (row >= 0) ? f + Sq(R - row) : kInf32;
+        for (int d = 1; d < SW; d <<= 1)
+        {
+          const int prow = __shfl_up(row, d, SW);
+          const int32_t pf = __shfl_up(f, d, SW);
+          if (j >= d && prow >= run_a)
+          {
+            const int32_t pval = pf + Sq(R - prow);
+            if (pval < val)
+            {
+              val = pval;
+              row = prow;
+              f = pf;
+            }
+          }
+        }
+        if (j + 1 < nwords) t.seed_lo[(j + 1) * W + line] = static_cast<int16_t>((g.debug_skip & 16) ? -1 : row);
+        if (j == 0) t.seed_lo[line] = -1;
+      }
+      // downwards: boundary row Q = last row of band j-1
+      {
+        const int Q = (j << 5) - 1;
+        const bool neg_q = (s_below >> 31) & 1u;
+        const int run_b = (neg_q ? lo_pos : lo_neg) - 1;  // inclusive scans: other class at or above band j
+        const int off = ok ? t.min_first[j * W + line] : 255;
+        int row = (off != 255) ? (j << 5) + off : -1;
+        int32_t f = 0;
+        if (row >= 0)
+        {
+          const int32_t v = t.F[row * W + line];
+          f = v < 0 ? -v : v;
+        }
+        if (row > run_b) row = -1;
+        int32_t val = (row >= 0) ? f + Sq(row - Q) : kInf32;
+        for (int d = 1; d < SW; d <<= 1)
+        {
+          const int prow = __shfl_down(row, d, SW);
+          const int32_t pf = __shfl_down(f, d, SW);
+          if (j + d < SW && prow >= 0 && prow <= run_b)
+          {
+            const int32_t pval = pf + Sq(prow - Q);
+            if (pval < val)
+            {
+              val = pval;
+              row = prow;
+              f = pf;
+            }
+          }
+        }
+        if (ok && j >= 1) t.seed_hi[(j - 1) * W + line] = static_cast<int16_t>((g.debug_skip & 16) ? -1 : row);
+        if (j == nwords - 1) t.seed_hi[j * W + line] = -1;
+      }
+    }
   }
   __syncthreads();
 
@@ -347,55 +426,19 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   // The run portions that continue into the neighbouring bands are seeded with the most
   // competitive published member on that side (a real site of the same run): most members that
   // only a far, strong site removes die here, in parallel, instead of in the merge levels. ----
+#if VGT_HULL_STATS > 1
+  int stat_iters = 0;
+#endif
   if (band < nwords)
   {
     uint32_t abits = 0;
     if (z < g.nz && !(g.debug_skip & 8) && finite)
     {
       const int nrows = r1 - r0;
-      // seeds
-      int seed_l = -1, seed_r = -1;
-      int32_t Gseed_l = 0, Gseed_r = 0;
-      if (!(g.debug_skip & 16))
-      {
-        const bool neg0 = sbits & 1u;
-        const int run_a = t.PrevOpp(r0, neg0) + 1;
-        int32_t best = kInf32;
-        for (int alpha = band - 1; alpha >= 0 && ((alpha << 5) + 31) >= run_a; alpha--)
-        {
-          const int off = t.min_last[alpha * W + t.w];
-          const int row = (alpha << 5) + off;
-          if (off == 255 || row < run_a) continue;
-          const int32_t f = t.Mag(row);
-          if (f == kInf32) continue;
-          const int32_t val = Sq(r0 - row) + f;
-          if (val < best)
-          {
-            best = val;
-            seed_l = row;
-            Gseed_l = f + Sq(row);
-          }
-        }
-        const int q_last = r1 - 1;
-        const bool neg1 = (sbits >> (nrows - 1)) & 1u;
-        const int run_b = t.NextOpp(q_last, neg1) - 1;
-        best = kInf32;
-        for (int beta = band + 1; beta < nwords && (beta << 5) <= run_b; beta++)
-        {
-          const int off = t.min_first[beta * W + t.w];
-          const int row = (beta << 5) + off;
-          if (off == 255 || row > run_b) continue;
-          const int32_t f = t.Mag(row);
-          if (f == kInf32) continue;
-          const int32_t val = Sq(q_last - row) + f;
-          if (val < best)
-          {
-            best = val;
-            seed_r = row;
-            Gseed_r = f + Sq(row);
-          }
-        }
-      }
+      // seeds chosen in 1b
+      int seed_l = t.seed_lo[band * W + t.w], seed_r = t.seed_hi[band * W + t.w];
+      const int32_t Gseed_l = (seed_l >= 0) ? t.Mag(seed_l) + Sq(seed_l) : 0;
+      const int32_t Gseed_r = (seed_r >= 0) ? t.Mag(seed_r) + Sq(seed_r) : 0;
 
 #ifdef VGT_HULL_STATS
       const long long clk_seeds = clock64();
@@ -403,49 +446,74 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       // Prefilter, branch-free over the register-resident rows: a member that is matched or
       // beaten AT ITS OWN ROW by a site on its left and by a site on its right never owns a row
       // (the left one wins everywhere below, the right one everywhere above), so it need not
-      // enter the stack.  Sites tried: the seeds and the members 1, 2 and 4 rows away in the
-      // same run portion.
+      // enter the stack.
       uint32_t cand = finite;
       if (!(g.debug_skip & 32))
       {
+        // One carried site per direction: sweeping up, the carried site is the one that was
+        // strictly better at its own row than the site carried before it; a member the carried
+        // site matches at the member's own row is "covered from the left".  Same downwards.  The
+        // carried sites are real members of the same run portion (or the seeds), so the kills are
+        // valid; the choice of carried site is only a heuristic (the stack below is exact).
+        constexpr int32_t kNone = 0x40000000;  // > any finite value (< 3 * 16384^2), no overflow when a square is added
         const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(nrows);
-        const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;
-        const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;
-        const int32_t fseed_l = (seed_l >= 0) ? Gseed_l - Sq(seed_l) : kInf32;
-        const int32_t fseed_r = (seed_r >= 0) ? Gseed_r - Sq(seed_r) : kInf32;
-        uint32_t dead = 0;
+        int32_t cf = (seed_l >= 0) ? Gseed_l - Sq(seed_l) : kNone;
+        int cd = (seed_l >= 0) ? r0 - seed_l : 0;
+        uint32_t covered_l = 0, covered_r = 0;
 #pragma unroll
         for (int k = 0; k < kBandRows; k++)
         {
-          const int32_t f = fr[k];
-          int32_t left = kInf32, right = kInf32;
-          if (seed_l >= 0 && k < first_end) left = fseed_l + Sq(r0 + k - seed_l);
-          if (seed_r >= 0 && k >= last_begin) right = fseed_r + Sq(seed_r - r0 - k);
-#pragma unroll
-          for (int d = 1; d <= 4; d <<= 1)
-          {
-            if (k - d >= 0)
-            {
-              // same portion: no flip in (k-d, k]
-              const bool same = ((flips >> (k - d + 1)) & LowMask(d)) == 0u;
-              const int32_t u = fr[k - d];
-              if (same && u != kInf32) left = min(left, u + d * d);
-            }
-            if (k + d < kBandRows)
-            {
-              const bool same = ((flips >> (k + 1)) & LowMask(d)) == 0u;
-              const int32_t u = fr[k + d];
-              if (same && u != kInf32) right = min(right, u + d * d);
-            }
-          }
-          if (left <= f && right <= f) dead |= 1u << k;
+          if ((flips >> k) & 1u) cf = kNone;
+          const int32_t lv = cf + Sq(cd);
+          const bool covered = lv <= fr[k];
+          covered_l |= (covered ? 1u : 0u) << k;
+          cf = covered ? cf : fr[k];
+          cd = covered ? cd + 1 : 1;
         }
-        cand &= ~dead;
+        cf = (seed_r >= 0) ? Gseed_r - Sq(seed_r) : kNone;
+        cd = (seed_r >= 0) ? seed_r - (r0 + kBandRows - 1) : 0;
+#pragma unroll
+        for (int k = kBandRows - 1; k >= 0; k--)
+        {
+          if (k + 1 < kBandRows && ((flips >> (k + 1)) & 1u)) cf = kNone;
+          const int32_t rv = cf + Sq(cd);
+          const bool covered = rv <= fr[k];
+          covered_r |= (covered ? 1u : 0u) << k;
+          cf = covered ? cf : fr[k];
+          cd = covered ? cd + 1 : 1;
+        }
+        cand &= ~(covered_l & covered_r);
+        // Chord tests at fixed spacings: member k lies on or above the chord of the members d rows
+        // below and above it (same run portion) <=> G(k-d) + G(k+d) <= 2 G(k)
+        // <=> f(k-d) + f(k+d) + 2 d^2 <= 2 f(k): no multiplications for a constant d.
+        if (!(g.debug_skip & 256))
+        {
+          uint32_t above = 0;
+#pragma unroll
+          for (int d = 1; d <= kChordMaxSpacing; d <<= 1)
+          {
+            uint32_t dom = 0;
+#pragma unroll
+            for (int k = d; k + d < kBandRows; k++)
+            {
+              const uint32_t lo = static_cast<uint32_t>(fr[k - d]), hi = static_cast<uint32_t>(fr[k + d]);
+              dom |= (lo + hi + 2u * d * d <= 2u * static_cast<uint32_t>(fr[k]) ? 1u : 0u) << k;
+            }
+            // both neighbours are members, and no class change in (k-d, k+d]
+            uint32_t change = 0;
+#pragma unroll
+            for (int j = -d + 1; j <= d; j++) change |= (j < 0) ? (flips << -j) : (flips >> j);
+            above |= dom & (finite << d) & (finite >> d) & ~change;
+          }
+          cand &= ~above;
+        }
       }
 
 #ifdef VGT_HULL_STATS
       const long long clk_pref = clock64();
-      if (threadIdx.x == 0) { VGT_CLK_ADD(14, clk_seeds - clk1b); VGT_CLK_ADD(15, clk_pref - clk_seeds); }
+#if VGT_HULL_STATS == 1
+      if (threadIdx.x == 256) { VGT_CLK_ADD(14, clk_seeds - clk1b); VGT_CLK_ADD(15, clk_pref - clk_seeds); VGT_CLK_ADD(12, clk_pref - clk1); }
+#endif
 #endif
       // stack over the remaining candidates: one predicate test or one push per iteration
       // (lanes never wait for each other's pops)
@@ -480,6 +548,9 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       int32_t fcur = (k < kBandRows) ? t.Mag(r0 + k) : 0;
       while (k < kBandRows)
       {
+#if VGT_HULL_STATS > 1
+        stat_iters++;
+#endif
         const int r = r0 + k;
         const bool sneg = (sbits >> k) & 1u;
         // a new run portion begins when the class differs from the previous candidate's or a
@@ -533,7 +604,19 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         if (t.Mag(r) != kInf32) abits |= 1u << (r - r0);
     }
     t.A[band * W + t.w] = abits;
+#if VGT_HULL_STATS == 1
+    if (threadIdx.x == 256) VGT_CLK_ADD(9, clock64() - clk1);
+#endif
   }
+#if VGT_HULL_STATS > 1
+  {
+    // [14] sum over lanes of stack-loop iterations, [15] sum over waves of the slowest lane's count
+    int wave_max = stat_iters;
+    for (int off = 32; off > 0; off >>= 1) wave_max = max(wave_max, __shfl_xor(wave_max, off));
+    VGT_STAT_ADD(14, stat_iters);
+    if ((threadIdx.x & 63) == 0) VGT_STAT_ADD(15, wave_max);
+  }
+#endif
   __syncthreads();
 
   // ---- 1d. summary of A: which mask words of a line are non-empty ----
