@@ -171,14 +171,22 @@ __device__ __forceinline__ bool Dominated(int32_t Ga, int a, int32_t Gb, int b, 
 }
 
 // First row at which site h beats its predecessor p (p < h): smallest integer q with
-// (q-h)^2 + f(h) < (q-p)^2 + f(p)  <=>  q > (Gh - Gp) / (2 (h - p)).
-// |Gh - Gp| < 2^31 and the divisor < 2^16, so the double quotient is correctly rounded and its
-// floor is exact (an exactly integral quotient is computed exactly).
+// (q-h)^2 + f(h) < (q-p)^2 + f(p)  <=>  q > (Gh - Gp) / (2 (h - p)), i.e. floor(quotient) + 1.
+// The callers clamp the result to the run, so it only has to be exact inside [-3, 32769]; outside
+// it saturates.  Inside, the float estimate of the quotient is off by less than 2^-7 (|q| <= 2^15,
+// relative error < 2^-22), so its floor is at most one away and one exact integer remainder
+// check repairs it (no overflow: |q| * divisor < 2^15 * 2^13).
 __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int h)
 {
-  const double q = floor(static_cast<double>(Gh - Gp) / static_cast<double>(2 * (h - p)));
-  // clamp before converting: the caller clamps to the run anyway
-  return static_cast<int>(fmin(fmax(q, -2.0), 1.0e6)) + 1;
+  const int num = Gh - Gp;
+  const int den = 2 * (h - p);  // 2 .. 4094 in the tiled kernel (n <= 2048)
+  float qf = static_cast<float>(num) * __frcp_rn(static_cast<float>(den));
+  qf = fminf(fmaxf(qf, -4.0f), 32768.0f);
+  int q = static_cast<int>(floorf(qf));
+  const int r = num - __mul24(q, den);
+  q += (r >= den) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q + 1;
 }
 
 using HullGeom = TileGeom;

@@ -223,6 +223,153 @@ __global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(
   }
 }
 
+// Main path for nz % 4 == 0, nz <= 256 * NCH: every lane owns FOUR consecutive voxels (one 16-byte
+// load, one 8-byte store), so a wave covers 256 voxels per chunk and the 64-bit mask work
+// (nearest group of the other class below / above, one ds_bpermute each to fetch that group's
+// bits) is paid once per four voxels; inside the group the neighbours are found on 4-bit masks.
+// All loads of a line are in flight before the first ballot.
+template <typename InT>
+struct QuadOf;
+template <>
+struct QuadOf<float>
+{
+  using type = float4;
+};
+template <>
+struct QuadOf<uint8_t>
+{
+  using type = uchar4;
+};
+
+template <typename InT, int NCH>
+__global__ __launch_bounds__(kScanBlock) void ScanZQuadKernel(
+    const InT* __restrict__ in, int16_t* __restrict__ out, int64_t num_lines, int nz,
+    int unknown_is_filled, SlabLineSummary* __restrict__ summary, int z_offset)
+{
+  using Vec = typename QuadOf<InT>::type;
+  constexpr int kNoneBelow = -40000, kNoneAbove = 80000;  // distances from these exceed kInf16
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint64_t gt_mask = (lane == kWave - 1) ? 0ull : (~0ull << (lane + 1));
+  for (int64_t line = static_cast<int64_t>(blockIdx.x) * kScanWaves + wave; line < num_lines;
+       line += static_cast<int64_t>(gridDim.x) * kScanWaves)
+  {
+    const Vec* src = reinterpret_cast<const Vec*>(in + line * nz);
+    short4* dst = reinterpret_cast<short4*>(out + line * nz);
+    Vec v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+    {
+      const int grp = c * kWave + lane;
+      if (grp * 4 < nz) v[c] = src[grp];
+    }
+    uint32_t fb[NCH], eb[NCH];   // filled / free voxels of my group (4 bits)
+    uint64_t HF[NCH], HE[NCH];   // groups of the chunk that hold a filled / a free voxel
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+    {
+      const bool valid = (c * kWave + lane) * 4 < nz;
+      uint32_t f = 0;
+      if (valid)
+        f = (IsFilled(v[c].x, unknown_is_filled) ? 1u : 0u) | (IsFilled(v[c].y, unknown_is_filled) ? 2u : 0u) |
+            (IsFilled(v[c].z, unknown_is_filled) ? 4u : 0u) | (IsFilled(v[c].w, unknown_is_filled) ? 8u : 0u);
+      fb[c] = f;
+      eb[c] = valid ? (~f & 0xfu) : 0u;
+      HF[c] = __ballot(fb[c] != 0u);
+      HE[c] = __ballot(eb[c] != 0u);
+    }
+    // scalar carries across chunks: nearest filled / free voxel after the chunk, before the chunk
+    int32_t next_filled[NCH], next_free[NCH], prev_filled[NCH], prev_free[NCH];
+    int32_t nf = kNoneAbove, ne = kNoneAbove;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--)
+    {
+      next_filled[c] = nf;
+      next_free[c] = ne;
+      if (HF[c])
+      {
+        const int g = __ffsll(static_cast<long long>(HF[c])) - 1;
+        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fb[c]), g));
+        nf = (c * kWave + g) * 4 + __ffs(static_cast<int>(bits)) - 1;
+      }
+      if (HE[c])
+      {
+        const int g = __ffsll(static_cast<long long>(HE[c])) - 1;
+        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eb[c]), g));
+        ne = (c * kWave + g) * 4 + __ffs(static_cast<int>(bits)) - 1;
+      }
+    }
+    int32_t pf = kNoneBelow, pe = kNoneBelow;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+    {
+      prev_filled[c] = pf;
+      prev_free[c] = pe;
+      if (HF[c])
+      {
+        const int g = 63 - __clzll(static_cast<long long>(HF[c]));
+        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fb[c]), g));
+        pf = (c * kWave + g) * 4 + 31 - __clz(static_cast<int>(bits));
+      }
+      if (HE[c])
+      {
+        const int g = 63 - __clzll(static_cast<long long>(HE[c]));
+        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eb[c]), g));
+        pe = (c * kWave + g) * 4 + 31 - __clz(static_cast<int>(bits));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+    {
+      const int grp = c * kWave + lane;
+      const int base = grp * 4;
+      // nearest filled / free voxel outside my group, below and above
+      const uint64_t fbelow = HF[c] & lt_mask, ebelow = HE[c] & lt_mask;
+      const uint64_t fabove = HF[c] & gt_mask, eabove = HE[c] & gt_mask;
+      const int g_fb = fbelow ? 63 - __clzll(static_cast<long long>(fbelow)) : lane;
+      const int g_eb = ebelow ? 63 - __clzll(static_cast<long long>(ebelow)) : lane;
+      const int g_fa = fabove ? __ffsll(static_cast<long long>(fabove)) - 1 : lane;
+      const int g_ea = eabove ? __ffsll(static_cast<long long>(eabove)) - 1 : lane;
+      const uint32_t b_fb = static_cast<uint32_t>(__shfl(static_cast<int>(fb[c]), g_fb));
+      const uint32_t b_eb = static_cast<uint32_t>(__shfl(static_cast<int>(eb[c]), g_eb));
+      const uint32_t b_fa = static_cast<uint32_t>(__shfl(static_cast<int>(fb[c]), g_fa));
+      const uint32_t b_ea = static_cast<uint32_t>(__shfl(static_cast<int>(eb[c]), g_ea));
+      const int32_t PFb = fbelow ? (c * kWave + g_fb) * 4 + 31 - __clz(static_cast<int>(b_fb)) : prev_filled[c];
+      const int32_t PEb = ebelow ? (c * kWave + g_eb) * 4 + 31 - __clz(static_cast<int>(b_eb)) : prev_free[c];
+      const int32_t PFa = fabove ? (c * kWave + g_fa) * 4 + __ffs(static_cast<int>(b_fa)) - 1 : next_filled[c];
+      const int32_t PEa = eabove ? (c * kWave + g_ea) * 4 + __ffs(static_cast<int>(b_ea)) - 1 : next_free[c];
+      if (base < nz)
+      {
+        int16_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          const bool is_filled = (fb[c] >> k) & 1u;
+          const uint32_t other = is_filled ? eb[c] : fb[c];
+          const uint32_t lowm = other & ((1u << k) - 1u);
+          const uint32_t highm = other >> (k + 1);
+          const int32_t below = lowm ? base + 31 - __clz(static_cast<int>(lowm)) : (is_filled ? PEb : PFb);
+          const int32_t above = highm ? base + k + __ffs(static_cast<int>(highm)) : (is_filled ? PEa : PFa);
+          const int32_t z = base + k;
+          const int32_t d = min(min(z - below, above - z), static_cast<int32_t>(kInf16));
+          r[k] = static_cast<int16_t>(is_filled ? -d : d);
+        }
+        dst[grp] = make_short4(r[0], r[1], r[2], r[3]);
+      }
+    }
+    if (summary && lane == 0)
+    {
+      SlabLineSummary out_summary;
+      out_summary.first_filled = static_cast<int16_t>(nf == kNoneAbove ? -1 : nf + z_offset);
+      out_summary.last_filled = static_cast<int16_t>(pf == kNoneBelow ? -1 : pf + z_offset);
+      out_summary.first_free = static_cast<int16_t>(ne == kNoneAbove ? -1 : ne + z_offset);
+      out_summary.last_free = static_cast<int16_t>(pe == kNoneBelow ? -1 : pe + z_offset);
+      summary[line] = out_summary;
+    }
+  }
+}
+
 // Multi-GPU: a voxel's distance along Z to the other class is the minimum of the slab-local
 // distance and the distances to the nearest such voxel in the slabs below / above.
 __global__ __launch_bounds__(256) void SlabFixupKernel(int16_t* __restrict__ io,
@@ -372,7 +519,22 @@ hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int un
 #define VGT_SCAN_CASE(N)                                                                        \
   hipLaunchKernelGGL((ScanZUnrolledKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
                      out16, lines, nz, unknown_is_filled, summary, z_offset)
-  if (nz <= 64)
+  // four voxels per lane when the lines allow 16-byte (float) / 4-byte (mask) vector accesses
+  const bool quad_ok = (nz % 4 == 0) && nz <= 2048 &&
+                       (reinterpret_cast<uintptr_t>(in) % (4 * sizeof(InT)) == 0) &&
+                       (reinterpret_cast<uintptr_t>(out16) % 8 == 0);
+#define VGT_QUAD_CASE(N)                                                                    \
+  hipLaunchKernelGGL((ScanZQuadKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
+                     out16, lines, nz, unknown_is_filled, summary, z_offset)
+  if (quad_ok && nz <= 256)
+    VGT_QUAD_CASE(1);
+  else if (quad_ok && nz <= 512)
+    VGT_QUAD_CASE(2);
+  else if (quad_ok && nz <= 1024)
+    VGT_QUAD_CASE(4);
+  else if (quad_ok)
+    VGT_QUAD_CASE(8);
+  else if (nz <= 64)
     VGT_SCAN_CASE(1);
   else if (nz <= 128)
     VGT_SCAN_CASE(2);
@@ -386,6 +548,7 @@ hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int un
     hipLaunchKernelGGL(ScanZKernel<InT>, dim3(grid), dim3(kScanBlock), 0, stream, in, out16, lines,
                        nz, unknown_is_filled, summary, z_offset);
 #undef VGT_SCAN_CASE
+#undef VGT_QUAD_CASE
   return hipGetLastError();
 }
 }  // namespace
