@@ -178,8 +178,16 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
 /* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
  * 0 = default (LDS-tiled lower envelope: stack + merge), 1 = pruned outward search from HBM
- * (any size), 2 = LDS-tiled monotone-argmin search. */
+ * (any size), 2 = LDS-tiled monotone-argmin search, 3 = line sweep (one lane per line, stacks in
+ * the workspace). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
+/* Diagnostic: the final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation
+ * with an exact fallback (csrc/edt_device.hpp); this runs both over d2 in
+ * [first_d2, first_d2 + count) on the device and reports how many results differ (must be 0)
+ * and the first differing d2 (UINT64_MAX if none). */
+int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t count,
+                                 double resolution, uint64_t* mismatches,
+                                 uint64_t* first_mismatch);
 
 /* ---- multi-GPU: the grid is cut into Z slabs, one device per slab (BASELINE.json config 5).
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class

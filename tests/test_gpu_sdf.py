@@ -180,3 +180,25 @@ def test_long_axes(ctx, oracle, shape):
         assert bits_equal(got, want), (shape, variant)
         assert (lo, hi) == (wlo, whi)
     ctx.set_edt_variant(0)
+
+
+@pytest.mark.parametrize("resolution", [0.01, 0.25, 1.0, 1.0 / 3.0, 0.1, 0.05, 2.5e-3, 7.0, 1.0e-20, 3.0e25, 1.0e-42])
+def test_fast_finalize_matches_exact_for_every_d2(ctx, resolution):
+    """The final conversion float(sqrt(double(d2)) * res) (signed_distance_field_generation.hpp:98-105) has a
+    fast evaluation with an exact fallback; both are run on the device for EVERY d2 in [0, 2^31)."""
+    bad, first = ctx.debug_finalize_check(0, 2 ** 31, resolution)
+    assert bad == 0, "first mismatch at d2 = %s" % first
+
+
+def test_exact_finalize_matches_numpy(ctx):
+    """Anchors the device's exact conversion itself: a one-voxel-thick grid whose distances sweep a range of
+    d2 values, compared with numpy's float32(sqrt(float64) * res)."""
+    n = 1500
+    occ = np.zeros((n, 1, 1), dtype=np.float32)
+    occ[0, 0, 0] = 1.0
+    for res in (0.01, 1.0 / 3.0, 0.123456789):
+        sdf, _, _ = ctx.sdf_from_occupancy(occ, res)
+        d2 = np.arange(n, dtype=np.float64) ** 2
+        expect = (np.sqrt(d2) * res).astype(np.float32)
+        expect[0] = -np.float32(np.sqrt(1.0) * res)
+        assert bits_equal(sdf[:, 0, 0], expect)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
+    "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
     "vgt_hip_sdf_slab_finish_dev": (_int, [_p, _i64, _i64, _i64, _i64, _i64, _f64, _int, _p, _p, _p,
@@ -172,6 +173,14 @@ class Context:
 
     def set_edt_variant(self, variant):
         check(self._lib.vgt_hip_set_edt_variant(self.handle, int(variant)))
+
+    def debug_finalize_check(self, first_d2, count, resolution):
+        """(mismatches, first mismatching d2 or None) of the fast vs exact final conversion."""
+        bad = ctypes.c_uint64(0)
+        first = ctypes.c_uint64(0)
+        check(self._lib.vgt_hip_debug_finalize_check(self.handle, int(first_d2), int(count), float(resolution),
+                                                     ctypes.byref(bad), ctypes.byref(first)))
+        return int(bad.value), (None if first.value == 2 ** 64 - 1 else int(first.value))
 
     # ---- SDF ----
     def sdf_from_occupancy(self, occupancy, resolution, unknown_is_filled=True,

@@ -46,28 +46,62 @@ __device__ __forceinline__ float DecodeOrdered(uint32_t e)
   return __uint_as_float(b);
 }
 
+// float(sqrt(double(d2)) * resolution), the reference's final conversion
+// (signed_distance_field_generation.hpp:98-105), bit for bit.
+__device__ __forceinline__ float SqrtTimesResolutionExact(int32_t d2, double resolution)
+{
+  return static_cast<float>(sqrt(static_cast<double>(d2)) * resolution);
+}
+
+// Same value, cheaper on the common path.  One Newton step in double from a float rsqrt seed gives
+// sqrt(d2) to a relative error below 2^-43 (seed error e0 < 2^-22: the step leaves
+// e0^2 / 2 + e0 * e_h), so the product with the resolution is within ~2^10 double ulps of the
+// reference's doubly rounded product.  Rounding either one to float gives the same result unless
+// the product lies that close to the midpoint of two floats, i.e. its 29 bits below the float
+// mantissa are within 2^10 of 2^28; a window of 2^13 is tested and those few values (2^-15 of
+// all) take the exact path, as does everything when the float result could be subnormal or
+// overflow.  tests/test_gpu_sdf.py::test_fast_finalize_matches_exact_for_every_d2 compares the two
+// over all d2 in [0, 2^31).
+__device__ __forceinline__ float SqrtTimesResolution(int32_t d2, double resolution)
+{
+  const float xf = static_cast<float>(d2);
+  const float y0 = __frsqrt_rn(xf);
+  const double gd = static_cast<double>(xf * y0);
+  const double hd = static_cast<double>(0.5f * y0);
+  const double rem = fma(-gd, gd, static_cast<double>(d2));  // exact: gd has 24 significant bits
+  const double p = fma(rem, hd, gd) * resolution;
+  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p)) & 0x1fffffffu;
+  const int off = static_cast<int>(low) - 0x10000000;
+  const bool range_ok = (resolution > 1.0e-30) && (resolution < 1.0e30);
+  if (d2 <= 0 || !range_ok || (off > -8192 && off < 8192)) return SqrtTimesResolutionExact(d2, resolution);
+  return static_cast<float>(p);
+}
+
+// Virtual border (signed_distance_field_generation.hpp:134-284) through its closed form
+// min(d2, b^2), b = distance to the nearest virtual border cell.
+__device__ __forceinline__ int32_t ClampToVirtualBorder(int32_t d2, int x, int y, int z, int nx, int ny, int nz)
+{
+  int32_t b = kInf32;
+  if (nx > 1) b = min(b, min(x + 1, nx - x));
+  if (ny > 1) b = min(b, min(y + 1, ny - y));
+  if (nz > 1) b = min(b, min(z + 1, nz - z));
+  return (b != kInf32) ? min(d2, Sq(b)) : d2;
+}
+
+// Squared voxel distance (after the border clamp) -> float SDF value.
+__device__ __forceinline__ float DistanceToSdf(int32_t d2, bool negative, double resolution)
+{
+  const float dist = (d2 == kInf32) ? __uint_as_float(0x7f800000u) : SqrtTimesResolution(d2, resolution);
+  return negative ? -dist : dist;
+}
+
 // Final conversion shared by every X-pass implementation: squared voxel distance -> float SDF.
-// Matches signed_distance_field_generation.hpp:98-105 evaluated in double, and the
-// virtual-border branch (:134-284) through its closed form min(d2, b^2) with b the distance to
-// the nearest virtual border cell.
 __device__ __forceinline__ float FinalizeSdf(int32_t d2, bool negative, int x, int y, int z,
                                              int nx, int ny, int nz, double resolution,
                                              int add_virtual_border)
 {
-  if (add_virtual_border)
-  {
-    int32_t b = kInf32;
-    if (nx > 1) b = min(b, min(x + 1, nx - x));
-    if (ny > 1) b = min(b, min(y + 1, ny - y));
-    if (nz > 1) b = min(b, min(z + 1, nz - z));
-    if (b != kInf32) d2 = min(d2, b * b);
-  }
-  float dist;
-  if (d2 == kInf32)
-    dist = __uint_as_float(0x7f800000u);
-  else
-    dist = static_cast<float>(sqrt(static_cast<double>(d2)) * resolution);
-  return negative ? -dist : dist;
+  if (add_virtual_border) d2 = ClampToVirtualBorder(d2, x, y, z, nx, ny, nz);
+  return DistanceToSdf(d2, negative, resolution);
 }
 
 // Wave + block reduction of the ordered encodings, one atomic pair per block.

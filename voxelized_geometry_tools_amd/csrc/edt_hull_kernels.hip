@@ -33,6 +33,15 @@
 
 #include <cstdlib>
 
+// Phase-skipping knobs for timing experiments (VGT_HULL_SKIP=<bits>) exist only in builds with
+// -DVGT_HULL_DEBUG: in the product build the tests are compile-time false, so no kernel argument
+// is re-read inside the hot loops.
+#ifdef VGT_HULL_DEBUG
+#define VGT_SKIP(bit) (g.debug_skip & (bit))
+#else
+#define VGT_SKIP(bit) false
+#endif
+
 namespace vgt
 {
 #ifdef VGT_HULL_STATS
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   int tile_id = blockIdx.x;
   {
     const int group = kNumXcd * g.ztiles;
-    if (!(g.debug_skip & 64) && tile_id < static_cast<int>(gridDim.x) / group * group)
+    if (!(VGT_SKIP(64)) && tile_id < static_cast<int>(gridDim.x) / group * group)
     {
       const int local = tile_id % group;
       tile_id = tile_id - local + (local % kNumXcd) * g.ztiles + local / kNumXcd;
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             }
           }
         }
-        if (j + 1 < nwords) t.seed_lo[(j + 1) * W + line] = static_cast<int16_t>((g.debug_skip & 16) ? -1 : row);
+        if (j + 1 < nwords) t.seed_lo[(j + 1) * W + line] = static_cast<int16_t>((VGT_SKIP(16)) ? -1 : row);
         if (j == 0) t.seed_lo[line] = -1;
       }
       // downwards: boundary row Q = last row of band j-1
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             }
           }
         }
-        if (ok && j >= 1) t.seed_hi[(j - 1) * W + line] = static_cast<int16_t>((g.debug_skip & 16) ? -1 : row);
+        if (ok && j >= 1) t.seed_hi[(j - 1) * W + line] = static_cast<int16_t>((VGT_SKIP(16)) ? -1 : row);
         if (j == nwords - 1) t.seed_hi[j * W + line] = -1;
       }
     }
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   if (band < nwords)
   {
     uint32_t abits = 0;
-    if (z < g.nz && !(g.debug_skip & 8) && finite)
+    if (z < g.nz && !(VGT_SKIP(8)) && finite)
     {
       const int nrows = r1 - r0;
       // seeds chosen in 1b
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       // (the left one wins everywhere below, the right one everywhere above), so it need not
       // enter the stack.
       uint32_t cand = finite;
-      if (!(g.debug_skip & 32))
+      if (!(VGT_SKIP(32)))
       {
         // One carried site per direction: sweeping up, the carried site is the one that was
         // strictly better at its own row than the site carried before it; a member the carried
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         // Chord tests at fixed spacings: member k lies on or above the chord of the members d rows
         // below and above it (same run portion) <=> G(k-d) + G(k+d) <= 2 G(k)
         // <=> f(k-d) + f(k+d) + 2 d^2 <= 2 f(k): no multiplications for a constant d.
-        if (!(g.debug_skip & 256))
+        if (!(VGT_SKIP(256)))
         {
           uint32_t above = 0;
 #pragma unroll
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           }
         }
         const int32_t Gc = fcur + Sq(r);
-        if (sec >= 0 && !(g.debug_skip & 4) && Dominated(Gsec, sec, Gtop, top, Gc, r))
+        if (sec >= 0 && !(VGT_SKIP(4)) && Dominated(Gsec, sec, Gtop, top, Gc, r))
         {
           pop();
           continue;  // same candidate again
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (seed_r >= 0)
         while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gseed_r, seed_r)) pop();
     }
-    else if (z < g.nz && (g.debug_skip & 8))
+    else if (z < g.nz && (VGT_SKIP(8)))
     {
       // debug: every finite member survives the band phase
       for (int r = r0; r < r1; r++)
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   for (int round = 0; round < 4 * nwords + 8; round++)
   {
     int changed = 0;
-    if (active && band > 0 && !(g.debug_skip & 1))
+    if (active && band > 0 && !(VGT_SKIP(1)))
     {
       const int R = r0;  // first row above the junction
       const bool neg = (sbits & 1u) != 0u;
@@ -799,7 +808,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 
   // ---- 3. evaluate this band's rows, store ----
   uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
-  if (active && !(g.debug_skip & 2))
+  int32_t lo_key = kInf32, hi_key = -kInf32;
+  if (active && !(VGT_SKIP(2)))
   {
     const uint32_t tw = t.T[band * W + t.w];
     // owner of r0: the k-th survivor of the line, k = number of start bits at or below r0
@@ -862,12 +872,12 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int x = (g.pass_axis == 0) ? r : outer;
         const int y = (g.pass_axis == 0) ? outer : r;
-        const float v = FinalizeSdf(best, neg, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global, g.resolution,
-                                    g.add_virtual_border);
-        *dst = v;
-        const uint32_t e = EncodeOrdered(v);
-        lo_enc = min(lo_enc, e);
-        hi_enc = max(hi_enc, e);
+        if (g.add_virtual_border) best = ClampToVirtualBorder(best, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
+        if (!VGT_SKIP(1024) || best == 123456789) *dst = DistanceToSdf(best, neg, g.resolution);
+        // the SDF value is monotone in the signed squared distance: track that, convert once
+        const int32_t key = neg ? -best : best;
+        lo_key = min(lo_key, key);
+        hi_key = max(hi_key, key);
       }
       else
       {
@@ -875,7 +885,15 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       }
     }
   }
-  if constexpr (kFinal) BlockMinMax(lo_enc, hi_enc, minmax_enc);
+  if constexpr (kFinal)
+  {
+    if (lo_key <= hi_key)
+    {
+      lo_enc = EncodeOrdered(DistanceToSdf(lo_key < 0 ? -lo_key : lo_key, lo_key < 0, g.resolution));
+      hi_enc = EncodeOrdered(DistanceToSdf(hi_key < 0 ? -hi_key : hi_key, hi_key < 0, g.resolution));
+    }
+    BlockMinMax(lo_enc, hi_enc, minmax_enc);
+  }
 #ifdef VGT_HULL_STATS
   __syncthreads();
   if (threadIdx.x == 0)

@@ -565,6 +565,42 @@ hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfPar
   return LaunchScanZ<uint8_t>(mask, out16, p, 0, summary, stream);
 }
 
+namespace
+{
+// Diagnostic: compares the fast final conversion with the exact one over a range of squared
+// distances; result[0] = number of differing values, result[1] = first differing d2 (or ~0).
+__global__ __launch_bounds__(256) void FinalizeCheckKernel(int64_t first, int64_t count, double resolution,
+                                                          unsigned long long* __restrict__ result)
+{
+  unsigned long long bad = 0, first_bad = ~0ull;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int32_t d2 = static_cast<int32_t>(first + i);
+    const float fast = SqrtTimesResolution(d2, resolution);
+    const float exact = SqrtTimesResolutionExact(d2, resolution);
+    if (__float_as_uint(fast) != __float_as_uint(exact))
+    {
+      bad++;
+      first_bad = min(first_bad, static_cast<unsigned long long>(d2));
+    }
+  }
+  if (bad)
+  {
+    atomicAdd(&result[0], bad);
+    atomicMin(&result[1], first_bad);
+  }
+}
+}  // namespace
+
+hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
+                               unsigned long long* result_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(FinalizeCheckKernel, dim3(4096), dim3(256), 0, stream, first, count, resolution,
+                     result_dev);
+  return hipGetLastError();
+}
+
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream)
 {

@@ -330,6 +330,29 @@ int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
   return VGT_HIP_OK;
 }
 
+int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t count, double resolution,
+                                 uint64_t* mismatches, uint64_t* first_mismatch)
+{
+  if (!ctx || !mismatches || !first_mismatch || first_d2 < 0 || count <= 0 ||
+      first_d2 + count > (int64_t{1} << 31))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid finalize-check range");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  unsigned long long* result = nullptr;
+  VGT_TRY_HIP(hipMalloc(&result, 2 * sizeof(unsigned long long)), "allocate check result");
+  const unsigned long long init[2] = {0ull, ~0ull};
+  hipError_t err = hipMemcpyAsync(result, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream);
+  if (err == hipSuccess) err = vgt::LaunchFinalizeCheck(first_d2, count, resolution, result, ctx->stream);
+  unsigned long long host[2] = {0ull, ~0ull};
+  if (err == hipSuccess)
+    err = hipMemcpyAsync(host, result, sizeof(host), hipMemcpyDeviceToHost, ctx->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(result);
+  VGT_TRY_HIP(err, "finalize check");
+  *mismatches = host[0];
+  *first_mismatch = host[1];
+  return VGT_HIP_OK;
+}
+
 /* ------------------------------ tracking grids ------------------------------ */
 
 int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t num_grids,
