@@ -202,3 +202,51 @@ def test_exact_finalize_matches_numpy(ctx):
         expect = (np.sqrt(d2) * res).astype(np.float32)
         expect[0] = -np.float32(np.sqrt(1.0) * res)
         assert bits_equal(sdf[:, 0, 0], expect)
+
+
+def test_two_giga_voxel_slab_is_indexed_with_64_bits(ctx):
+    """One rank's share of BASELINE config 5 at two GPUs (2048 x 2048 x 512 = 2^31 voxels), device-resident.
+    Three filled voxels in far corners make the field analytic (min over three point distances), so every
+    voxel is checked, chunk by chunk, against float32(sqrt(float64(d2)) * res) computed with torch."""
+    import torch
+    free = torch.cuda.mem_get_info()[0]
+    if free < 70 * 2 ** 30:
+        pytest.skip("needs ~60 GiB of free HBM")
+    shape = (2048, 2048, 512)
+    res = 0.01
+    sites = [(2047, 2047, 511), (0, 2040, 3), (1999, 1, 500)]
+    occ = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    for s in sites:
+        occ[s] = 1.0
+    sdf = torch.empty(shape, dtype=torch.float32, device="cuda")
+    nbytes = capi.sdf_workspace_bytes(shape)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    minmax = torch.zeros(2, dtype=torch.float32, device="cuda")
+    ctx.set_stream(None)
+    try:
+        ctx.sdf_dev(occ.data_ptr(), shape, res, sdf.data_ptr(), ws.data_ptr(), nbytes, minmax.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.reset_stream()
+    del ws
+    ay = torch.arange(shape[1], device="cuda", dtype=torch.int64)
+    az = torch.arange(shape[2], device="cuda", dtype=torch.int64)
+    worst = 0
+    hi = 0.0
+    for x0 in range(0, shape[0], 64):
+        ax = torch.arange(x0, x0 + 64, device="cuda", dtype=torch.int64)
+        d2 = None
+        for (sx, sy, sz) in sites:
+            d = ((ax - sx) ** 2)[:, None, None] + ((ay - sy) ** 2)[None, :, None] + ((az - sz) ** 2)[None, None, :]
+            d2 = d if d2 is None else torch.minimum(d2, d)
+        want = (torch.sqrt(d2.to(torch.float64)) * res).to(torch.float32)
+        got = sdf[x0:x0 + 64]
+        filled = d2 == 0
+        # a filled voxel's distance is to the nearest FREE voxel: 1 voxel here
+        want = torch.where(filled, torch.full_like(want, -float(np.float32(res))), want)
+        diff = (got.view(torch.int32) - want.view(torch.int32)).abs().max().item()
+        worst = max(worst, diff)
+        hi = max(hi, got.max().item())
+    assert worst == 0
+    mm = minmax.cpu().numpy()
+    assert mm[0] == -np.float32(res) and mm[1] == np.float32(hi)
