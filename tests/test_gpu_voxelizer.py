@@ -184,3 +184,42 @@ def test_handle_errors(ctx):
     assert not grids.retrieve(0).any()                 # empty cloud is a no-op
     with pytest.raises(capi.VgtHipUnavailable):
         capi.Context(9999)                             # device index out of range
+
+
+@pytest.mark.parametrize("add_virtual_border", [False, True])
+def test_device_resident_voxelize_then_sdf(ctx, oracle, add_virtual_border):
+    """raycast -> filter -> SDF without leaving the device (the filtered grid's device buffer is
+    the EDT's input, the extrema come back from the device instead of SignedDistanceField::Lock()'s host
+    rescan), against the same chain through the oracle."""
+    import torch
+    counts = (96, 80, 64)
+    vs = np.float32(0.05)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    static = synthetic.make_occupancy(counts, "spheres", seed=5) * np.float32(0.0) + np.float32(0.5)  # all unknown
+    clouds = [synthetic.raycast_cloud(40_000, seed=7 + i) * np.float32(0.6) for i in range(2)]
+    xfs = [synthetic.translation_xform(2.0 + i, 2.0, 1.6).astype(np.float32) for i in range(2)]
+    grids = ctx.tracking_grids(int(np.prod(counts)), 2)
+    want_tracking = []
+    for i in range(2):
+        grids.raycast_f32(i, clouds[i], 4.0, xfs[i], vs, ivs, sizes, counts)
+        want_tracking.append(oracle.raycast_f32(clouds[i], 4.0, xfs[i], vs, ivs, sizes, counts))
+    fg = ctx.filter_grid(static)
+    fg.filter(grids, 0.9, 1, 1)
+    want_occ = oracle.filter_grids(np.stack(want_tracking), static, 0.9, 1, 1, False)
+    assert len(np.unique(want_occ)) == 3          # free, unknown and filled cells all present
+    want_sdf, wlo, whi = oracle.sdf_from_occupancy(want_occ, float(vs), True, add_virtual_border)
+
+    sdf = torch.empty(counts, dtype=torch.float32, device="cuda")
+    nbytes = capi.sdf_workspace_bytes(counts)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    minmax = torch.zeros(2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    # same context => same stream as the raycast and the filter: no host synchronisation in between
+    ctx.sdf_dev(fg.dev_ptr(), counts, float(vs), sdf.data_ptr(), ws.data_ptr(), nbytes, minmax.data_ptr(),
+                unknown_is_filled=True, add_virtual_border=add_virtual_border)
+    ctx.synchronize()
+    got = sdf.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want_sdf.view(np.uint32))
+    mm = minmax.cpu().numpy()
+    assert (float(mm[0]), float(mm[1])) == (wlo, whi)
