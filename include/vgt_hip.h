@@ -189,6 +189,43 @@ int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t cou
                                  double resolution, uint64_t* mismatches,
                                  uint64_t* first_mismatch);
 
+/* ---- SDFs of the map types whose cells carry more than an occupancy ----
+ * Replaces the per-voxel `is_filled_fn` + EDT of
+ *   OccupancyComponentMap::ExtractSignedDistanceField            occupancy_component_map.hpp:270-306
+ *   TaggedObjectOccupancyMap::ExtractSignedDistanceField         tagged_object_occupancy_map.hpp:199-247
+ *     ::MakeSeparateObjectSDFs / ::MakeAllObjectSDFs             :249-290
+ *     ::ExtractFreeAndNamedObjectsSignedDistanceField            :292-378
+ *   TaggedObjectOccupancyComponentMap (same four)                tagged_object_occupancy_component_map.hpp:361-540
+ * The raw cell store (`GetImmutableRawData().data()`) is uploaded once; every extraction after that
+ * evaluates its predicate on the device and runs the same exact EDT.
+ *   cell_bytes        sizeof the cell: 8 (OccupancyComponentCell, TaggedObjectOccupancyCell) or
+ *                     16 (TaggedObjectOccupancyComponentCell); 4 (plain OccupancyCell) also works.
+ *                     The float occupancy is the first member of all of them.
+ *   object_id_offset  byte offset of the uint32 object id inside a cell (4 for both tagged types),
+ *                     or -1 for a type without one (OccupancyComponentCell: the component is not
+ *                     used by its SDF). */
+typedef struct vgt_hip_cells vgt_hip_cells;
+int vgt_hip_cells_create(vgt_hip_ctx* ctx, const void* cells_host, int64_t nx, int64_t ny,
+                         int64_t nz, int32_t cell_bytes, int32_t object_id_offset,
+                         vgt_hip_cells** out_cells);
+void vgt_hip_cells_destroy(vgt_hip_cells* cells);
+/* Distinct object ids > 0 in ascending order (what MakeAllObjectSDFs collects in a std::set).
+ * Writes at most `capacity` ids; *count receives the number found. */
+int vgt_hip_cells_object_ids(vgt_hip_ctx* ctx, vgt_hip_cells* cells, uint32_t* ids_out,
+                             int64_t capacity, int64_t* count);
+/* ExtractSignedDistanceField(objects_to_use, parameters): a cell is filled when its occupancy is
+ * (> 0.5, or == 0.5 with unknown_is_filled) AND (num_objects == 0 or its object id is listed).
+ * One call per object id = MakeSeparateObjectSDFs. */
+int vgt_hip_cells_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* objects_to_use,
+                      int64_t num_objects, double resolution, int unknown_is_filled,
+                      int add_virtual_border, float* sdf_host, float* out_min, float* out_max);
+/* ExtractFreeAndNamedObjectsSignedDistanceField: the field of all filled cells where it is >= 0,
+ * the field of the filled cells of named objects (id > 0) where that is <= 0, else 0. */
+int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells,
+                                             double resolution, int unknown_is_filled,
+                                             int add_virtual_border, float* sdf_host,
+                                             float* out_min, float* out_max);
+
 /* ---- multi-GPU: the grid is cut into Z slabs, one device per slab (BASELINE.json config 5).
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
  * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest

@@ -14,6 +14,9 @@
 #include <string>
 #include <vector>
 
+struct vgt_hip_ctx;
+struct vgt_hip_cells;
+
 #include "hip_voxelization_helpers.h"
 #include "host_types.hpp"
 
@@ -56,4 +59,42 @@ private:
 // reference rejects, std::runtime_error when no HIP device can be used (no CPU fallback).
 SignedDistanceField ExtractSignedDistanceField(
     const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters);
+
+// ---- the other three map types ----
+// OccupancyComponentMap::ExtractSignedDistanceField<float> (occupancy_component_map.hpp:270-306).
+SignedDistanceField ExtractSignedDistanceField(
+    const OccupancyComponentMap& map, const SignedDistanceFieldGenerationParameters& parameters);
+
+// A tagged map's cells on the device, for any number of extractions.  The methods are the
+// reference's (tagged_object_occupancy_map.hpp:199-378 and
+// tagged_object_occupancy_component_map.hpp:361-540), float instantiation.
+class DeviceTaggedObjectMap
+{
+public:
+  DeviceTaggedObjectMap(const TaggedObjectOccupancyMap& map, int hip_device = 0);
+  DeviceTaggedObjectMap(const TaggedObjectOccupancyComponentMap& map, int hip_device = 0);
+  ~DeviceTaggedObjectMap();
+  DeviceTaggedObjectMap(const DeviceTaggedObjectMap&) = delete;
+  DeviceTaggedObjectMap& operator=(const DeviceTaggedObjectMap&) = delete;
+
+  SignedDistanceField ExtractSignedDistanceField(
+      const std::vector<uint32_t>& objects_to_use,
+      const SignedDistanceFieldGenerationParameters& parameters) const;
+  std::map<uint32_t, SignedDistanceField> MakeSeparateObjectSDFs(
+      const std::vector<uint32_t>& object_ids,
+      const SignedDistanceFieldGenerationParameters& parameters) const;
+  std::map<uint32_t, SignedDistanceField> MakeAllObjectSDFs(
+      const SignedDistanceFieldGenerationParameters& parameters) const;
+  SignedDistanceField ExtractFreeAndNamedObjectsSignedDistanceField(
+      const SignedDistanceFieldGenerationParameters& parameters) const;
+  // distinct object ids > 0, ascending
+  std::vector<uint32_t> ObjectIds() const;
+
+private:
+  void Upload(const void* cells, int cell_bytes, int object_id_offset, int hip_device);
+  SignedDistanceField EmptyField(const SignedDistanceFieldGenerationParameters& parameters) const;
+  ::vgt_hip_ctx* ctx_ = nullptr;
+  ::vgt_hip_cells* cells_ = nullptr;
+  DenseGrid shape_;  // origin / frame / sizes of the map, for the fields handed back
+};
 }  // namespace vgt_hip

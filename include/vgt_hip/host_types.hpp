@@ -158,6 +158,80 @@ private:
 
 using OccupancyMap = DenseGrid;
 
+// Cell types of the other three map types, laid out exactly as the reference's
+// (occupancy_component_map.hpp:29-72, tagged_object_occupancy_map.hpp:29-69,
+// tagged_object_occupancy_component_map.hpp:30-99): the float occupancy first, then uint32s.
+struct OccupancyComponentCell
+{
+  float occupancy = 0.0f;
+  uint32_t component = 0u;
+};
+struct TaggedObjectOccupancyCell
+{
+  float occupancy = 0.0f;
+  uint32_t object_id = 0u;
+};
+struct TaggedObjectOccupancyComponentCell
+{
+  float occupancy = 0.0f;
+  uint32_t object_id = 0u;
+  uint32_t component = 0u;
+  uint32_t spatial_segment = 0u;
+};
+static_assert(sizeof(OccupancyComponentCell) == 8 && sizeof(TaggedObjectOccupancyCell) == 8 &&
+                  sizeof(TaggedObjectOccupancyComponentCell) == 16,
+              "cell records must match the reference's raw store");
+
+// The part of OccupancyComponentMap / TaggedObjectOccupancyMap /
+// TaggedObjectOccupancyComponentMap that their SDF entry points touch: a dense X-major /
+// Z-fastest grid of cells with a uniform voxel size.
+template <typename Cell>
+class CellGrid
+{
+public:
+  CellGrid() = default;
+  CellGrid(const Isometry3& origin_transform, const std::string& frame, double resolution,
+           int64_t num_x, int64_t num_y, int64_t num_z, const Cell& default_value)
+      : origin_(origin_transform), frame_(frame), resolution_(resolution), nx_(num_x), ny_(num_y),
+        nz_(num_z)
+  {
+    if (!(resolution > 0.0) || num_x <= 0 || num_y <= 0 || num_z <= 0)
+      throw std::invalid_argument("Grid must have positive resolution and voxel counts");
+    data_.assign(static_cast<size_t>(num_x * num_y * num_z), default_value);
+  }
+  bool IsInitialized() const { return !data_.empty(); }
+  int64_t NumXVoxels() const { return nx_; }
+  int64_t NumYVoxels() const { return ny_; }
+  int64_t NumZVoxels() const { return nz_; }
+  double Resolution() const { return resolution_; }
+  const Isometry3& OriginTransform() const { return origin_; }
+  const std::string& Frame() const { return frame_; }
+  const Cell& GetIndexImmutable(int64_t x, int64_t y, int64_t z) const
+  {
+    if (x < 0 || x >= nx_ || y < 0 || y >= ny_ || z < 0 || z >= nz_)
+      throw std::runtime_error("index out of grid bounds");
+    return data_[static_cast<size_t>((x * ny_ + y) * nz_ + z)];
+  }
+  void SetIndex(int64_t x, int64_t y, int64_t z, const Cell& value)
+  {
+    if (x < 0 || x >= nx_ || y < 0 || y >= ny_ || z < 0 || z >= nz_)
+      throw std::runtime_error("index out of grid bounds");
+    data_[static_cast<size_t>((x * ny_ + y) * nz_ + z)] = value;
+  }
+  const std::vector<Cell>& GetImmutableRawData() const { return data_; }
+
+private:
+  Isometry3 origin_;
+  std::string frame_;
+  double resolution_ = 0.0;
+  int64_t nx_ = 0, ny_ = 0, nz_ = 0;
+  std::vector<Cell> data_;
+};
+
+using OccupancyComponentMap = CellGrid<OccupancyComponentCell>;
+using TaggedObjectOccupancyMap = CellGrid<TaggedObjectOccupancyCell>;
+using TaggedObjectOccupancyComponentMap = CellGrid<TaggedObjectOccupancyComponentCell>;
+
 // SignedDistanceFieldGenerationParameters<float> (signed_distance_field.hpp:1234-1264), minus
 // the CPU parallelism knob, plus the device to run on.
 struct SignedDistanceFieldGenerationParameters

@@ -46,6 +46,9 @@ def load(path=None):
     lib.vgt_oracle_sdf_from_occupancy.argtypes = [
         _p, _i64, _i64, _i64, _f64, ctypes.c_int, ctypes.c_int, _p, _p, _p, ctypes.c_int]
     lib.vgt_oracle_sdf_from_occupancy.restype = ctypes.c_int
+    lib.vgt_oracle_cells_filled_mask.argtypes = [_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _p, _i64,
+                                                 ctypes.c_int, _p]
+    lib.vgt_oracle_combine_free_and_named.argtypes = [_p, _p, _i64, _p, _p, _p]
     lib.vgt_oracle_raycast_f32.argtypes = [
         _p, _i64, _f32, _p, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _i32, _p, ctypes.c_int]
     lib.vgt_oracle_raycast_f64.argtypes = [
@@ -102,6 +105,41 @@ def sdf_from_occupancy(occupancy, resolution, unknown_is_filled=True,
         int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo), ctypes.byref(hi), threads)
     if rc != 0:
         raise RuntimeError("vgt_oracle_sdf_from_occupancy failed rc=%d" % rc)
+    return out, float(lo.value), float(hi.value)
+
+
+def cells_filled_mask(records, shape, mode, objects=(), unknown_is_filled=True, object_id_offset=4):
+    """is_filled_fn of the tagged map types over a numpy record array (mode 0 / 1 / 2, see vgt_oracle.h)."""
+    rec = np.ascontiguousarray(records)
+    objs = np.ascontiguousarray(np.asarray(list(objects), dtype=np.uint32))
+    mask = np.empty(rec.size, dtype=np.uint8)
+    load().vgt_oracle_cells_filled_mask(_ptr(rec), rec.size, rec.dtype.itemsize, int(object_id_offset),
+                                        int(mode), _ptr(objs) if objs.size else None, objs.size,
+                                        int(bool(unknown_is_filled)), _ptr(mask))
+    return mask.reshape(shape)
+
+
+def sdf_from_cells(records, shape, resolution, objects_to_use=(), unknown_is_filled=True,
+                   add_virtual_border=False, mode=None, object_id_offset=4):
+    """ExtractSignedDistanceField of the tagged map types; returns (sdf, min, max)."""
+    if mode is None:
+        mode = 1 if object_id_offset >= 0 else 0
+    mask = cells_filled_mask(records, shape, mode, objects_to_use, unknown_is_filled, object_id_offset)
+    # a 0/1 occupancy through the plain predicate is the same is_filled_fn
+    return sdf_from_occupancy(mask.astype(np.float32), resolution, False, add_virtual_border)
+
+
+def free_and_named_objects_sdf(records, shape, resolution, unknown_is_filled=True, add_virtual_border=False,
+                               object_id_offset=4):
+    """ExtractFreeAndNamedObjectsSignedDistanceField; returns (sdf, min, max)."""
+    free_sdf, _, _ = sdf_from_cells(records, shape, resolution, (), unknown_is_filled, add_virtual_border, 0,
+                                    object_id_offset)
+    named_sdf, _, _ = sdf_from_cells(records, shape, resolution, (), unknown_is_filled, add_virtual_border, 2,
+                                     object_id_offset)
+    out = np.empty_like(free_sdf)
+    lo, hi = ctypes.c_float(), ctypes.c_float()
+    load().vgt_oracle_combine_free_and_named(_ptr(free_sdf), _ptr(named_sdf), free_sdf.size, _ptr(out),
+                                             ctypes.byref(lo), ctypes.byref(hi))
     return out, float(lo.value), float(hi.value)
 
 

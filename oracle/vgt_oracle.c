@@ -343,6 +343,63 @@ int vgt_oracle_sdf_from_occupancy(const float* occupancy, int64_t nx,
 /* ------------------------------------------------------------------------- */
 /* Raycast DDA -- float32 (device kernel restatement)                        */
 /* ------------------------------------------------------------------------- */
+/* Map types whose cells carry an object id.                    */
+/* ------------------------------------------------------------------------- */
+
+void vgt_oracle_cells_filled_mask(const void* cells, int64_t num_cells, int cell_bytes,
+                                  int object_id_offset, int mode, const uint32_t* objects,
+                                  int64_t num_objects, int unknown_is_filled,
+                                  uint8_t* mask_out)
+{
+  const uint8_t* base = (const uint8_t*)cells;
+  for (int64_t i = 0; i < num_cells; i++)
+  {
+    float occupancy;
+    uint32_t object_id = 0;
+    memcpy(&occupancy, base + i * cell_bytes, sizeof(float));
+    if (object_id_offset >= 0)
+      memcpy(&object_id, base + i * cell_bytes + object_id_offset, sizeof(uint32_t));
+    int considered = 1;
+    if (mode == 1)
+    {
+      /* tagged_object_occupancy_map.hpp:219-221: in the set, or no objects supplied */
+      considered = (num_objects == 0);
+      for (int64_t k = 0; k < num_objects && !considered; k++)
+        if (objects[k] == object_id) considered = 1;
+    }
+    else if (mode == 2)
+    {
+      considered = (object_id > 0u); /* :330 */
+    }
+    mask_out[i] = (uint8_t)(considered && occupancy_is_filled(occupancy, unknown_is_filled));
+  }
+}
+
+void vgt_oracle_combine_free_and_named(const float* free_sdf, const float* named_sdf,
+                                       int64_t num_cells, float* out, float* out_min,
+                                       float* out_max)
+{
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = 0; i < num_cells; i++)
+  {
+    const float free_sdf_value = free_sdf[i];
+    const float named_objects_sdf_value = named_sdf[i];
+    float v;
+    if (free_sdf_value >= 0.0)
+      v = free_sdf_value;
+    else if (named_objects_sdf_value <= -0.0)
+      v = named_objects_sdf_value;
+    else
+      v = 0.0f;
+    out[i] = v;
+    if (v < lo) lo = v;
+    if (v > hi) hi = v;
+  }
+  if (out_min) *out_min = lo;
+  if (out_max) *out_max = hi;
+}
+
+/* ------------------------------------------------------------------------- */
 
 static int32_t step_from_diff_i32(int32_t diff)
 {

@@ -29,6 +29,30 @@ def sdf_scipy_cases():
 
 
 @pytest.fixture(scope="session")
+def sdf_tagged_cases():
+    """tests/golden/sdf_tagged_scipy.npz: {grid: {field: array}} (make_golden.make_tagged_sdf_fixture)."""
+    z = np.load(os.path.join(GOLDEN, "sdf_tagged_scipy.npz"))
+    out = {}
+    for k in z.files:
+        name, field = k.split("__", 1)
+        out.setdefault(name, {})[field] = z[k]
+    return out
+
+
+def tagged_records(case, dtype):
+    """Cell records of one tagged fixture grid in the layout of one of the reference's cell types."""
+    rec = np.zeros(case["occ"].shape, dtype=dtype)
+    rec["occupancy"] = case["occ"]
+    if "object_id" in dtype.names:
+        rec["object_id"] = case["ids"]
+    if "component" in dtype.names:
+        rec["component"] = (case["ids"] * 7 + 3).astype(np.uint32)      # must not influence any SDF
+    if "spatial_segment" in dtype.names:
+        rec["spatial_segment"] = 0xDEADBEEF
+    return rec
+
+
+@pytest.fixture(scope="session")
 def voxelization_scene():
     z = np.load(os.path.join(GOLDEN, "voxelization_scene.npz"))
     return {k: z[k] for k in z.files}

@@ -238,6 +238,66 @@ static void UnavailableBackendTests()
   EXPECT_TRUE(threw);
 }
 
+// ---- tagged map types: values derivable by hand on a 1 x 1 x 8 line ----
+static void TaggedObjectSdfTests()
+{
+  // z:          0    1    2    3    4    5    6    7
+  // occupancy:  1    1    0    0   .5    0    1    0
+  // object id:  3    3    0    0    0    0    9    0
+  TaggedObjectOccupancyMap map(Isometry3::Identity(), "test_frame", 1.0, 1, 1, 8, TaggedObjectOccupancyCell());
+  const float occ[8] = {1, 1, 0, 0, 0.5f, 0, 1, 0};
+  const uint32_t ids[8] = {3, 3, 0, 0, 0, 0, 9, 0};
+  for (int z = 0; z < 8; z++) map.SetIndex(0, 0, z, TaggedObjectOccupancyCell{occ[z], ids[z]});
+  const DeviceTaggedObjectMap device_map(map);
+  SignedDistanceFieldGenerationParameters params;
+  {  // no object list: every filled cell, the unknown one included
+    const SignedDistanceField sdf = device_map.ExtractSignedDistanceField({}, params);
+    const float want[8] = {-2, -1, 1, 1, -1, 1, -1, 1};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
+    EXPECT_FLOAT_EQ(sdf.minimum, -2.0f);
+    EXPECT_FLOAT_EQ(sdf.maximum, 1.0f);
+    EXPECT_TRUE(sdf.IsLocked());
+  }
+  {  // object 9 only
+    const SignedDistanceField sdf = device_map.ExtractSignedDistanceField({9u}, params);
+    const float want[8] = {6, 5, 4, 3, 2, 1, -1, 1};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
+  }
+  {  // MakeAllObjectSDFs finds ids 3 and 9
+    const std::vector<uint32_t> found = device_map.ObjectIds();
+    EXPECT_EQ(found.size(), 2u);
+    const std::map<uint32_t, SignedDistanceField> all = device_map.MakeAllObjectSDFs(params);
+    EXPECT_EQ(all.size(), 2u);
+    EXPECT_TRUE(all.count(3u) == 1 && all.count(9u) == 1);
+    const float want3[8] = {-2, -1, 1, 2, 3, 4, 5, 6};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(all.at(3u).GetIndexImmutable(0, 0, z), want3[z]);
+  }
+  {  // free-and-named: free field where >= 0, named field where <= 0, else 0 (the unknown cell of object 0)
+    const SignedDistanceField sdf = device_map.ExtractFreeAndNamedObjectsSignedDistanceField(params);
+    const float want[8] = {-2, -1, 1, 1, 0, 1, -1, 1};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
+    EXPECT_FLOAT_EQ(sdf.minimum, -2.0f);
+    EXPECT_FLOAT_EQ(sdf.maximum, 1.0f);
+  }
+  {  // the 16-byte cell type gives the same fields; the component map ignores its component
+    TaggedObjectOccupancyComponentMap map16(Isometry3::Identity(), "test_frame", 1.0, 1, 1, 8,
+                                            TaggedObjectOccupancyComponentCell());
+    OccupancyComponentMap map_c(Isometry3::Identity(), "test_frame", 1.0, 1, 1, 8, OccupancyComponentCell());
+    for (int z = 0; z < 8; z++)
+    {
+      map16.SetIndex(0, 0, z, TaggedObjectOccupancyComponentCell{occ[z], ids[z], 77u + z, 5u});
+      map_c.SetIndex(0, 0, z, OccupancyComponentCell{occ[z], 1000u + z});
+    }
+    const DeviceTaggedObjectMap device_map16(map16);
+    const SignedDistanceField a = device_map16.ExtractSignedDistanceField({9u}, params);
+    const float want9[8] = {6, 5, 4, 3, 2, 1, -1, 1};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(a.GetIndexImmutable(0, 0, z), want9[z]);
+    const SignedDistanceField c = ExtractSignedDistanceField(map_c, params);
+    const float want_all[8] = {-2, -1, 1, 1, -1, 1, -1, 1};
+    for (int z = 0; z < 8; z++) EXPECT_FLOAT_EQ(c.GetIndexImmutable(0, 0, z), want_all[z]);
+  }
+}
+
 int main(int argc, char** argv)
 {
   const bool no_device = (argc > 1 && std::strcmp(argv[1], "--no-device") == 0);
@@ -245,6 +305,7 @@ int main(int argc, char** argv)
   if (!no_device)
   {
     SdfGenerationTests();
+    TaggedObjectSdfTests();
     PointCloudVoxelizationTests(1);
     PointCloudVoxelizationTests(4);
   }

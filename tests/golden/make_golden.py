@@ -6,6 +6,8 @@ Run in the BUILD container only (needs scipy; compiles gen_raycast_rays.cpp with
     python tests/golden/make_golden.py
 
 Outputs
+  sdf_tagged_scipy.npz     tagged-object grids with per-object / free-and-named SDFs from the reference's
+                           definitions + scipy's EDT
   sdf_scipy.npz            random / structured occupancy grids with the expected float SDF
                            computed by an INDEPENDENT exact EDT
                            (scipy.ndimage.distance_transform_edt),
@@ -109,6 +111,51 @@ def make_sdf_fixture():
     print("sdf_scipy.npz:", len(cases) // 5, "cases")
 
 
+def make_tagged_sdf_fixture():
+    """Tagged-object grids (occupancy, object id per cell) with the SDFs the reference's
+    TaggedObjectOccupancyMap methods define (tagged_object_occupancy_map.hpp:199-378), computed from
+    those definitions with scipy's EDT -- independent of the oracle and of the HIP path.  The
+    reference's own tests hold no known answers for these methods."""
+    rng = np.random.default_rng(20240901)
+    cases = {}
+
+    def add(name, shape, p_filled, p_unknown, num_ids, res):
+        occ = np.zeros(shape, dtype=np.float32)
+        r = rng.random(shape)
+        occ[r < p_filled] = 1.0
+        occ[(r >= p_filled) & (r < p_filled + p_unknown)] = 0.5
+        occ[rng.random(shape) < 0.05] = 0.25
+        ids = rng.integers(0, num_ids + 1, size=shape).astype(np.uint32)
+        ids[rng.random(shape) < 0.3] = 0
+        cases[name + "__occ"] = occ
+        cases[name + "__ids"] = ids
+        cases[name + "__res"] = np.float64(res)
+        for uif in (0, 1):
+            filled = is_filled(occ, bool(uif))
+            tag = "__uif%d" % uif
+            cases[name + tag + "__all"] = scipy_sdf(filled, res)
+            cases[name + tag + "__all_vb"] = scipy_sdf_virtual_border(filled, res)
+            for k, objs in enumerate(([2], [1, 3], [num_ids + 7], list(range(1, num_ids + 1)))):
+                sel = filled & np.isin(ids, objs)
+                cases[name + tag + "__objs%d" % k] = np.asarray(objs, dtype=np.uint32)
+                cases[name + tag + "__sdf%d" % k] = scipy_sdf(sel, res)
+            free_sdf = scipy_sdf(filled, res)
+            named_sdf = scipy_sdf(filled & (ids > 0), res)
+            combined = np.zeros(shape, dtype=np.float32)
+            pick_free = free_sdf >= 0.0
+            pick_named = (~pick_free) & (named_sdf <= -0.0)
+            combined[pick_free] = free_sdf[pick_free]
+            combined[pick_named] = named_sdf[pick_named]
+            cases[name + tag + "__free_and_named"] = combined
+        cases[name + "__object_ids"] = np.unique(ids[ids > 0]).astype(np.uint32)
+
+    add("tagged_14x11x9", (14, 11, 9), 0.15, 0.05, 4, 0.25)
+    add("tagged_8x20x12", (8, 20, 12), 0.4, 0.1, 3, 0.02)
+    add("tagged_24x24x24", (24, 24, 24), 0.03, 0.01, 6, 0.01)
+    np.savez_compressed(os.path.join(HERE, "sdf_tagged_scipy.npz"), **cases)
+    print("sdf_tagged_scipy.npz: 3 grids")
+
+
 # ---- Eigen-equivalent rigid transform construction (documented in DESIGN.md) ----
 def quat_from_angle_axis(angle, axis):
     s = np.sin(angle / 2.0)
@@ -197,5 +244,6 @@ def make_raycast_rays():
 
 if __name__ == "__main__":
     make_sdf_fixture()
+    make_tagged_sdf_fixture()
     make_voxelization_scene()
     make_raycast_rays()

@@ -1,0 +1,107 @@
+"""(gpu) SDF entry points of the map types with tagged cells (vgt_hip_cells_*): the HIP path
+against the committed scipy fixture and, on larger random grids, against the oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, tagged_records
+from voxelized_geometry_tools_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [capi.TAGGED_OBJECT_CELL, capi.TAGGED_OBJECT_COMPONENT_CELL]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["tagged8", "tagged16"])
+def test_fixture_objects_to_use_and_free_and_named(ctx, sdf_tagged_cases, dtype):
+    for name, case in sdf_tagged_cases.items():
+        rec = tagged_records(case, dtype)
+        res = float(case["res"])
+        cells = ctx.cells(rec, rec.shape)
+        assert np.array_equal(cells.object_ids(), case["object_ids"]), name
+        for uif in (0, 1):
+            tag = "uif%d__" % uif
+            got, lo, hi = cells.sdf(res, (), bool(uif))
+            assert bits_equal(got, case[tag + "all"]), (name, uif)
+            assert (lo, hi) == (got.min(), got.max())
+            got, _, _ = cells.sdf(res, (), bool(uif), True)
+            assert bits_equal(got, case[tag + "all_vb"]), (name, uif)
+            for k in range(4):
+                got, lo, hi = cells.sdf(res, case[tag + "objs%d" % k], bool(uif))
+                assert bits_equal(got, case[tag + "sdf%d" % k]), (name, uif, k)
+                assert (lo, hi) == (got.min(), got.max())
+            got, lo, hi = cells.free_and_named_objects_sdf(res, bool(uif))
+            assert bits_equal(got, case[tag + "free_and_named"]), (name, uif)
+            assert (lo, hi) == (got.min(), got.max())
+        cells.close()
+
+
+def test_component_map(ctx, sdf_tagged_cases):
+    for name, case in sdf_tagged_cases.items():
+        rec = tagged_records(case, capi.OCCUPANCY_COMPONENT_CELL)
+        cells = ctx.cells(rec, rec.shape, object_id_offset=-1)
+        got, _, _ = cells.sdf(float(case["res"]))
+        assert bits_equal(got, case["uif1__all"]), name
+        assert cells.object_ids().size == 0
+        with pytest.raises(ValueError):
+            cells.sdf(float(case["res"]), [1])
+        with pytest.raises(ValueError):
+            cells.free_and_named_objects_sdf(float(case["res"]))
+        cells.close()
+
+
+def test_all_object_sdfs_vs_oracle(ctx, oracle):
+    """MakeAllObjectSDFs on a 96 x 64 x 80 scene of box-shaped objects, ids up to 0xffffffff, long object lists
+    (bisection path) and duplicated ids in the list."""
+    rng = np.random.default_rng(77)
+    shape = (96, 64, 80)
+    rec = np.zeros(shape, dtype=capi.TAGGED_OBJECT_CELL)
+    ids = [1, 2, 5, 40, 41, 1000, 70000, 0xffffffff]
+    for oid in ids:
+        lo = [int(rng.integers(0, s - 12)) for s in shape]
+        ext = [int(rng.integers(3, 12)) for _ in shape]
+        box = tuple(slice(a, a + e) for a, e in zip(lo, ext))
+        rec["occupancy"][box] = 1.0
+        rec["object_id"][box] = oid
+    rec["occupancy"][rng.random(shape) < 0.002] = 0.5          # unknown cells of object 0
+    cells = ctx.cells(rec, shape)
+    found = cells.object_ids()
+    assert np.array_equal(found, np.unique(rec["object_id"][rec["object_id"] > 0]))
+    per_object = cells.all_object_sdfs(0.05)
+    assert sorted(per_object) == [int(i) for i in found]
+    for oid, (sdf, lo, hi) in per_object.items():
+        want, wlo, whi = oracle.sdf_from_cells(rec, shape, 0.05, [oid])
+        assert bits_equal(sdf, want), oid
+        assert (lo, hi) == (wlo, whi)
+    many = list(range(2, 60)) + [70000, 70000, 5]
+    got, lo, hi = cells.sdf(0.05, many, unknown_is_filled=False, add_virtual_border=True)
+    want, wlo, whi = oracle.sdf_from_cells(rec, shape, 0.05, many, False, True)
+    assert bits_equal(got, want) and (lo, hi) == (wlo, whi)
+    got, lo, hi = cells.free_and_named_objects_sdf(0.05, True, True)
+    want, wlo, whi = oracle.free_and_named_objects_sdf(rec, shape, 0.05, True, True)
+    assert bits_equal(got, want) and (lo, hi) == (wlo, whi)
+    cells.close()
+
+
+def test_argument_errors(ctx):
+    rec = np.zeros((4, 4, 4), dtype=capi.TAGGED_OBJECT_CELL)
+    with pytest.raises(ValueError):
+        ctx.cells(rec, (4, 4, 4), object_id_offset=6)            # misaligned
+    with pytest.raises(ValueError):
+        ctx.cells(rec, (4, 4, 4), object_id_offset=8)            # outside the record
+    cells = ctx.cells(rec, (4, 4, 4))
+    with pytest.raises(ValueError):
+        cells.sdf(0.0)                                            # resolution must be positive
+    cells.close()

@@ -60,6 +60,12 @@ SIGNATURES = {
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
+    "vgt_hip_cells_create": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                   ctypes.c_int32, _p]),
+    "vgt_hip_cells_destroy": (None, [_p]),
+    "vgt_hip_cells_object_ids": (_int, [_p, _p, _p, ctypes.c_int64, _p]),
+    "vgt_hip_cells_sdf": (_int, [_p, _p, _p, ctypes.c_int64, ctypes.c_double, _int, _int, _p, _p, _p]),
+    "vgt_hip_cells_free_and_named_objects_sdf": (_int, [_p, _p, ctypes.c_double, _int, _int, _p, _p, _p]),
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
@@ -181,6 +187,10 @@ class Context:
         check(self._lib.vgt_hip_debug_finalize_check(self.handle, int(first_d2), int(count), float(resolution),
                                                      ctypes.byref(bad), ctypes.byref(first)))
         return int(bad.value), (None if first.value == 2 ** 64 - 1 else int(first.value))
+
+    def cells(self, records, shape, object_id_offset=4):
+        """Uploads a grid of cell records (see Cells)."""
+        return Cells(self, records, shape, object_id_offset)
 
     # ---- SDF ----
     def sdf_from_occupancy(self, occupancy, resolution, unknown_is_filled=True,
@@ -359,3 +369,73 @@ class FilterGrid:
         out = np.empty(self.shape, dtype=np.float32)
         check(self._lib.vgt_hip_retrieve_filtered_grid(self.ctx.handle, self.handle, _ptr(out)))
         return out
+
+
+# numpy record layouts of the reference's cell types (occupancy first, then uint32 fields)
+OCCUPANCY_COMPONENT_CELL = np.dtype([("occupancy", np.float32), ("component", np.uint32)])
+TAGGED_OBJECT_CELL = np.dtype([("occupancy", np.float32), ("object_id", np.uint32)])
+TAGGED_OBJECT_COMPONENT_CELL = np.dtype([("occupancy", np.float32), ("object_id", np.uint32),
+                                         ("component", np.uint32), ("spatial_segment", np.uint32)])
+
+
+class Cells:
+    """Device copy of the raw cell store of an OccupancyComponentMap / TaggedObjectOccupancyMap /
+    TaggedObjectOccupancyComponentMap, for any number of SDF extractions (vgt_hip_cells_*)."""
+
+    def __init__(self, ctx, records, shape, object_id_offset=4):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        rec = np.ascontiguousarray(records)
+        self.shape = tuple(int(s) for s in shape)
+        if rec.size != int(np.prod(self.shape)):
+            raise ValueError("records do not match the grid shape")
+        h = _p()
+        check(self._lib.vgt_hip_cells_create(ctx.handle, _ptr(rec), self.shape[0], self.shape[1], self.shape[2],
+                                             rec.dtype.itemsize, int(object_id_offset), ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.vgt_hip_cells_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def object_ids(self, capacity=4096):
+        ids = np.zeros(capacity, dtype=np.uint32)
+        count = ctypes.c_int64(0)
+        check(self._lib.vgt_hip_cells_object_ids(self.ctx.handle, self.handle, _ptr(ids), capacity,
+                                                 ctypes.byref(count)))
+        if count.value > capacity:
+            return self.object_ids(int(count.value))
+        return ids[:count.value].copy()
+
+    def sdf(self, resolution, objects_to_use=(), unknown_is_filled=True, add_virtual_border=False):
+        objs = np.ascontiguousarray(np.asarray(list(objects_to_use), dtype=np.uint32))
+        out = np.empty(self.shape, dtype=np.float32)
+        lo, hi = ctypes.c_float(0), ctypes.c_float(0)
+        check(self._lib.vgt_hip_cells_sdf(self.ctx.handle, self.handle, _ptr(objs) if objs.size else None,
+                                          objs.size, float(resolution), int(bool(unknown_is_filled)),
+                                          int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo),
+                                          ctypes.byref(hi)))
+        return out, float(lo.value), float(hi.value)
+
+    def separate_object_sdfs(self, resolution, object_ids, **kw):
+        """MakeSeparateObjectSDFs: {object id: (sdf, min, max)}."""
+        return {int(i): self.sdf(resolution, [int(i)], **kw) for i in object_ids}
+
+    def all_object_sdfs(self, resolution, **kw):
+        """MakeAllObjectSDFs."""
+        return self.separate_object_sdfs(resolution, self.object_ids(), **kw)
+
+    def free_and_named_objects_sdf(self, resolution, unknown_is_filled=True, add_virtual_border=False):
+        out = np.empty(self.shape, dtype=np.float32)
+        lo, hi = ctypes.c_float(0), ctypes.c_float(0)
+        check(self._lib.vgt_hip_cells_free_and_named_objects_sdf(
+            self.ctx.handle, self.handle, float(resolution), int(bool(unknown_is_filled)),
+            int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo), ctypes.byref(hi)))
+        return out, float(lo.value), float(hi.value)

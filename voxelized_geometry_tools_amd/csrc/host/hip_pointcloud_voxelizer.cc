@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -180,6 +181,152 @@ SignedDistanceField ExtractSignedDistanceField(
   if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
   if (rc != VGT_HIP_OK) throw std::runtime_error(msg);
   sdf.locked = true;  // min / max were computed on the device: Lock() has nothing left to scan
+  return sdf;
+}
+
+// ---- the other three map types ----
+
+namespace
+{
+[[noreturn]] void ThrowForCode(int rc, const std::string& msg)
+{
+  if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+}  // namespace
+
+SignedDistanceField ExtractSignedDistanceField(
+    const OccupancyComponentMap& map, const SignedDistanceFieldGenerationParameters& parameters)
+{
+  if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
+  vgt_hip_ctx* ctx = nullptr;
+  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
+    throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
+  vgt_hip_cells* cells = nullptr;
+  // the component does not enter the SDF (occupancy_component_map.hpp:276-296): no object id
+  int rc = vgt_hip_cells_create(ctx, map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(),
+                                map.NumZVoxels(), static_cast<int32_t>(sizeof(OccupancyComponentCell)), -1,
+                                &cells);
+  SignedDistanceField sdf;
+  sdf.oob_value = parameters.oob_value;
+  sdf.grid = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                       map.NumYVoxels(), map.NumZVoxels(), parameters.oob_value);
+  if (rc == VGT_HIP_OK)
+    rc = vgt_hip_cells_sdf(ctx, cells, nullptr, 0, map.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+                           parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(),
+                           &sdf.minimum, &sdf.maximum);
+  const std::string msg = (rc == VGT_HIP_OK) ? std::string() : std::string(vgt_hip_last_error());
+  vgt_hip_cells_destroy(cells);
+  vgt_hip_destroy(ctx);
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, msg);
+  sdf.locked = true;
+  return sdf;
+}
+
+DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyMap& map, int hip_device)
+{
+  if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
+  shape_ = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(), map.NumYVoxels(),
+                     map.NumZVoxels(), 0.0f);
+  Upload(map.GetImmutableRawData().data(), static_cast<int>(sizeof(TaggedObjectOccupancyCell)),
+         static_cast<int>(offsetof(TaggedObjectOccupancyCell, object_id)), hip_device);
+}
+
+DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyComponentMap& map, int hip_device)
+{
+  if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
+  shape_ = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(), map.NumYVoxels(),
+                     map.NumZVoxels(), 0.0f);
+  Upload(map.GetImmutableRawData().data(), static_cast<int>(sizeof(TaggedObjectOccupancyComponentCell)),
+         static_cast<int>(offsetof(TaggedObjectOccupancyComponentCell, object_id)), hip_device);
+}
+
+void DeviceTaggedObjectMap::Upload(const void* cells, int cell_bytes, int object_id_offset, int hip_device)
+{
+  if (vgt_hip_create(hip_device, -1, &ctx_) != VGT_HIP_OK)
+    throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
+  const int rc = vgt_hip_cells_create(ctx_, cells, shape_.NumXVoxels(), shape_.NumYVoxels(),
+                                      shape_.NumZVoxels(), cell_bytes, object_id_offset, &cells_);
+  if (rc != VGT_HIP_OK)
+  {
+    const std::string msg = vgt_hip_last_error();
+    vgt_hip_destroy(ctx_);
+    ctx_ = nullptr;
+    ThrowForCode(rc, msg);
+  }
+}
+
+DeviceTaggedObjectMap::~DeviceTaggedObjectMap()
+{
+  vgt_hip_cells_destroy(cells_);
+  vgt_hip_destroy(ctx_);
+}
+
+SignedDistanceField DeviceTaggedObjectMap::EmptyField(
+    const SignedDistanceFieldGenerationParameters& parameters) const
+{
+  SignedDistanceField sdf;
+  sdf.oob_value = parameters.oob_value;
+  sdf.grid = DenseGrid(shape_.OriginTransform(), shape_.Frame(), shape_.Resolution(), shape_.NumXVoxels(),
+                       shape_.NumYVoxels(), shape_.NumZVoxels(), parameters.oob_value);
+  return sdf;
+}
+
+SignedDistanceField DeviceTaggedObjectMap::ExtractSignedDistanceField(
+    const std::vector<uint32_t>& objects_to_use,
+    const SignedDistanceFieldGenerationParameters& parameters) const
+{
+  SignedDistanceField sdf = EmptyField(parameters);
+  const int rc = vgt_hip_cells_sdf(
+      ctx_, cells_, objects_to_use.empty() ? nullptr : objects_to_use.data(),
+      static_cast<int64_t>(objects_to_use.size()), shape_.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+      parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(), &sdf.minimum, &sdf.maximum);
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  sdf.locked = true;
+  return sdf;
+}
+
+std::map<uint32_t, SignedDistanceField> DeviceTaggedObjectMap::MakeSeparateObjectSDFs(
+    const std::vector<uint32_t>& object_ids, const SignedDistanceFieldGenerationParameters& parameters) const
+{
+  std::map<uint32_t, SignedDistanceField> per_object_sdfs;
+  for (const uint32_t object_id : object_ids)
+    per_object_sdfs[object_id] = ExtractSignedDistanceField(std::vector<uint32_t>{object_id}, parameters);
+  return per_object_sdfs;
+}
+
+std::vector<uint32_t> DeviceTaggedObjectMap::ObjectIds() const
+{
+  std::vector<uint32_t> ids(64);
+  for (;;)
+  {
+    int64_t count = 0;
+    const int rc = vgt_hip_cells_object_ids(ctx_, cells_, ids.data(), static_cast<int64_t>(ids.size()), &count);
+    if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+    if (count <= static_cast<int64_t>(ids.size()))
+    {
+      ids.resize(static_cast<size_t>(count));
+      return ids;
+    }
+    ids.assign(static_cast<size_t>(count), 0u);
+  }
+}
+
+std::map<uint32_t, SignedDistanceField> DeviceTaggedObjectMap::MakeAllObjectSDFs(
+    const SignedDistanceFieldGenerationParameters& parameters) const
+{
+  return MakeSeparateObjectSDFs(ObjectIds(), parameters);
+}
+
+SignedDistanceField DeviceTaggedObjectMap::ExtractFreeAndNamedObjectsSignedDistanceField(
+    const SignedDistanceFieldGenerationParameters& parameters) const
+{
+  SignedDistanceField sdf = EmptyField(parameters);
+  const int rc = vgt_hip_cells_free_and_named_objects_sdf(
+      ctx_, cells_, shape_.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+      parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(), &sdf.minimum, &sdf.maximum);
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  sdf.locked = true;
   return sdf;
 }
 }  // namespace vgt_hip

@@ -4,11 +4,13 @@
 
 #include "vgt_internal.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 struct vgt_hip_ctx
 {
@@ -36,6 +38,25 @@ struct vgt_hip_filter
   vgt_hip_ctx* ctx = nullptr;
   float* dev = nullptr;
   int64_t num_cells = 0;
+};
+
+// Device copy of a grid of cell records (occupancy + optional object id) and the buffers the
+// per-object SDF extractions reuse.
+struct vgt_hip_cells
+{
+  vgt_hip_ctx* ctx = nullptr;
+  int64_t nx = 0, ny = 0, nz = 0;
+  int cell_bytes = 0;
+  int object_id_offset = -1;
+  void* records = nullptr;      // [num_cells] records of cell_bytes bytes
+  uint8_t* mask = nullptr;      // [num_cells] predicate result, the Z scan's input
+  float* sdf = nullptr;         // [num_cells]
+  float* sdf_named = nullptr;   // [num_cells], allocated by the first free-and-named extraction
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  uint32_t* objects = nullptr;  // object list of the current call
+  size_t objects_capacity = 0;
+  uint32_t* scalar = nullptr;   // two uint32: result of a reduction + found flag
 };
 
 namespace
@@ -733,6 +754,236 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
 }
 
 /* ------------------------------ multi-GPU Z slabs ----------------------------- */
+
+/* ------------------- SDFs of the map types with tagged cells ------------------- */
+
+namespace
+{
+void FreeCells(vgt_hip_cells* c)
+{
+  if (!c) return;
+  if (c->records) (void)hipFree(c->records);
+  if (c->mask) (void)hipFree(c->mask);
+  if (c->sdf) (void)hipFree(c->sdf);
+  if (c->sdf_named) (void)hipFree(c->sdf_named);
+  if (c->workspace) (void)hipFree(c->workspace);
+  if (c->objects) (void)hipFree(c->objects);
+  if (c->scalar) (void)hipFree(c->scalar);
+  delete c;
+}
+
+int CheckCells(const vgt_hip_ctx* ctx, const vgt_hip_cells* cells)
+{
+  if (!ctx || !cells) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (cells->ctx != ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "cells belong to another context");
+  return VGT_HIP_OK;
+}
+
+// mask (mode, objects) -> signed distance field in `sdf_dev`, extrema in ctx->minmax_out.
+// Caller holds the context mutex.
+int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, const vgt::SdfParams& p,
+                float* sdf_dev)
+{
+  const int64_t n = c->nx * c->ny * c->nz;
+  VGT_TRY_HIP(vgt::LaunchCellMask(c->records, n, c->cell_bytes, c->object_id_offset, mode, c->objects,
+                                  num_objects, p.unknown_is_filled, c->mask, ctx->stream),
+              "cell predicate");
+  vgt::SdfParams mask_params = p;
+  mask_params.unknown_is_filled = 0;
+  return RunSdfPipeline<uint8_t>(ctx, c->mask, mask_params, sdf_dev, c->workspace, c->workspace_bytes,
+                                 ctx->minmax_out, nullptr);
+}
+
+int CopySdfToHost(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t n, float* sdf_host, float* out_min,
+                  float* out_max)
+{
+  float mm[2] = {0.0f, 0.0f};
+  hipError_t err = hipMemcpyAsync(sdf_host, sdf_dev, static_cast<size_t>(n) * sizeof(float),
+                                  hipMemcpyDeviceToHost, ctx->stream);
+  if (err == hipSuccess)
+    err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+  if (err != hipSuccess) return FailHip("copy SDF to host", err);
+  if (out_min) *out_min = mm[0];
+  if (out_max) *out_max = mm[1];
+  return VGT_HIP_OK;
+}
+}  // namespace
+
+int vgt_hip_cells_create(vgt_hip_ctx* ctx, const void* cells_host, int64_t nx, int64_t ny, int64_t nz,
+                         int32_t cell_bytes, int32_t object_id_offset, vgt_hip_cells** out_cells)
+{
+  if (!ctx || !cells_host || !out_cells) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *out_cells = nullptr;
+  const int rc = CheckSdfShape(nx, ny, nz, 1.0);
+  if (rc != VGT_HIP_OK) return rc;
+  if (cell_bytes < 4 || cell_bytes % 4 != 0 || cell_bytes > 64)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "cell records must be 4..64 bytes, a multiple of 4");
+  if (object_id_offset != -1 &&
+      (object_id_offset < 4 || object_id_offset % 4 != 0 || object_id_offset + 4 > cell_bytes))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "object id offset outside the cell record");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt_hip_cells* c = new (std::nothrow) vgt_hip_cells();
+  if (!c) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
+  c->ctx = ctx;
+  c->nx = nx;
+  c->ny = ny;
+  c->nz = nz;
+  c->cell_bytes = cell_bytes;
+  c->object_id_offset = object_id_offset;
+  const size_t n = static_cast<size_t>(nx * ny * nz);
+  c->workspace_bytes = vgt_hip_sdf_workspace_bytes(nx, ny, nz);
+  hipError_t err = hipMalloc(&c->records, n * static_cast<size_t>(cell_bytes));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&c->mask), n);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&c->sdf), n * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(&c->workspace, c->workspace_bytes);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&c->scalar), 2 * sizeof(uint32_t));
+  if (err == hipSuccess)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    err = hipMemcpyAsync(c->records, cells_host, n * static_cast<size_t>(cell_bytes), hipMemcpyHostToDevice,
+                         ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+  }
+  if (err != hipSuccess)
+  {
+    FreeCells(c);
+    return FailHip("upload cell records", err);
+  }
+  *out_cells = c;
+  return VGT_HIP_OK;
+}
+
+void vgt_hip_cells_destroy(vgt_hip_cells* cells)
+{
+  if (!cells) return;
+  if (cells->ctx)
+  {
+    (void)hipSetDevice(cells->ctx->device);
+    (void)hipStreamSynchronize(cells->ctx->stream);
+  }
+  FreeCells(cells);
+}
+
+int vgt_hip_cells_object_ids(vgt_hip_ctx* ctx, vgt_hip_cells* cells, uint32_t* ids_out, int64_t capacity,
+                             int64_t* count)
+{
+  const int rc = CheckCells(ctx, cells);
+  if (rc != VGT_HIP_OK) return rc;
+  if (!count || capacity < 0 || (capacity > 0 && !ids_out))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid id buffer");
+  *count = 0;
+  if (cells->object_id_offset < 0) return VGT_HIP_OK;  // this map type has no object ids
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const int64_t n = cells->nx * cells->ny * cells->nz;
+  uint32_t after = 0;  // ids > 0 only (tagged_object_occupancy_map.hpp:279-283)
+  for (;;)
+  {
+    const uint32_t init[2] = {0xffffffffu, 0u};
+    VGT_TRY_HIP(hipMemcpyAsync(cells->scalar, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream),
+                "reset id scan");
+    VGT_TRY_HIP(vgt::LaunchNextObjectId(cells->records, n, cells->cell_bytes, cells->object_id_offset, after,
+                                        cells->scalar, ctx->stream),
+                "object id scan");
+    uint32_t next[2] = {0u, 0u};
+    VGT_TRY_HIP(hipMemcpyAsync(next, cells->scalar, sizeof(next), hipMemcpyDeviceToHost, ctx->stream),
+                "read id scan");
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "id scan");
+    if (!next[1]) break;
+    if (*count < capacity) ids_out[*count] = next[0];
+    (*count)++;
+    after = next[0];
+    if (after == 0xffffffffu) break;
+  }
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_cells_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* objects_to_use,
+                      int64_t num_objects, double resolution, int unknown_is_filled, int add_virtual_border,
+                      float* sdf_host, float* out_min, float* out_max)
+{
+  int rc = CheckCells(ctx, cells);
+  if (rc != VGT_HIP_OK) return rc;
+  if (!sdf_host || num_objects < 0 || (num_objects > 0 && !objects_to_use))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (num_objects > 0 && cells->object_id_offset < 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "this cell type carries no object id");
+  rc = CheckSdfShape(cells->nx, cells->ny, cells->nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  // the reference looks the ids up in a std::set (tagged_object_occupancy_map.hpp:206-211)
+  std::vector<uint32_t> objects(objects_to_use, objects_to_use + num_objects);
+  std::sort(objects.begin(), objects.end());
+  objects.erase(std::unique(objects.begin(), objects.end()), objects.end());
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  if (objects.size() > cells->objects_capacity)
+  {
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain before regrowing object list");
+    if (cells->objects) (void)hipFree(cells->objects);
+    cells->objects = nullptr;
+    cells->objects_capacity = 0;
+    VGT_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&cells->objects), objects.size() * sizeof(uint32_t)),
+                "allocate object list");
+    cells->objects_capacity = objects.size();
+  }
+  if (!objects.empty())
+  {
+    VGT_TRY_HIP(hipMemcpyAsync(cells->objects, objects.data(), objects.size() * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, ctx->stream),
+                "upload object list");
+    // `objects` is pageable host memory: the copy has been staged when the call returns
+  }
+  const vgt::SdfParams p{cells->nx, cells->ny, cells->nz, resolution, unknown_is_filled ? 1 : 0,
+                         add_virtual_border ? 1 : 0};
+  rc = RunCellsSdf(ctx, cells, objects.empty() ? 0 : 1, static_cast<int>(objects.size()), p, cells->sdf);
+  if (rc != VGT_HIP_OK)
+  {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  return CopySdfToHost(ctx, cells->sdf, cells->nx * cells->ny * cells->nz, sdf_host, out_min, out_max);
+}
+
+int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, double resolution,
+                                             int unknown_is_filled, int add_virtual_border, float* sdf_host,
+                                             float* out_min, float* out_max)
+{
+  int rc = CheckCells(ctx, cells);
+  if (rc != VGT_HIP_OK) return rc;
+  if (!sdf_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (cells->object_id_offset < 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "this cell type carries no object id");
+  rc = CheckSdfShape(cells->nx, cells->ny, cells->nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const int64_t n = cells->nx * cells->ny * cells->nz;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  if (!cells->sdf_named)
+    VGT_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&cells->sdf_named), static_cast<size_t>(n) * sizeof(float)),
+                "allocate second SDF");
+  const vgt::SdfParams p{cells->nx, cells->ny, cells->nz, resolution, unknown_is_filled ? 1 : 0,
+                         add_virtual_border ? 1 : 0};
+  rc = RunCellsSdf(ctx, cells, 0, 0, p, cells->sdf);                      // free-space field: every filled cell
+  if (rc == VGT_HIP_OK) rc = RunCellsSdf(ctx, cells, 2, 0, p, cells->sdf_named);  // cells of named objects only
+  if (rc == VGT_HIP_OK)
+  {
+    uint32_t* enc = CarveWorkspace(cells->workspace, cells->nx, cells->ny, cells->nz).minmax_enc;
+    hipError_t err = vgt::LaunchInitMinMax(enc, ctx->stream);
+    if (err == hipSuccess)
+      err = vgt::LaunchCombineFreeAndNamed(cells->sdf, cells->sdf_named, n, cells->sdf, enc, ctx->stream);
+    if (err == hipSuccess) err = vgt::LaunchDecodeMinMax(enc, ctx->minmax_out, ctx->stream);
+    if (err != hipSuccess) rc = FailHip("combine fields", err);
+  }
+  if (rc != VGT_HIP_OK)
+  {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  return CopySdfToHost(ctx, cells->sdf, n, sdf_host, out_min, out_max);
+}
+
+/* --------------------------------- multi-GPU --------------------------------- */
 
 size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny)
 {

@@ -76,6 +76,15 @@ size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
 hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
 
+// --- launchers (cell_kernels.hip): map types whose cells carry an object id ---
+hipError_t LaunchCellMask(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                          int mode, const uint32_t* objects_dev, int num_objects, int unknown_is_filled,
+                          uint8_t* mask_dev, hipStream_t stream);
+hipError_t LaunchNextObjectId(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                              uint32_t after, uint32_t* result_dev, hipStream_t stream);
+hipError_t LaunchCombineFreeAndNamed(const float* free_sdf_dev, const float* named_sdf_dev, int64_t num_cells,
+                                     float* out_dev, uint32_t* minmax_enc, hipStream_t stream);
+
 // --- launchers (voxelizer_kernels.hip) ---
 struct RaycastGridF32
 {
