@@ -94,6 +94,20 @@ int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
                                float grid_x_size, float grid_y_size, float grid_z_size,
                                int32_t num_x_voxels, int32_t num_y_voxels,
                                int32_t num_z_voxels);
+/* PointCloud2 ingestion: the message's data buffer is uploaded as it is and the
+ * kernel reads x, y, z in place -- instead of the per-point virtual
+ * CopyPointLocationIntoFloatPtr gather of S/device_pointcloud_voxelization.cpp:130-136 over
+ * PointCloud2Wrapper (I/pointcloud_voxelization_ros_interface.hpp:68-91).
+ *   cloud_data_host  sensor_msgs/PointCloud2::data, num_points = width * height records
+ *   point_step       bytes per record;  xyz_offset = offset of field "x" (y and z follow, FLOAT32;
+ *                    S/pointcloud_voxelization_ros_interface.cpp:49-78).  Both multiples of 4. */
+int vgt_hip_raycast_pointcloud2_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                    const uint8_t* cloud_data_host, int64_t num_points,
+                                    int64_t point_step, int64_t xyz_offset, float max_range,
+                                    const float* grid_pointcloud_transform, float voxel_size,
+                                    float inverse_voxel_size, float grid_x_size,
+                                    float grid_y_size, float grid_z_size, int32_t num_x_voxels,
+                                    int32_t num_y_voxels, int32_t num_z_voxels);
 /* Same, points already resident on the device (bench / device-resident pipelines). */
 int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
                                    const float* points_xyz_dev, int64_t num_points,

@@ -27,6 +27,20 @@ namespace pointcloud_voxelization
 {
 namespace hip_helpers
 {
+// Extension of the plugin interface implemented by the HIP helper: raycast a
+// buffer of fixed-size records holding x, y, z as consecutive FLOAT32 (a PointCloud2 data
+// buffer) in place.  Callers discover it with dynamic_cast on the helper.
+class StridedRaycastInterface
+{
+public:
+  virtual ~StridedRaycastInterface() {}
+  virtual void RaycastStridedPoints(
+      const uint8_t* data, int64_t num_points, int64_t point_step, int64_t xyz_offset, float max_range,
+      const float* grid_pointcloud_transform, float voxel_size, float inverse_voxel_size, float grid_x_size,
+      float grid_y_size, float grid_z_size, int32_t num_x_voxels, int32_t num_y_voxels, int32_t num_z_voxels,
+      TrackingGridsHandle& tracking_grids, size_t tracking_grid_index) = 0;
+};
+
 std::vector<AvailableDevice> GetAvailableDevices();
 
 std::unique_ptr<DeviceVoxelizationHelperInterface> MakeHipVoxelizationHelper(

@@ -11,6 +11,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -296,10 +297,92 @@ public:
     CopyPointLocationIntoFloatPtrImpl(point_index, destination);
   }
 
+  // Extension: a wrapper whose points sit in one buffer of fixed-size records
+  // with x, y, z as consecutive FLOAT32 reports the layout, and the HIP voxelizer raycasts the
+  // buffer in place instead of gathering point by point.  Default: not available.
+  virtual bool StridedFloat32Layout(const uint8_t** data, int64_t* point_step, int64_t* xyz_offset) const
+  {
+    (void)data;
+    (void)point_step;
+    (void)xyz_offset;
+    return false;
+  }
+
 protected:
   virtual void CopyPointLocationIntoFloatPtrImpl(int64_t point_index, float* destination) const = 0;
 };
 using PointCloudWrapperSharedPtr = std::shared_ptr<PointCloudWrapper>;
+
+// sensor_msgs/PointCloud2, the members the voxelizer reads (ROS is not a dependency here).
+struct PointField
+{
+  enum : uint8_t { INT8 = 1, UINT8 = 2, INT16 = 3, UINT16 = 4, INT32 = 5, UINT32 = 6, FLOAT32 = 7, FLOAT64 = 8 };
+  std::string name;
+  uint32_t offset = 0;
+  uint8_t datatype = 0;
+  uint32_t count = 1;
+};
+struct PointCloud2
+{
+  uint32_t height = 0, width = 0;
+  std::vector<PointField> fields;
+  uint32_t point_step = 0;
+  std::vector<uint8_t> data;
+};
+
+// NonOwningPointCloud2Wrapper (pointcloud_voxelization_ros_interface.hpp:36-119; constructor
+// checks: pointcloud_voxelization_ros_interface.cpp:28-78).
+class NonOwningPointCloud2Wrapper : public PointCloudWrapper
+{
+public:
+  NonOwningPointCloud2Wrapper(const PointCloud2* cloud_ptr, const Isometry3& origin_transform,
+                              double max_range = std::numeric_limits<double>::infinity())
+      : cloud_ptr_(cloud_ptr), origin_transform_(origin_transform), max_range_(max_range)
+  {
+    if (cloud_ptr_ == nullptr) throw std::invalid_argument("cloud_ptr_ == nullptr");
+    if (max_range_ <= 0.0) throw std::runtime_error("max_range_ <= 0.0");
+    const PointField* xyz[3] = {nullptr, nullptr, nullptr};
+    for (const PointField& field : cloud_ptr_->fields)
+    {
+      if (field.name == "x") xyz[0] = &field;
+      if (field.name == "y") xyz[1] = &field;
+      if (field.name == "z") xyz[2] = &field;
+    }
+    const char* names[3] = {"x", "y", "z"};
+    for (int a = 0; a < 3; a++)
+    {
+      if (xyz[a] == nullptr) throw std::out_of_range("map::at");  // field_type_map.at(...) of the reference
+      if (xyz[a]->datatype != PointField::FLOAT32)
+        throw std::invalid_argument(std::string("PointCloud ") + names[a] + " field is not FLOAT32");
+    }
+    if ((xyz[2]->offset - xyz[1]->offset) == sizeof(float) && (xyz[1]->offset - xyz[0]->offset) == sizeof(float))
+      xyz_offset_from_point_start_ = xyz[0]->offset;
+    else
+      throw std::invalid_argument("PointCloud does not have sequential xyz fields");
+  }
+  double MaxRange() const override { return max_range_; }
+  int64_t Size() const override { return static_cast<int64_t>(cloud_ptr_->width) * cloud_ptr_->height; }
+  const Isometry3& PointCloudOriginTransform() const override { return origin_transform_; }
+  bool StridedFloat32Layout(const uint8_t** data, int64_t* point_step, int64_t* xyz_offset) const override
+  {
+    *data = cloud_ptr_->data.data();
+    *point_step = static_cast<int64_t>(cloud_ptr_->point_step);
+    *xyz_offset = static_cast<int64_t>(xyz_offset_from_point_start_);
+    return true;
+  }
+
+private:
+  void CopyPointLocationIntoFloatPtrImpl(int64_t point_index, float* destination) const override
+  {
+    const size_t starting_offset =
+        static_cast<size_t>(point_index) * static_cast<size_t>(cloud_ptr_->point_step) + xyz_offset_from_point_start_;
+    std::memcpy(destination, &(cloud_ptr_->data.at(starting_offset)), sizeof(float) * 3);
+  }
+  const PointCloud2* const cloud_ptr_;
+  size_t xyz_offset_from_point_start_ = 0;
+  Isometry3 origin_transform_;
+  double max_range_;
+};
 
 // VoxelizerRuntime (pointcloud_voxelization_interface.hpp:206-229).
 class VoxelizerRuntime

@@ -208,6 +208,48 @@ static void PointCloudVoxelizationTests(int dispatch_threads)
         [&](const VoxelizerRuntime& rt) { raycast_s = rt.RaycastingTime(); });
     check_voxelization(voxelized);
     EXPECT_TRUE(raycast_s >= 0.0);
+    {
+      // the same clouds as PointCloud2 messages (32-byte records: intensity, x, y, z, ring, pad)
+      // are raycast in place and must give the identical grid.
+      const auto to_cloud2 = [](const VectorPointCloudWrapper& src, PointCloud2& msg) {
+        msg.height = 1;
+        msg.width = static_cast<uint32_t>(src.Size());
+        msg.point_step = 32;
+        msg.fields = {PointField{"intensity", 0, PointField::FLOAT32, 1}, PointField{"x", 4, PointField::FLOAT32, 1},
+                      PointField{"y", 8, PointField::FLOAT32, 1}, PointField{"z", 12, PointField::FLOAT32, 1},
+                      PointField{"ring", 16, PointField::UINT16, 1}};
+        msg.data.assign(static_cast<size_t>(msg.width) * msg.point_step, 0xAB);
+        for (int64_t i = 0; i < src.Size(); i++)
+          src.CopyPointLocationIntoFloatPtr(i, reinterpret_cast<float*>(msg.data.data() + i * 32 + 4));
+      };
+      PointCloud2 msg1, msg2, msg3;
+      to_cloud2(*cam1, msg1);
+      to_cloud2(*cam2, msg2);
+      to_cloud2(*cam3, msg3);
+      auto w1 = std::make_shared<NonOwningPointCloud2Wrapper>(&msg1, cam1->PointCloudOriginTransform());
+      auto w2 = std::make_shared<NonOwningPointCloud2Wrapper>(&msg2, cam2->PointCloudOriginTransform());
+      auto w3 = std::make_shared<NonOwningPointCloud2Wrapper>(&msg3, cam3->PointCloudOriginTransform());
+      const OccupancyMap from_msgs = voxelizer.VoxelizePointClouds(static_environment, filter_options, {w1, w2, w3});
+      check_voxelization(from_msgs);
+      EXPECT_TRUE(from_msgs.GetImmutableRawData() == voxelized.GetImmutableRawData());
+      // constructor checks of pointcloud_voxelization_ros_interface.cpp:28-78
+      bool rejected = false;
+      PointCloud2 bad = msg1;
+      bad.fields[2].offset = 20;  // y no longer follows x
+      try { NonOwningPointCloud2Wrapper w(&bad, Isometry3::Identity()); }
+      catch (const std::invalid_argument&) { rejected = true; }
+      EXPECT_TRUE(rejected);
+      rejected = false;
+      bad = msg1;
+      bad.fields[3].datatype = PointField::FLOAT64;
+      try { NonOwningPointCloud2Wrapper w(&bad, Isometry3::Identity()); }
+      catch (const std::invalid_argument&) { rejected = true; }
+      EXPECT_TRUE(rejected);
+      rejected = false;
+      try { NonOwningPointCloud2Wrapper w(nullptr, Isometry3::Identity()); }
+      catch (const std::invalid_argument&) { rejected = true; }
+      EXPECT_TRUE(rejected);
+    }
     // argument validation of the public entry point (pointcloud_voxelization_interface.hpp:267-289)
     bool threw = false;
     try { voxelizer.VoxelizePointClouds(static_environment, filter_options, {nullptr}); }

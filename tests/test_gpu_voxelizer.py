@@ -223,3 +223,29 @@ def test_device_resident_voxelize_then_sdf(ctx, oracle, add_virtual_border):
     assert np.array_equal(got.view(np.uint32), want_sdf.view(np.uint32))
     mm = minmax.cpu().numpy()
     assert (float(mm[0]), float(mm[1])) == (wlo, whi)
+
+
+@pytest.mark.parametrize("layout", [(16, 0), (32, 4), (20, 8), (12, 0)], ids=["xyzi", "padded", "tail", "packed"])
+def test_pointcloud2_ingestion(ctx, oracle, layout):
+    """a PointCloud2 data buffer (point_step bytes per record, x/y/z FLOAT32 at an offset, other
+    fields around them) raycast in place gives exactly the counts of the packed xyz path."""
+    point_step, xyz_offset = layout
+    counts = (64, 64, 64)
+    vs = np.float32(0.05)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(50_000, seed=3) * np.float32(0.5)
+    xf = synthetic.translation_xform(1.6, 1.5, 1.4).astype(np.float32)
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, size=(len(pts), point_step), dtype=np.uint8)    # junk in the other fields
+    data[:, xyz_offset:xyz_offset + 12] = pts.view(np.uint8).reshape(len(pts), 12)
+    grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+    grids.raycast_pointcloud2(0, data, len(pts), point_step, xyz_offset, 2.0, xf, vs, ivs, sizes, counts)
+    want = oracle.raycast_f32(pts, 2.0, xf, vs, ivs, sizes, counts)
+    assert want.sum() > 0
+    assert np.array_equal(grids.retrieve(0, counts), want)
+    with pytest.raises(ValueError):
+        grids.raycast_pointcloud2(0, data, len(pts), point_step, point_step - 8, 2.0, xf, vs, ivs, sizes, counts)
+    if point_step % 4 == 0:
+        with pytest.raises(ValueError):
+            grids.raycast_pointcloud2(0, data, len(pts), point_step, 2, 2.0, xf, vs, ivs, sizes, counts)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "vgt_hip_tracking_grids_clear": (_int, [_p, _p]),
     "vgt_hip_raycast_points_f32": (_int, [_p, _p, _sz, _p, _i64, _f32, _p, _f32, _f32, _f32, _f32,
                                           _f32, _i32, _i32, _i32]),
+    "vgt_hip_raycast_pointcloud2_f32": (_int, [_p, _p, _sz, _p, _i64, _i64, _i64, _f32, _p, _f32, _f32, _f32,
+                                               _f32, _f32, _i32, _i32, _i32]),
     "vgt_hip_raycast_points_f32_dev": (_int, [_p, _p, _sz, _p, _i64, _f32, _p, _f32, _f32, _f32,
                                               _f32, _f32, _i32, _i32, _i32]),
     "vgt_hip_raycast_points_f64": (_int, [_p, _p, _sz, _p, _i64, _f64, _p, _f64, _f64, _f64, _f64,
@@ -298,6 +300,20 @@ class TrackingGrids:
             self.ctx.handle, self.handle, index, _ptr(pts) if pts.size else None, pts.size // 3,
             float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
             float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
+            int(counts[0]), int(counts[1]), int(counts[2])))
+
+    def raycast_pointcloud2(self, index, data, num_points, point_step, xyz_offset, max_range, xform, voxel_size,
+                            inverse_voxel_size, grid_sizes, counts):
+        """sensor_msgs/PointCloud2 data buffer (bytes) with x, y, z FLOAT32 at xyz_offset of every record."""
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray)
+                                   else data.view(np.uint8).reshape(-1))
+        if buf.size < int(num_points) * int(point_step):
+            raise ValueError("data buffer shorter than num_points * point_step")
+        T = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+        check(self._lib.vgt_hip_raycast_pointcloud2_f32(
+            self.ctx.handle, self.handle, index, _ptr(buf) if buf.size else None, int(num_points),
+            int(point_step), int(xyz_offset), float(max_range), _ptr(T), float(voxel_size),
+            float(inverse_voxel_size), float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
             int(counts[0]), int(counts[1]), int(counts[2])))
 
     def raycast_f32_dev(self, index, points_ptr, num_points, max_range, xform, voxel_size,

@@ -98,6 +98,19 @@ VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
     if (cloud->Size() <= 0) return;  // empty arrays never reach the device interface
     const std::array<float, 16> X_GC = (X_GW * cloud->PointCloudOriginTransform()).CastFloat();
     const float max_range = static_cast<float>(cloud->MaxRange());
+    // a cloud that exposes a strided FLOAT32 layout (PointCloud2) is raycast in place
+    const uint8_t* strided_data = nullptr;
+    int64_t point_step = 0, xyz_offset = 0;
+    hip_helpers::StridedRaycastInterface* strided =
+        dynamic_cast<hip_helpers::StridedRaycastInterface*>(helper_interface_.get());
+    if (strided != nullptr && cloud->StridedFloat32Layout(&strided_data, &point_step, &xyz_offset) &&
+        point_step % 4 == 0 && xyz_offset % 4 == 0)
+    {
+      strided->RaycastStridedPoints(strided_data, cloud->Size(), point_step, xyz_offset, max_range, X_GC.data(),
+                                    voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size,
+                                    num_x_voxels, num_y_voxels, num_z_voxels, *tracking_grids, cloud_index);
+      return;
+    }
     std::vector<float> raw_points(static_cast<size_t>(cloud->Size()) * 3, 0.0f);
     for (int64_t point = 0; point < cloud->Size(); point++)
       cloud->CopyPointLocationIntoFloatPtr(point, raw_points.data() + point * 3);

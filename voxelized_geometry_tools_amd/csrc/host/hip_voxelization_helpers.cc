@@ -67,7 +67,7 @@ private:
   vgt_hip_filter* filter_;
 };
 
-class HipVoxelizationHelper : public DeviceVoxelizationHelperInterface
+class HipVoxelizationHelper : public DeviceVoxelizationHelperInterface, public StridedRaycastInterface
 {
 public:
   HipVoxelizationHelper(const std::map<std::string, int32_t>& options,
@@ -127,6 +127,21 @@ public:
         static_cast<int64_t>(raw_points.size() / 3), max_range, grid_pointcloud_transform,
         voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size, num_x_voxels,
         num_y_voxels, num_z_voxels));
+  }
+
+  void RaycastStridedPoints(
+      const uint8_t* data, const int64_t num_points, const int64_t point_step, const int64_t xyz_offset,
+      const float max_range, const float* const grid_pointcloud_transform, const float voxel_size,
+      const float inverse_voxel_size, const float grid_x_size, const float grid_y_size,
+      const float grid_z_size, const int32_t num_x_voxels, const int32_t num_y_voxels,
+      const int32_t num_z_voxels, TrackingGridsHandle& tracking_grids,
+      const size_t tracking_grid_index) override
+  {
+    HipTrackingGridsHandle& real = dynamic_cast<HipTrackingGridsHandle&>(tracking_grids);
+    Check(vgt_hip_raycast_pointcloud2_f32(
+        ctx_, real.Get(), tracking_grid_index, data, num_points, point_step, xyz_offset, max_range,
+        grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size,
+        num_x_voxels, num_y_voxels, num_z_voxels));
   }
 
   std::unique_ptr<FilterGridHandle> PrepareFilterGrid(

@@ -474,7 +474,7 @@ int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   std::lock_guard<std::mutex> lock(ctx->mutex);
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, g, tracking,
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, 3, g, tracking,
                                     ctx->threads_per_block, ctx->stream),
               "Failed to dispatch raycast kernel");
   return VGT_HIP_OK;
@@ -513,10 +513,55 @@ int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
   VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, points_xyz_host, bytes, hipMemcpyHostToDevice,
                              ctx->stream),
               "Failed to copy points to the device");
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(static_cast<const float*>(ctx->stage), num_points, g, tracking,
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(static_cast<const float*>(ctx->stage), num_points, 3, g, tracking,
                                     ctx->threads_per_block, ctx->stream),
               "Failed to dispatch raycast kernel");
   // The host buffer may be released by the caller as soon as we return.
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_raycast_pointcloud2_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                    const uint8_t* cloud_data_host, int64_t num_points, int64_t point_step,
+                                    int64_t xyz_offset, float max_range,
+                                    const float* grid_pointcloud_transform, float voxel_size,
+                                    float inverse_voxel_size, float grid_x_size, float grid_y_size,
+                                    float grid_z_size, int32_t num_x_voxels, int32_t num_y_voxels,
+                                    int32_t num_z_voxels)
+{
+  const int rc = CheckRaycastArgs(ctx, grids, grid_index, cloud_data_host, num_points,
+                                  grid_pointcloud_transform, num_x_voxels, num_y_voxels, num_z_voxels);
+  if (rc != VGT_HIP_OK) return rc;
+  // x, y, z are three consecutive FLOAT32 fields (pointcloud_voxelization_ros_interface.cpp:49-78);
+  // the kernel reads them in place, which needs them 4-byte aligned inside the buffer
+  if (xyz_offset < 0 || point_step < xyz_offset + 12)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "PointCloud does not have sequential xyz fields");
+  if (point_step % 4 != 0 || xyz_offset % 4 != 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "point_step and the xyz offset must be multiples of 4");
+  if (num_points == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::RaycastGridF32 g;
+  g.max_range = max_range;
+  std::memcpy(g.xform, grid_pointcloud_transform, sizeof(g.xform));
+  g.voxel_size = voxel_size;
+  g.inverse_voxel_size = inverse_voxel_size;
+  g.grid_size[0] = grid_x_size;
+  g.grid_size[1] = grid_y_size;
+  g.grid_size[2] = grid_z_size;
+  g.counts[0] = num_x_voxels;
+  g.counts[1] = num_y_voxels;
+  g.counts[2] = num_z_voxels;
+  int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
+  const size_t bytes = static_cast<size_t>(num_points) * static_cast<size_t>(point_step);
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const int src = EnsureStage(ctx, bytes);
+  if (src != VGT_HIP_OK) return src;
+  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, cloud_data_host, bytes, hipMemcpyHostToDevice, ctx->stream),
+              "Failed to copy points to the device");
+  const float* first = reinterpret_cast<const float*>(static_cast<const uint8_t*>(ctx->stage) + xyz_offset);
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(first, num_points, point_step / 4, g, tracking, ctx->threads_per_block,
+                                    ctx->stream),
+              "Failed to dispatch raycast kernel");
   VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
   return VGT_HIP_OK;
 }

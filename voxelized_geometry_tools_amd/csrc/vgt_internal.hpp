@@ -102,8 +102,10 @@ struct RaycastGridF64
   double grid_size[3];
   int32_t counts[3];
 };
-hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, const RaycastGridF32& g,
-                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream);
+// point_stride = floats between consecutive points (3 for packed xyz; PointCloud2: point_step / 4)
+hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t point_stride,
+                            const RaycastGridF32& g, int32_t* tracking_dev, int threads_per_block,
+                            hipStream_t stream);
 hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
                             int32_t* tracking_dev, int threads_per_block, hipStream_t stream);
 hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,

@@ -88,15 +88,16 @@ __device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracki
 // the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
 template <typename Real>
 __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_points,
+                              int64_t point_stride,  // elements between consecutive points (3 = packed xyz)
                               const typename RaycastTraits<Real>::Grid g,
                               int32_t* __restrict__ tracking)
 {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= num_points) return;
 
-  const Real px = points[3 * i + 0];
-  const Real py = points[3 * i + 1];
-  const Real pz = points[3 * i + 2];
+  const Real px = points[point_stride * i + 0];
+  const Real py = points[point_stride * i + 1];
+  const Real pz = points[point_stride * i + 2];
   if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) return;
 
   const Real* T = g.xform;
@@ -242,13 +243,15 @@ __global__ void FilterKernel(const int32_t* __restrict__ tracking, int64_t num_c
 }
 }  // namespace
 
-hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, const RaycastGridF32& g,
-                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream)
+hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t point_stride,
+                            const RaycastGridF32& g, int32_t* tracking_dev, int threads_per_block,
+                            hipStream_t stream)
 {
   if (num_points <= 0) return hipSuccess;
   const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
   hipLaunchKernelGGL(RaycastKernel<float>, dim3(static_cast<unsigned>(blocks)),
-                     dim3(threads_per_block), 0, stream, points_dev, num_points, g, tracking_dev);
+                     dim3(threads_per_block), 0, stream, points_dev, num_points, point_stride, g,
+                     tracking_dev);
   return hipGetLastError();
 }
 
@@ -258,7 +261,8 @@ hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const 
   if (num_points <= 0) return hipSuccess;
   const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
   hipLaunchKernelGGL(RaycastKernel<double>, dim3(static_cast<unsigned>(blocks)),
-                     dim3(threads_per_block), 0, stream, points_dev, num_points, g, tracking_dev);
+                     dim3(threads_per_block), 0, stream, points_dev, num_points, int64_t{3}, g,
+                     tracking_dev);
   return hipGetLastError();
 }
 
