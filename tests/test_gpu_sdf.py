@@ -250,3 +250,35 @@ def test_two_giga_voxel_slab_is_indexed_with_64_bits(ctx):
     assert worst == 0
     mm = minmax.cpu().numpy()
     assert mm[0] == -np.float32(res) and mm[1] == np.float32(hi)
+
+
+@pytest.mark.parametrize("shape", [(5, 6, 1024), (4, 3, 516), (3, 4, 260), (2, 2, 2048), (2, 3, 768), (3, 2, 1028),
+                                   (6, 5, 4), (2, 2, 252), (3, 3, 1023), (2, 2, 2044)])
+def test_z_scan_chunkings(ctx, oracle, shape):
+    """Every chunk count of the four-voxels-per-lane Z scan (nz % 4 == 0: 1, 2, 4, 8 chunks of 256 voxels, full and
+    ragged last chunk) and the one-voxel-per-lane kernels it falls back to, for occupancy and mask inputs, with
+    long runs, isolated voxels and empty / full lines."""
+    rng = np.random.default_rng(sum(shape) * 7 + shape[2])
+    nx, ny, nz = shape
+    occ = np.zeros(shape, dtype=np.float32)
+    for x in range(nx):
+        for y in range(ny):
+            kind = (x * ny + y) % 5
+            if kind == 0:
+                occ[x, y] = (rng.random(nz) < 0.01)
+            elif kind == 1:
+                occ[x, y] = (rng.random(nz) < 0.6)
+            elif kind == 2:
+                a, b = sorted(rng.integers(0, nz, size=2))
+                occ[x, y, a:b + 1] = 1.0                       # one long run
+            elif kind == 3:
+                occ[x, y, :] = 1.0 if (x + y) % 2 else 0.0     # full / empty line
+            else:
+                occ[x, y, rng.integers(0, nz)] = 1.0           # a single voxel
+                occ[x, y, nz - 1] = 1.0
+    want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.03)
+    got, lo, hi = ctx.sdf_from_occupancy(occ, 0.03)
+    assert bits_equal(got, want), shape
+    assert (lo, hi) == (wlo, whi)
+    got, _, _ = ctx.sdf_from_mask((occ > 0.5).astype(np.uint8), 0.03)
+    assert bits_equal(got, want), shape
