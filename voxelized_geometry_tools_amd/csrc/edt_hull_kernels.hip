@@ -83,6 +83,7 @@ struct Tile
   uint16_t* cumT;      // [nwords][W] start bits in lower words
   int16_t* seed_lo;    // [nwords][W] seed row entering the band from below (-1 none); aliases cumA
   int16_t* seed_hi;    //             ... from above; aliases cumT (both dead before 2c writes cumA/cumT)
+  int16_t* first_start;  // [nwords][W] start row of the band's first member (-1 none); aliases cumA (2b only)
   uint8_t* min_first;  // [nwords][W] offset of the smallest member of the band's first run portion
   uint8_t* min_last;   //             ... of its last run portion (255 = none)
   uint64_t* sumA;      // [W] words of A that may be non-empty (superset)
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   t.cumT = t.cumA + mw;
   t.seed_lo = reinterpret_cast<int16_t*>(t.cumA);
   t.seed_hi = reinterpret_cast<int16_t*>(t.cumT);
+  t.first_start = reinterpret_cast<int16_t*>(t.cumA);
   t.min_first = reinterpret_cast<uint8_t*>(t.cumT + mw);
   t.min_last = t.min_first + mw;
   t.n = n;
@@ -718,56 +720,100 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 
   // ---- 2b. first owned row of every hull member; drop members that own no row ----
-  if (band < nwords)
+  // A member owns [its start, the start of the next member of its run) clipped to the run.  Every
+  // thread computes the start of each of its members once (the predecessor of the band's first
+  // member is found in the bands below), publishes the start of the band's first member, and
+  // after a barrier closes its last member with the published start of the next member above.
   {
     uint32_t a2 = 0;
-    if (z < g.nz)
-    {
-      uint32_t bits = t.A[band * W + t.w];
-      int run_a = 0, run_b = -1;        // current run [run_a, run_b]
-      int nxt = -1, start_nxt = 0;      // cached successor of the previous member + its start
-      int32_t Gnxt = 0;
-      while (bits)
+    int pend_row = -1, pend_start = 0, pend_run_b = -1;  // last member, if its run continues above
+    auto owns = [&](int member, int start, int end) {
+      if (start < end)
       {
-        const int h = r0 + __ffs(static_cast<int>(bits)) - 1;
-        bits &= bits - 1u;
-        int32_t Gh;
-        int start_h;
-        if (h > run_b)
+        a2 |= 1u << (member - r0);
+        atomicOr(&t.T[(start >> 5) * W + t.w], 1u << (start & 31));
+        VGT_STAT_ADD(10, 1);
+      }
+    };
+    if (band < nwords)
+    {
+      int first_start = -1;
+      if (z < g.nz)
+      {
+        uint32_t bits = t.A[band * W + t.w];
+        int run_a = 0, run_b = -1;  // current run [run_a, run_b]
+        int prev = -1, prev_start = 0;
+        int32_t Gprev = 0;
+        bool first = true;
+        while (bits)
         {
-          const bool neg = (sbits >> (h - r0)) & 1u;
-          run_a = t.PrevOpp(h, neg) + 1;
-          run_b = t.NextOpp(h, neg) - 1;
-          nxt = -1;
+          const int h = r0 + __ffs(static_cast<int>(bits)) - 1;
+          bits &= bits - 1u;
+          const int32_t Gh = t.Mag(h) + Sq(h);
+          int start_h;
+          if (h > run_b)
+          {
+            // new run: the previous member was the last of its run
+            if (prev >= 0) owns(prev, prev_start, run_b + 1);
+            const bool neg = (sbits >> (h - r0)) & 1u;
+            run_a = t.PrevOpp(h, neg) + 1;
+            run_b = t.NextOpp(h, neg) - 1;
+            start_h = run_a;
+            if (run_a < r0)
+            {
+              const int p = t.PrevBit(t.A, t.sumA, r0, run_a);  // nearest member of the run below the band
+              if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + Sq(p), p, Gh, h));
+            }
+          }
+          else
+          {
+            start_h = max(run_a, FirstOwnedRow(Gprev, prev, Gh, h));
+            owns(prev, prev_start, min(run_b + 1, start_h));
+          }
+          if (first) first_start = min(start_h, n);
+          first = false;
+          prev = h;
+          prev_start = start_h;
+          Gprev = Gh;
         }
-        if (nxt == h)
+        if (prev >= 0)
         {
-          Gh = Gnxt;
-          start_h = start_nxt;
-        }
-        else
-        {
-          Gh = t.Mag(h) + Sq(h);
-          const int p = t.PrevBit(t.A, t.sumA, h, run_a);
-          start_h = run_a;
-          if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + Sq(p), p, Gh, h));
-        }
-        nxt = t.NextBit(t.A, t.sumA, h, run_b + 1);
-        start_nxt = run_b + 1;
-        if (nxt >= 0)
-        {
-          Gnxt = t.Mag(nxt) + Sq(nxt);
-          start_nxt = min(run_b + 1, max(run_a, FirstOwnedRow(Gh, h, Gnxt, nxt)));
-        }
-        if (start_h < start_nxt)
-        {
-          a2 |= 1u << (h - r0);
-          atomicOr(&t.T[(start_h >> 5) * W + t.w], 1u << (start_h & 31));
-          VGT_STAT_ADD(10, 1);
+          if (run_b >= r1)
+          {
+            pend_row = prev;
+            pend_start = prev_start;
+            pend_run_b = run_b;
+          }
+          else
+            owns(prev, prev_start, run_b + 1);
         }
       }
+      t.first_start[band * W + t.w] = static_cast<int16_t>(first_start);
     }
-    t.A2[band * W + t.w] = a2;
+    __syncthreads();
+    if (band < nwords)
+    {
+      if (pend_row >= 0)
+      {
+        int end = pend_run_b + 1;
+        // first member above this band (sumA may list words that have become empty)
+        uint64_t cand = (band < 63) ? (t.sumA[t.w] & ~((2ull << band) - 1ull)) : 0ull;
+        while (cand)
+        {
+          const int jj = __ffsll(static_cast<long long>(cand)) - 1;
+          const uint32_t m = t.A[jj * W + t.w];
+          if (m)
+          {
+            const int row = (jj << 5) + __ffs(static_cast<int>(m)) - 1;
+            if (row <= pend_run_b) end = min(end, static_cast<int>(t.first_start[jj * W + t.w]));
+            break;
+          }
+          cand &= cand - 1ull;
+        }
+        owns(pend_row, pend_start, end);
+      }
+      t.A2[band * W + t.w] = a2;
+    }
   }
   __syncthreads();
 
