@@ -861,6 +861,9 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     // owner of r0: the k-th survivor of the line, k = number of start bits at or below r0
     int cur = -1;
     int32_t fcur = 0;
+    // iterator over the line's owners (bits of A2): word index and the bits of that word above cur
+    int owner_word = -1;
+    uint32_t owner_rest = 0;
     {
       int k = t.cumT[band * W + t.w] + static_cast<int>(tw & 1u);
       if (k > 0)
@@ -890,6 +893,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         }
         cur = (lo << 5) + pos;
         fcur = t.Mag(cur);
+        owner_word = lo;
+        owner_rest = t.A2[lo * W + t.w] & ~LowMask(pos + 1);
       }
     }
     bool neg = false;
@@ -899,7 +904,16 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     {
       if (r > r0 && ((tw >> (r - r0)) & 1u))
       {
-        cur = t.NextBit(t.A2, t.sumA2, cur, n);
+        // every start bit has its owner: the next bit of A2 (sumA2 lists the non-empty words exactly)
+        if (owner_rest == 0u)
+        {
+          uint64_t above = t.sumA2[t.w];
+          if (owner_word >= 0) above &= ~((2ull << owner_word) - 1ull);
+          owner_word = __ffsll(static_cast<long long>(above)) - 1;
+          owner_rest = t.A2[owner_word * W + t.w];
+        }
+        cur = (owner_word << 5) + __ffs(static_cast<int>(owner_rest)) - 1;
+        owner_rest &= owner_rest - 1u;
         fcur = t.Mag(cur);
       }
       const bool sneg = (sbits >> (r - r0)) & 1u;
