@@ -674,15 +674,50 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int lo = t.PrevOpp(R, neg) + 1;
         const int hi = t.NextOpp(R - 1, neg);
-        int i = t.PrevBit(t.A, t.sumA, R, lo);
-        int j = t.NextBit(t.A, t.sumA, R - 1, hi);
+        // walkers over the members below / above the junction: the current mask word is held in
+        // a register (its bits already passed are cleared), the next non-empty word comes from
+        // the per-line summary.  A word copy may miss kills made by other junctions meanwhile;
+        // a killed member is still a real site, so a removal it justifies stays valid, and the
+        // last round (no kills anywhere) sees stable words.
+        int down_word = band - 1, up_word = band;
+        uint32_t down_rest = t.A[down_word * W + t.w], up_rest = t.A[up_word * W + t.w];
+        auto prev_member = [&]() -> int {
+          while (down_rest == 0u)
+          {
+            const uint64_t below = t.sumA[t.w] & ((1ull << down_word) - 1ull);
+            if (below == 0ull) return -1;
+            down_word = 63 - __clzll(static_cast<long long>(below));
+            if (((down_word << 5) + 31) < lo) return -1;
+            down_rest = t.A[down_word * W + t.w];
+          }
+          const int bit = 31 - __clz(static_cast<int>(down_rest));
+          down_rest &= ~(1u << bit);
+          const int row = (down_word << 5) + bit;
+          return row >= lo ? row : -1;
+        };
+        auto next_member = [&]() -> int {
+          while (up_rest == 0u)
+          {
+            const uint64_t above = (up_word < 63) ? (t.sumA[t.w] & ~((2ull << up_word) - 1ull)) : 0ull;
+            if (above == 0ull) return -1;
+            up_word = __ffsll(static_cast<long long>(above)) - 1;
+            if ((up_word << 5) >= hi) return -1;
+            up_rest = t.A[up_word * W + t.w];
+          }
+          const int bit = __ffs(static_cast<int>(up_rest)) - 1;
+          up_rest &= up_rest - 1u;
+          const int row = (up_word << 5) + bit;
+          return row < hi ? row : -1;
+        };
+        int i = prev_member();
+        int j = next_member();
         if (i >= 0 && j >= 0)
         {
           int32_t Gi = t.Mag(i) + Sq(i);
           int32_t Gj = t.Mag(j) + Sq(j);
-          int a = t.PrevBit(t.A, t.sumA, i, lo);
+          int a = prev_member();
           int32_t Ga = (a >= 0) ? t.Mag(a) + Sq(a) : 0;
-          int c = t.NextBit(t.A, t.sumA, j, hi);
+          int c = next_member();
           int32_t Gc = (c >= 0) ? t.Mag(c) + Sq(c) : 0;
           for (;;)
           {
@@ -693,7 +728,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
               changed = 1;
               i = a;
               Gi = Ga;
-              a = t.PrevBit(t.A, t.sumA, i, lo);
+              a = prev_member();
               Ga = (a >= 0) ? t.Mag(a) + Sq(a) : 0;
               continue;
             }
@@ -704,7 +739,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
               changed = 1;
               j = c;
               Gj = Gc;
-              c = t.NextBit(t.A, t.sumA, j, hi);
+              c = next_member();
               Gc = (c >= 0) ? t.Mag(c) + Sq(c) : 0;
               continue;
             }
@@ -919,9 +954,14 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       const bool sneg = (sbits >> (r - r0)) & 1u;
       if (r == r0 || sneg != neg)
       {
+        // bounding rows of the other class: inside the band from the sign word in registers,
+        // outside it from the per-word carries of phase 1b
         neg = sneg;
-        prev_opp = (r == r0) ? t.PrevOpp(r, neg) : r - 1;
-        next_opp = t.NextOpp(r, neg);
+        const int wi = band * W + t.w;
+        prev_opp = (r == r0) ? static_cast<int>(neg ? t.last_pos[wi] : t.last_neg[wi]) : r - 1;
+        const uint32_t other_above = (neg ? ~sbits : sbits) & LowMask(r1 - r0) & ~LowMask(r - r0 + 1);
+        next_opp = other_above ? r0 + __ffs(static_cast<int>(other_above)) - 1
+                               : static_cast<int>(neg ? t.next_pos[wi] : t.next_neg[wi]);
         run_a = prev_opp + 1;
       }
       int32_t best = kInf32;
