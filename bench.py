@@ -36,6 +36,9 @@ def parse_args():
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
     ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2, 3 cross-check implementations)")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
+                         "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -132,13 +135,18 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_slab
     if dist_on:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
     res = 0.01
-    if world == 1:
+    if not dist_on:
         edge = args.size or 1024
         full_shape = (edge, edge, edge)
         local_shape = full_shape
@@ -161,14 +169,14 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_edt_variant(args.variant)
-    if world > 1:
+    if dist_on:
         runner = multi_gpu.SlabSdf(ctx, torch, dist, full_shape, rank, world, device)
 
     kernel_ms = np.zeros(3, dtype=np.float32)
     kernel_sum = np.zeros(3, dtype=np.float64)
 
     def step(timed):
-        if world == 1:
+        if not dist_on:
             ctx.sdf_dev(occ.data_ptr(), local_shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes,
                         minmax.data_ptr(), kernel_ms=kernel_ms if timed else None)
         else:
@@ -206,7 +214,7 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = profiled_traffic(
-            KERNEL_NAMES[dom], world == 1 and not args.size and args.dist == "spheres" and args.variant == 0)
+            KERNEL_NAMES[dom], not dist_on and not args.size and args.dist == "spheres" and args.variant == 0)
         line = {
             "metric": "Mvoxels/s for 1024^3 float SDF extract @1 GPU; % HBM roofline",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
@@ -223,7 +231,7 @@ def main():
                          "whole_sdf_frac": round(whole / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes_per_voxel": {"per_pass": 8, "whole_sdf": 24}},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dist_on:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
