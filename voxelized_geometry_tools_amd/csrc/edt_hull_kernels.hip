@@ -1012,15 +1012,18 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 }
 
-// Lines per tile for n rows.  32 lines (128-byte int32 rows) while two workgroups still fit in
-// one CU's LDS (tile <= 64 KiB); otherwise 16 lines: half the row width but twice the resident
-// workgroups up to n = 1024 (measured 15 % faster than 32 x 1024 with one workgroup per CU).  A
-// line may have at most 64 mask words (one wave-wide scan), i.e. n <= 2048.
+// Lines per tile for n rows: the widest tile that still lets two workgroups share a CU's LDS
+// (tile <= 64 KiB).  32 lines (128-byte int32 rows) up to n = 512, 16 lines up to 1024
+// (measured 15 % faster than 32 x 1024 with one workgroup per CU), 8 lines up to 2048 (8-10 %
+// faster than 16 x 2048 on the slabs of BASELINE config 5; the XCD-aware tile order lets the L2
+// merge the short row segments of neighbouring tiles).  A line may have at most 64 mask words
+// (one wave-wide scan), i.e. n <= 2048.
 int LinesPerTile(int64_t n)
 {
   const int64_t rows = (n + kBandRows - 1) / kBandRows * kBandRows;
   if (rows * 32 <= 16384) return 32;
-  if (rows * 16 <= 32768) return 16;
+  if (rows * 16 <= 16384) return 16;
+  if (rows * 8 <= 16384) return 8;
   return 0;
 }
 
@@ -1059,7 +1062,8 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
   int W = LinesPerTile(g.n);
   if (force_w == 32 && g.n <= 1024) W = 32;  // experiment knob: full-width tiles
-  if (force_w == 8 && g.n <= 1024) W = 8;    // experiment knob: quarter-width tiles
+  if (force_w == 8 && g.n <= 2048) W = 8;    // experiment knob: quarter-width tiles
+  if (force_w == 16 && g.n <= 2048) W = 16;  // experiment knob: half-width tiles
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
@@ -1075,8 +1079,10 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
   if (W == 32)
     return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
-  if (W == 8)
+  if (W == 8 && nwords <= 32)
     return LaunchHull<InT, OutT, kFinal, 8, 32>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 8)
+    return LaunchHull<InT, OutT, kFinal, 8, 64>(in, out, minmax_enc, g, outer_count, stream);
   if (nwords <= 32)
     return LaunchHull<InT, OutT, kFinal, 16, 32>(in, out, minmax_enc, g, outer_count, stream);
   return LaunchHull<InT, OutT, kFinal, 16, 64>(in, out, minmax_enc, g, outer_count, stream);
