@@ -1012,18 +1012,20 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 }
 
-// Lines per tile for n rows: the widest tile that still lets two workgroups share a CU's LDS
-// (tile <= 64 KiB).  32 lines (128-byte int32 rows) up to n = 512, 16 lines up to 1024
-// (measured 15 % faster than 32 x 1024 with one workgroup per CU), 8 lines up to 2048 (8-10 %
-// faster than 16 x 2048 on the slabs of BASELINE config 5; the XCD-aware tile order lets the L2
-// merge the short row segments of neighbouring tiles).  A line may have at most 64 mask words
-// (one wave-wide scan), i.e. n <= 2048.
+// Lines per tile for n rows.  The kernel needs ~120 VGPRs, so a CU holds at most 16 of its waves;
+// what matters beyond that is how many workgroups share the CU (they are in different phases,
+// which keeps the VALUs busy across barriers and load / store phases) without starving the row
+// segments.  Measured (ms per SDF, D1): n = 512: 32 lines 2.08, 16 lines 2.19, 8 lines 2.16;
+// n = 768: 8.97 / 9.52 / 6.88; n = 1024: 21.6 / 16.4 / 15.7; n = 2048 slabs: - / 8.26 / 7.70.
+// So: 32 lines (tile <= 64 KiB, two workgroups per CU) up to n = 512, 8 lines above (four or
+// more workgroups per CU up to n = 1024, two at 2048; the XCD-aware tile order lets the L2 merge
+// the short row segments of neighbouring tiles).  A line may have at most 64 mask words (one
+// wave-wide scan), i.e. n <= 2048.
 int LinesPerTile(int64_t n)
 {
   const int64_t rows = (n + kBandRows - 1) / kBandRows * kBandRows;
-  if (rows * 32 <= 16384) return 32;
-  if (rows * 16 <= 16384) return 16;
-  if (rows * 8 <= 16384) return 8;
+  if (rows <= 512) return 32;
+  if (rows <= 2048) return 8;
   return 0;
 }
 
