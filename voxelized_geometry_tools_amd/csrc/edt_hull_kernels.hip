@@ -286,11 +286,24 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   uint32_t finite = 0;
   if (band < nwords)
   {
+    // (lines beyond nz hold +kInf32 in the tile, so only rows past the end need a guard; a full
+    // band reads its 32 rows at constant offsets from one address)
+    int32_t raw[kBandRows];
+    const int32_t* column = t.F + r0 * W + t.w;
+    if (r0 + kBandRows <= n)
+    {
+#pragma unroll
+      for (int k = 0; k < kBandRows; k++) raw[k] = column[k * W];
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < kBandRows; k++) raw[k] = (r0 + k < n) ? column[k * W] : kInf32;
+    }
 #pragma unroll
     for (int k = 0; k < kBandRows; k++)
     {
-      int32_t v = kInf32;
-      if (z < g.nz && r0 + k < n) v = t.Raw(r0 + k);
+      const int32_t v = raw[k];
       if (v < 0) sbits |= 1u << k;
       fr[k] = v < 0 ? -v : v;
       if (fr[k] != kInf32) finite |= 1u << k;
