@@ -240,6 +240,23 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
                                              int add_virtual_border, float* sdf_host,
                                              float* out_min, float* out_max);
 
+/* ---- SDF consumers ----
+ * SignedDistanceField<float>::GetGridAlignedIndexCoarseGradient
+ * (I/signed_distance_field.hpp:923-1016) for every voxel of a field at once: gradient[3 * i + a]
+ * (double), i = x*ny*nz + y*nz + z.  Voxels on a face of the grid get one-sided differences when
+ * enable_edge_gradients is set, otherwise NaN and has_value[i] = 0 (has_value may be NULL).
+ * rotation (NULL or 9 doubles, row-major) = the rotation of OriginTransform(): with it the
+ * result is GetIndexCoarseGradient's (:906-921). */
+int vgt_hip_sdf_coarse_gradient(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny,
+                                int64_t nz, double resolution, int enable_edge_gradients,
+                                const double* rotation, double* gradient_host,
+                                uint8_t* has_value_host);
+/* Same on device buffers (e.g. straight after vgt_hip_sdf_dev, without leaving the device). */
+int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny,
+                                    int64_t nz, double resolution, int enable_edge_gradients,
+                                    const double* rotation, double* gradient_dev,
+                                    uint8_t* has_value_dev);
+
 /* ---- multi-GPU: the grid is cut into Z slabs, one device per slab (BASELINE.json config 5).
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
  * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest

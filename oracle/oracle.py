@@ -49,6 +49,7 @@ def load(path=None):
     lib.vgt_oracle_cells_filled_mask.argtypes = [_p, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _p, _i64,
                                                  ctypes.c_int, _p]
     lib.vgt_oracle_combine_free_and_named.argtypes = [_p, _p, _i64, _p, _p, _p]
+    lib.vgt_oracle_coarse_gradient.argtypes = [_p, _i64, _i64, _i64, _f64, ctypes.c_int, _p, _p]
     lib.vgt_oracle_raycast_f32.argtypes = [
         _p, _i64, _f32, _p, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _i32, _p, ctypes.c_int]
     lib.vgt_oracle_raycast_f64.argtypes = [
@@ -141,6 +142,17 @@ def free_and_named_objects_sdf(records, shape, resolution, unknown_is_filled=Tru
     load().vgt_oracle_combine_free_and_named(_ptr(free_sdf), _ptr(named_sdf), free_sdf.size, _ptr(out),
                                              ctypes.byref(lo), ctypes.byref(hi))
     return out, float(lo.value), float(hi.value)
+
+
+def coarse_gradient(sdf, resolution, enable_edge_gradients=False):
+    """GetGridAlignedIndexCoarseGradient at every voxel: (gradient [nx, ny, nz, 3] float64, has_value bool)."""
+    field = np.ascontiguousarray(sdf, dtype=np.float32)
+    nx, ny, nz = field.shape
+    grad = np.empty((nx, ny, nz, 3), dtype=np.float64)
+    has = np.empty((nx, ny, nz), dtype=np.uint8)
+    load().vgt_oracle_coarse_gradient(_ptr(field), nx, ny, nz, float(resolution), int(bool(enable_edge_gradients)),
+                                      _ptr(grad), _ptr(has))
+    return grad, has.astype(bool)
 
 
 def raycast_f32(points, max_range, xform, voxel_size, inverse_voxel_size,

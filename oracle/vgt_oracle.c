@@ -400,6 +400,83 @@ void vgt_oracle_combine_free_and_named(const float* free_sdf, const float* named
 }
 
 /* ------------------------------------------------------------------------- */
+/* SDF consumer: coarse gradient.                               */
+/* ------------------------------------------------------------------------- */
+
+void vgt_oracle_coarse_gradient(const float* sdf, int64_t nx, int64_t ny, int64_t nz,
+                                double resolution, int enable_edge_gradients, double* gradient,
+                                uint8_t* has_value)
+{
+#define SDF_AT(xi, yi, zi) sdf[((xi) * ny + (yi)) * nz + (zi)]
+  for (int64_t x_index = 0; x_index < nx; x_index++)
+    for (int64_t y_index = 0; y_index < ny; y_index++)
+      for (int64_t z_index = 0; z_index < nz; z_index++)
+      {
+        const int64_t i = (x_index * ny + y_index) * nz + z_index;
+        double gx = NAN, gy = NAN, gz = NAN;
+        int ok = 1;
+        /* signed_distance_field.hpp:933-950 */
+        if ((x_index > 0) && (y_index > 0) && (z_index > 0) && (x_index < (nx - 1)) &&
+            (y_index < (ny - 1)) && (z_index < (nz - 1)))
+        {
+          const double inv_twice_resolution = 1.0 / (2.0 * resolution);
+          /* the operands are floats: the difference is a float, the product a double */
+          const float dx = SDF_AT(x_index + 1, y_index, z_index) - SDF_AT(x_index - 1, y_index, z_index);
+          const float dy = SDF_AT(x_index, y_index + 1, z_index) - SDF_AT(x_index, y_index - 1, z_index);
+          const float dz = SDF_AT(x_index, y_index, z_index + 1) - SDF_AT(x_index, y_index, z_index - 1);
+          gx = dx * inv_twice_resolution;
+          gy = dy * inv_twice_resolution;
+          gz = dz * inv_twice_resolution;
+        }
+        else if (enable_edge_gradients) /* :955-1004 */
+        {
+          const int64_t low_x_index = (x_index - 1 > 0) ? x_index - 1 : 0;
+          const int64_t high_x_index = (x_index + 1 < nx - 1) ? x_index + 1 : nx - 1;
+          const int64_t low_y_index = (y_index - 1 > 0) ? y_index - 1 : 0;
+          const int64_t high_y_index = (y_index + 1 < ny - 1) ? y_index + 1 : ny - 1;
+          const int64_t low_z_index = (z_index - 1 > 0) ? z_index - 1 : 0;
+          const int64_t high_z_index = (z_index + 1 < nz - 1) ? z_index + 1 : nz - 1;
+          const double x_increment = (double)(high_x_index - low_x_index) * resolution;
+          const double y_increment = (double)(high_y_index - low_y_index) * resolution;
+          const double z_increment = (double)(high_z_index - low_z_index) * resolution;
+          gx = 0.0;
+          gy = 0.0;
+          gz = 0.0;
+          if (x_increment > 0.0)
+          {
+            const double inv_x_increment = 1.0 / x_increment;
+            const double high_x_value = SDF_AT(high_x_index, y_index, z_index);
+            const double low_x_value = SDF_AT(low_x_index, y_index, z_index);
+            gx = (high_x_value - low_x_value) * inv_x_increment;
+          }
+          if (y_increment > 0.0)
+          {
+            const double inv_y_increment = 1.0 / y_increment;
+            const double high_y_value = SDF_AT(x_index, high_y_index, z_index);
+            const double low_y_value = SDF_AT(x_index, low_y_index, z_index);
+            gy = (high_y_value - low_y_value) * inv_y_increment;
+          }
+          if (z_increment > 0.0)
+          {
+            const double inv_z_increment = 1.0 / z_increment;
+            const double high_z_value = SDF_AT(x_index, y_index, high_z_index);
+            const double low_z_value = SDF_AT(x_index, y_index, low_z_index);
+            gz = (high_z_value - low_z_value) * inv_z_increment;
+          }
+        }
+        else
+        {
+          ok = 0; /* :1006-1010 empty GradientQuery */
+        }
+        gradient[3 * i + 0] = gx;
+        gradient[3 * i + 1] = gy;
+        gradient[3 * i + 2] = gz;
+        if (has_value) has_value[i] = (uint8_t)ok;
+      }
+#undef SDF_AT
+}
+
+/* ------------------------------------------------------------------------- */
 
 static int32_t step_from_diff_i32(int32_t diff)
 {

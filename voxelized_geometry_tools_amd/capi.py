@@ -68,6 +68,10 @@ SIGNATURES = {
     "vgt_hip_cells_object_ids": (_int, [_p, _p, _p, ctypes.c_int64, _p]),
     "vgt_hip_cells_sdf": (_int, [_p, _p, _p, ctypes.c_int64, ctypes.c_double, _int, _int, _p, _p, _p]),
     "vgt_hip_cells_free_and_named_objects_sdf": (_int, [_p, _p, ctypes.c_double, _int, _int, _p, _p, _p]),
+    "vgt_hip_sdf_coarse_gradient": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                          _int, _p, _p, _p]),
+    "vgt_hip_sdf_coarse_gradient_dev": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_double, _int, _p, _p, _p]),
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
@@ -189,6 +193,18 @@ class Context:
         check(self._lib.vgt_hip_debug_finalize_check(self.handle, int(first_d2), int(count), float(resolution),
                                                      ctypes.byref(bad), ctypes.byref(first)))
         return int(bad.value), (None if first.value == 2 ** 64 - 1 else int(first.value))
+
+    def sdf_coarse_gradient(self, sdf, resolution, enable_edge_gradients=False, rotation=None):
+        """Grid-aligned (or rotated) coarse gradient of every voxel: (gradient [nx, ny, nz, 3] float64, has_value)."""
+        field = np.ascontiguousarray(sdf, dtype=np.float32)
+        nx, ny, nz = field.shape
+        grad = np.empty((nx, ny, nz, 3), dtype=np.float64)
+        has = np.empty((nx, ny, nz), dtype=np.uint8)
+        rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+        check(self._lib.vgt_hip_sdf_coarse_gradient(self.handle, _ptr(field), nx, ny, nz, float(resolution),
+                                                    int(bool(enable_edge_gradients)), _ptr(rot), _ptr(grad),
+                                                    _ptr(has)))
+        return grad, has.astype(bool)
 
     def cells(self, records, shape, object_id_offset=4):
         """Uploads a grid of cell records (see Cells)."""

@@ -163,3 +163,97 @@ hipError_t LaunchCombineFreeAndNamed(const float* free_sdf_dev, const float* nam
   return hipGetLastError();
 }
 }  // namespace vgt
+
+// ---------------------------------------------------------------------------------------------
+// SDF consumer: SignedDistanceField::GetGridAlignedIndexCoarseGradient
+// (signed_distance_field.hpp:923-1016) for every voxel at once.  Interior voxels: central
+// differences, the float difference taken in float and scaled in double exactly as the
+// reference's expression evaluates; voxels on a face of the grid: one-sided differences in double
+// when edge gradients are enabled (:951-1004), otherwise no value (NaN, has_value = 0).
+// `rotation` (optional, 9 doubles row-major) turns the result into GetIndexCoarseGradient's
+// (:906-921): OriginTransform() * gradient, translation not applied to a direction.
+// ---------------------------------------------------------------------------------------------
+namespace vgt
+{
+namespace
+{
+struct Rotation
+{
+  double m[9];
+  int enabled;
+};
+
+__global__ __launch_bounds__(256) void CoarseGradientKernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                           double resolution, int enable_edge_gradients,
+                                                           const Rotation rot, double* __restrict__ gradient,
+                                                           uint8_t* __restrict__ has_value)
+{
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  const int64_t sx = static_cast<int64_t>(ny) * nz, sy = nz;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int z = static_cast<int>(i % nz);
+    const int y = static_cast<int>((i / nz) % ny);
+    const int x = static_cast<int>(i / sx);
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    bool ok = true;
+    if (x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1)
+    {
+      const double inv_twice_resolution = 1.0 / (2.0 * resolution);
+      gx = static_cast<double>(sdf[i + sx] - sdf[i - sx]) * inv_twice_resolution;
+      gy = static_cast<double>(sdf[i + sy] - sdf[i - sy]) * inv_twice_resolution;
+      gz = static_cast<double>(sdf[i + 1] - sdf[i - 1]) * inv_twice_resolution;
+    }
+    else if (enable_edge_gradients)
+    {
+      const int lx = max(0, x - 1), hx = min(nx - 1, x + 1);
+      const int ly = max(0, y - 1), hy = min(ny - 1, y + 1);
+      const int lz = max(0, z - 1), hz = min(nz - 1, z + 1);
+      const double x_increment = static_cast<double>(hx - lx) * resolution;
+      const double y_increment = static_cast<double>(hy - ly) * resolution;
+      const double z_increment = static_cast<double>(hz - lz) * resolution;
+      if (x_increment > 0.0)
+        gx = (static_cast<double>(sdf[i + (hx - x) * sx]) - static_cast<double>(sdf[i - (x - lx) * sx])) *
+             (1.0 / x_increment);
+      if (y_increment > 0.0)
+        gy = (static_cast<double>(sdf[i + (hy - y) * sy]) - static_cast<double>(sdf[i - (y - ly) * sy])) *
+             (1.0 / y_increment);
+      if (z_increment > 0.0)
+        gz = (static_cast<double>(sdf[i + (hz - z)]) - static_cast<double>(sdf[i - (z - lz)])) * (1.0 / z_increment);
+    }
+    else
+    {
+      ok = false;
+      gx = gy = gz = __longlong_as_double(0x7ff8000000000000ll);
+    }
+    if (ok && rot.enabled)
+    {
+      const double wx = rot.m[0] * gx + rot.m[1] * gy + rot.m[2] * gz;
+      const double wy = rot.m[3] * gx + rot.m[4] * gy + rot.m[5] * gz;
+      const double wz = rot.m[6] * gx + rot.m[7] * gy + rot.m[8] * gz;
+      gx = wx;
+      gy = wy;
+      gz = wz;
+    }
+    gradient[3 * i + 0] = gx;
+    gradient[3 * i + 1] = gy;
+    gradient[3 * i + 2] = gz;
+    if (has_value) has_value[i] = ok ? 1 : 0;
+  }
+}
+}  // namespace
+
+hipError_t LaunchCoarseGradient(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                int enable_edge_gradients, const double* rotation_host, double* gradient_dev,
+                                uint8_t* has_value_dev, hipStream_t stream)
+{
+  Rotation rot;
+  rot.enabled = rotation_host ? 1 : 0;
+  for (int k = 0; k < 9; k++) rot.m[k] = rotation_host ? rotation_host[k] : 0.0;
+  hipLaunchKernelGGL(CoarseGradientKernel, dim3(CellGrid(nx * ny * nz)), dim3(256), 0, stream, sdf_dev,
+                     static_cast<int>(nx), static_cast<int>(ny), static_cast<int>(nz), resolution,
+                     enable_edge_gradients, rot, gradient_dev, has_value_dev);
+  return hipGetLastError();
+}
+}  // namespace vgt

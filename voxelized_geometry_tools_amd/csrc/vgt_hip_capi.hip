@@ -1028,6 +1028,59 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
   return CopySdfToHost(ctx, cells->sdf, n, sdf_host, out_min, out_max);
 }
 
+/* ------------------------------- SDF consumers ------------------------------- */
+
+int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
+                                    double resolution, int enable_edge_gradients, const double* rotation,
+                                    double* gradient_dev, uint8_t* has_value_dev)
+{
+  if (!ctx || !sdf_dev || !gradient_dev) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(vgt::LaunchCoarseGradient(sdf_dev, nx, ny, nz, resolution, enable_edge_gradients ? 1 : 0, rotation,
+                                        gradient_dev, has_value_dev, ctx->stream),
+              "coarse gradient");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_sdf_coarse_gradient(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                                double resolution, int enable_edge_gradients, const double* rotation,
+                                double* gradient_host, uint8_t* has_value_host)
+{
+  if (!ctx || !sdf_host || !gradient_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const size_t n = static_cast<size_t>(nx * ny * nz);
+  float* sdf_dev = nullptr;
+  double* grad_dev = nullptr;
+  uint8_t* has_dev = nullptr;
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&sdf_dev), n * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&grad_dev), n * 3 * sizeof(double));
+  if (err == hipSuccess && has_value_host) err = hipMalloc(reinterpret_cast<void**>(&has_dev), n);
+  if (err == hipSuccess)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    err = hipMemcpyAsync(sdf_dev, sdf_host, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (err == hipSuccess)
+      err = vgt::LaunchCoarseGradient(sdf_dev, nx, ny, nz, resolution, enable_edge_gradients ? 1 : 0, rotation,
+                                      grad_dev, has_dev, ctx->stream);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(gradient_host, grad_dev, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess && has_value_host)
+      err = hipMemcpyAsync(has_value_host, has_dev, n, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);
+    if (err == hipSuccess) err = sync;
+  }
+  if (sdf_dev) (void)hipFree(sdf_dev);
+  if (grad_dev) (void)hipFree(grad_dev);
+  if (has_dev) (void)hipFree(has_dev);
+  VGT_TRY_HIP(err, "coarse gradient");
+  return VGT_HIP_OK;
+}
+
 /* --------------------------------- multi-GPU --------------------------------- */
 
 size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny)

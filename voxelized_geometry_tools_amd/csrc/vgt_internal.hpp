@@ -85,6 +85,11 @@ hipError_t LaunchNextObjectId(const void* cells_dev, int64_t num_cells, int cell
 hipError_t LaunchCombineFreeAndNamed(const float* free_sdf_dev, const float* named_sdf_dev, int64_t num_cells,
                                      float* out_dev, uint32_t* minmax_enc, hipStream_t stream);
 
+// SDF consumer: grid-aligned (or rotated) coarse gradient of every voxel, 3 doubles per voxel.
+hipError_t LaunchCoarseGradient(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                int enable_edge_gradients, const double* rotation_host, double* gradient_dev,
+                                uint8_t* has_value_dev, hipStream_t stream);
+
 // --- launchers (voxelizer_kernels.hip) ---
 struct RaycastGridF32
 {
