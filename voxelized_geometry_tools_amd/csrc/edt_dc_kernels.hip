@@ -450,9 +450,7 @@ template <typename InT, typename OutT, bool kFinal>
 hipError_t DispatchDc(const InT* in, OutT* out, uint32_t* minmax_enc, TileGeom g,
                       int64_t outer_count, hipStream_t stream, bool* handled)
 {
-  static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
-  int W = DcLinesPerTile(g.n);
-  if (W == 32 && force_w == 16) W = 16;  // experiment: half-width tiles, two workgroups per CU
+  const int W = DcLinesPerTile(g.n);
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;

@@ -1074,16 +1074,22 @@ template <typename InT, typename OutT, bool kFinal>
 hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom g,
                         int64_t outer_count, hipStream_t stream, bool* handled)
 {
-  static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
   int W = LinesPerTile(g.n);
-  if (force_w == 32 && g.n <= 1024) W = 32;  // experiment knob: full-width tiles
-  if (force_w == 8 && g.n <= 2048) W = 8;    // experiment knob: quarter-width tiles
-  if (force_w == 16 && g.n <= 2048) W = 16;  // experiment knob: half-width tiles
+#ifdef VGT_HULL_DEBUG  // tile-width experiments (diagnostic build only)
+  static const int force_w = getenv("VGT_HULL_W") ? atoi(getenv("VGT_HULL_W")) : 0;
+  if (force_w == 32 && g.n <= 1024) W = 32;
+  if (force_w == 16 && g.n <= 2048) W = 16;
+  if (force_w == 8 && g.n <= 2048) W = 8;
+#endif
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
   g.ztiles = (g.nz + W - 1) / W;
+#ifdef VGT_HULL_DEBUG
   static const int debug_skip = getenv("VGT_HULL_SKIP") ? atoi(getenv("VGT_HULL_SKIP")) : 0;
   g.debug_skip = debug_skip;
+#else
+  g.debug_skip = 0;
+#endif
   constexpr int kVec = 16 / static_cast<int>(sizeof(InT));
   g.vector_io = (g.nz % kVec == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0);
   if (outer_count * g.ztiles > 0x7fffffffLL)
