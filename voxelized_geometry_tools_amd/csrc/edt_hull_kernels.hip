@@ -15,19 +15,32 @@
 // the two voxels of the other class that bound the run (when they exist).
 //
 // Parallelisation inside a line: the line is cut into bands of 32 rows, one thread per
-// (line, band); lanes of a wave are different lines (neighbouring Z).  An envelope is a bit mask
-// (bit = member survives), one 32-bit word per band, so "pop" clears a bit and stack neighbours
-// are clz/ffs; a per-line summary word skips empty mask words.  Phases (workgroup barriers
-// between them):
-//   1  each thread builds the hull of its band (stack algorithm, exact integer predicate)
-//   1b per-word carries of the nearest row of either class below/above (wave scans)
-//   2  the band hulls are joined at every band boundary at once (tangent walks with atomic bit
-//      clears), in rounds, until a round changes nothing
-//   2b every surviving member computes the first row it owns (exact floor division); members
-//      that own no row are dropped, the others set a "start" bit at that row
+// (line, band); lanes of a wave are different lines (neighbouring Z) and different bands.  An
+// envelope is a bit mask (bit = member survives), one 32-bit word per band, so "pop" clears a
+// bit and stack neighbours are clz/ffs; a per-line summary word skips empty mask words.  Phases
+// (workgroup barriers between them):
+//   1a the band's 32 rows -> registers; sign word; the strongest member of the band's first and
+//      last run portion is published
+//   1b per-word carries of the nearest row of either class below / above (wave scans) and, by a
+//      doubling scan over the published members, one SEED per band and direction: a strong
+//      member of the same run in the bands below / above
+//   1c branch-free prefilter over the registers (a member matched at its own row by a site on
+//      each side never owns a row; chord test against the adjacent rows), then the stack
+//      algorithm over the surviving candidates, with the seeds as virtual bottom / closing
+//      elements (exact integer predicate)
+//   2  the band hulls are joined at every band boundary at once (walks with atomic bit clears),
+//      in rounds, until a round changes nothing
+//   2b every surviving member computes the first row it owns once (float quotient estimate +
+//      exact remainder repair); bands exchange the start of their first member; members that own
+//      no row are dropped, the others set a "start" bit at that row
 //   2c per-word prefix counts of survivors and of start bits (wave scans)
-//   3  each thread evaluates its 32 rows: the owner of a row is the k-th survivor, k = number of
-//      start bits at or below the row (rank / select), then advances at every start bit.
+//   3  each thread evaluates its 32 rows: the owner of the first row is the k-th survivor, k =
+//      number of start bits at or below it (rank / select); at every further start bit the owner
+//      iterator moves to the next survivor.
+// The kernel is VALU-issue bound, and a wave pays for its busiest lane: slow paths that only some
+// lane takes run on almost every iteration, so the data-dependent loops keep their state (mask
+// words, iterators) in registers and avoid the generic LDS bit searches wherever a wave would
+// otherwise execute them all the time.  Tile width: see LinesPerTile.
 // All predicates are integer-exact (64-bit cross multiplication / exact floor of a quotient).
 #include "edt_tile.hpp"
 
