@@ -11,6 +11,20 @@ constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, workgroup b of a launch goes to X
 // Square of a row / voxel offset (|v| <= 16384): 24-bit multiply, full rate on CDNA (the 32-bit
 // v_mul_lo is quarter rate).
 __device__ __forceinline__ int32_t Sq(int v) { return __mul24(v, v); }
+// The same as single instructions, for hot loops where the compiler keeps the library wrapper's
+// (redundant) 24-bit sign-extension shifts around the multiply: v * v and v * v + add.
+__device__ __forceinline__ int32_t SqAsm(int v)
+{
+  int32_t r;
+  asm("v_mul_i32_i24 %0, %1, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ int32_t SqPlusAsm(int v, int32_t add)
+{
+  int32_t r;
+  asm("v_mad_i32_i24 %0, %1, %1, %2" : "=v"(r) : "v"(v), "v"(add));
+  return r;
+}
 
 // Decoding of the intermediate encodings into (class, squared distance so far).
 __device__ __forceinline__ void Decode(int16_t v, bool& negative, int32_t& f)

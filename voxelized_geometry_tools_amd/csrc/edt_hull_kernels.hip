@@ -990,10 +990,14 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
                                : static_cast<int>(neg ? t.next_pos[wi] : t.next_neg[wi]);
         run_a = prev_opp + 1;
       }
-      int32_t best = kInf32;
-      if (cur >= run_a) best = Sq(r - cur) + fcur;
-      if (prev_opp >= 0) best = min(best, Sq(r - prev_opp));
-      if (next_opp < n) best = min(best, Sq(next_opp - r));
+      // three candidates, all computed and then selected (no branches): the owner's parabola and
+      // the two rows of the other class that bound the run
+      const int32_t via_owner = SqPlusAsm(r - cur, fcur);
+      const int32_t via_prev = SqAsm(r - prev_opp);
+      const int32_t via_next = SqAsm(next_opp - r);
+      int32_t best = (cur >= run_a) ? via_owner : kInf32;
+      best = (prev_opp >= 0) ? min(best, via_prev) : best;
+      best = (next_opp < n) ? min(best, via_next) : best;
       if constexpr (kFinal)
       {
         const int x = (g.pass_axis == 0) ? r : outer;
