@@ -172,15 +172,11 @@ def main():
     if dist_on:
         runner = multi_gpu.SlabSdf(ctx, torch, dist, full_shape, rank, world, device)
 
-    kernel_ms = np.zeros(3, dtype=np.float32)
-    kernel_sum = np.zeros(3, dtype=np.float64)
-
-    def step(timed):
+    def step():
         if not dist_on:
-            ctx.sdf_dev(occ.data_ptr(), local_shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes,
-                        minmax.data_ptr(), kernel_ms=kernel_ms if timed else None)
+            ctx.sdf_dev(occ.data_ptr(), local_shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes, minmax.data_ptr())
         else:
-            runner.run(occ, sdf, ws, minmax, res, kernel_ms if timed else None)
+            runner.run(occ, sdf, ws, minmax, res)
 
     def fence():
         torch.cuda.synchronize()
@@ -189,23 +185,27 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     fence()
+    # per-kernel durations: HIP events recorded by the library around each kernel of the timed steps, on
+    # the stream the kernels run on, read back once after the timed region (no per-step synchronisation)
+    ctx.timing_start(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-        kernel_sum += kernel_ms
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    per_step_ms = ctx.timing_stop()
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    kernel_sum = per_step_ms.astype(np.float64).sum(axis=0) if len(per_step_ms) else np.zeros(3)
 
     total_vox = float(np.prod(full_shape))
     ms_per_step = elapsed / args.steps * 1e3
     value = total_vox / (elapsed / args.steps) / 1e6
-    avg_ms = kernel_sum / max(args.steps, 1)
+    avg_ms = kernel_sum / max(len(per_step_ms), 1)
     dom = int(np.argmax(avg_ms))
     local_vox = float(np.prod(local_shape))
     achieved = ALG_BYTES_PER_VOXEL_PASS * local_vox / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0

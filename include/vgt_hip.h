@@ -240,6 +240,16 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
                                              int add_virtual_border, float* sdf_host,
                                              float* out_min, float* out_max);
 
+/* ---- deferred per-kernel timing (benchmarks) ----
+ * Between start and stop every vgt_hip_sdf_dev call (or vgt_hip_sdf_slab_begin_dev /
+ * _finish_dev pair called with kernel_ms == NULL) on this context records HIP events around its
+ * kernels on the stream they run on, WITHOUT synchronising; stop waits for the stream once and
+ * returns, per call, the milliseconds of {Z scan (+ slab fix-up), Y pass, X pass}.  Calls beyond
+ * max_calls are not recorded. */
+int vgt_hip_timing_start(vgt_hip_ctx* ctx, int32_t max_calls);
+int vgt_hip_timing_stop(vgt_hip_ctx* ctx, float* kernel_ms /* [max_calls][3] */,
+                        int32_t* num_calls);
+
 /* ---- SDF consumers ----
  * SignedDistanceField<float>::GetGridAlignedIndexCoarseGradient
  * (I/signed_distance_field.hpp:923-1016) for every voxel of a field at once: gradient[3 * i + a]

@@ -282,3 +282,26 @@ def test_z_scan_chunkings(ctx, oracle, shape):
     assert (lo, hi) == (wlo, whi)
     got, _, _ = ctx.sdf_from_mask((occ > 0.5).astype(np.uint8), 0.03)
     assert bits_equal(got, want), shape
+
+
+def test_deferred_kernel_timing(ctx):
+    """vgt_hip_timing_start / _stop: per-call kernel durations without per-call synchronisation."""
+    import torch
+    shape = (128, 128, 128)
+    occ = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    occ[40:60, 50:70, 30:90] = 1.0
+    sdf = torch.empty(shape, dtype=torch.float32, device="cuda")
+    nbytes = capi.sdf_workspace_bytes(shape)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(None)
+    try:
+        ctx.timing_start(3)
+        for _ in range(5):                                   # two calls beyond the capacity are not recorded
+            ctx.sdf_dev(occ.data_ptr(), shape, 0.01, sdf.data_ptr(), ws.data_ptr(), nbytes)
+        ms = ctx.timing_stop()
+    finally:
+        ctx.reset_stream()
+    assert ms.shape == (3, 3)
+    assert np.all(ms > 0.0) and np.all(ms < 50.0)
+    with pytest.raises(ValueError):
+        ctx.timing_start(0)

@@ -72,6 +72,8 @@ SIGNATURES = {
                                           _int, _p, _p, _p]),
     "vgt_hip_sdf_coarse_gradient_dev": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_double, _int, _p, _p, _p]),
+    "vgt_hip_timing_start": (_int, [_p, ctypes.c_int32]),
+    "vgt_hip_timing_stop": (_int, [_p, _p, _p]),
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
@@ -182,6 +184,18 @@ class Context:
 
     def synchronize(self):
         check(self._lib.vgt_hip_synchronize(self.handle))
+
+    def timing_start(self, max_calls):
+        """Deferred per-kernel timing of the following SDF calls (no synchronisation until timing_stop)."""
+        self._timing_capacity = int(max_calls)
+        check(self._lib.vgt_hip_timing_start(self.handle, int(max_calls)))
+
+    def timing_stop(self):
+        """-> float32 array [calls, 3]: ms of (Z scan [+ slab fix-up], Y pass, X pass) per recorded call."""
+        out = np.zeros((self._timing_capacity, 3), dtype=np.float32)
+        n = ctypes.c_int32(0)
+        check(self._lib.vgt_hip_timing_stop(self.handle, _ptr(out), ctypes.byref(n)))
+        return out[:n.value].copy()
 
     def set_edt_variant(self, variant):
         check(self._lib.vgt_hip_set_edt_variant(self.handle, int(variant)))

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 #include <new>
 #include <string>
 #include <vector>
@@ -23,6 +24,11 @@ struct vgt_hip_ctx
   size_t stage_bytes = 0;
   float* minmax_out = nullptr;   // 2 floats (device) for host-facing SDF calls
   vgt::EdtVariant variant = vgt::EdtVariant::kDefault;
+  // deferred per-kernel timing (vgt_hip_timing_start / _stop): 8 events per SDF call
+  std::vector<hipEvent_t> timing_events;
+  std::vector<uint8_t> timing_kind;  // 1 = single-device call, 2 = slab begin + finish
+  int timing_slots = 0;
+  int timing_used = 0;
 };
 
 struct vgt_hip_grids
@@ -119,6 +125,13 @@ int CheckSdfShape(int64_t nx, int64_t ny, int64_t nz, double resolution)
   if (!(resolution > 0.0) || !std::isfinite(resolution))
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "Grid must have uniform, positive resolution");
   return VGT_HIP_OK;
+}
+
+// Events of the current timing slot (nullptr when no session is active or it is full).
+hipEvent_t* TimingSlot(vgt_hip_ctx* ctx)
+{
+  if (ctx->timing_slots == 0 || ctx->timing_used >= ctx->timing_slots) return nullptr;
+  return &ctx->timing_events[static_cast<size_t>(ctx->timing_used) * 8];
 }
 
 // Enqueues the three passes.  events (optional) = 4 recorded events bracketing the kernels.
@@ -309,6 +322,8 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stage) (void)hipFree(ctx->stage);
   if (ctx->minmax_out) (void)hipFree(ctx->minmax_out);
+  for (hipEvent_t e : ctx->timing_events)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -757,8 +772,11 @@ int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, in
   const vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0,
                          add_virtual_border ? 1 : 0};
   std::lock_guard<std::mutex> lock(ctx->mutex);
-  return RunSdfPipeline<float>(ctx, occupancy_dev, p, sdf_dev, workspace_dev, workspace_bytes,
-                               minmax_dev, nullptr);
+  hipEvent_t* slot = TimingSlot(ctx);
+  const int result = RunSdfPipeline<float>(ctx, occupancy_dev, p, sdf_dev, workspace_dev, workspace_bytes,
+                                           minmax_dev, slot);
+  if (slot && result == VGT_HIP_OK) ctx->timing_kind[static_cast<size_t>(ctx->timing_used++)] = 1;
+  return result;
 }
 
 int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
@@ -1028,6 +1046,75 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
   return CopySdfToHost(ctx, cells->sdf, n, sdf_host, out_min, out_max);
 }
 
+/* ------------------------------ deferred timing ------------------------------ */
+
+namespace
+{
+void ReleaseTiming(vgt_hip_ctx* ctx)
+{
+  for (hipEvent_t e : ctx->timing_events)
+    if (e) (void)hipEventDestroy(e);
+  ctx->timing_events.clear();
+  ctx->timing_kind.clear();
+  ctx->timing_slots = 0;
+  ctx->timing_used = 0;
+}
+}  // namespace
+
+int vgt_hip_timing_start(vgt_hip_ctx* ctx, int32_t max_calls)
+{
+  if (!ctx || max_calls <= 0 || max_calls > 4096)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid timing capacity");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  ReleaseTiming(ctx);
+  ctx->timing_events.assign(static_cast<size_t>(max_calls) * 8, nullptr);
+  ctx->timing_kind.assign(static_cast<size_t>(max_calls), 0);
+  for (hipEvent_t& e : ctx->timing_events)
+  {
+    const hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess)
+    {
+      ReleaseTiming(ctx);
+      return FailHip("create event", err);
+    }
+  }
+  ctx->timing_slots = max_calls;
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_timing_stop(vgt_hip_ctx* ctx, float* kernel_ms, int32_t* num_calls)
+{
+  if (!ctx || !kernel_ms || !num_calls) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  hipError_t err = hipStreamSynchronize(ctx->stream);
+  *num_calls = ctx->timing_used;
+  for (int i = 0; i < ctx->timing_used && err == hipSuccess; i++)
+  {
+    hipEvent_t* e = &ctx->timing_events[static_cast<size_t>(i) * 8];
+    float* out = kernel_ms + 3 * i;
+    float fix = 0.0f;
+    if (ctx->timing_kind[static_cast<size_t>(i)] == 1)
+    {
+      err = hipEventElapsedTime(&out[0], e[0], e[1]);
+      if (err == hipSuccess) err = hipEventElapsedTime(&out[1], e[1], e[2]);
+      if (err == hipSuccess) err = hipEventElapsedTime(&out[2], e[2], e[3]);
+    }
+    else
+    {
+      err = hipEventElapsedTime(&out[0], e[0], e[1]);
+      if (err == hipSuccess) err = hipEventElapsedTime(&fix, e[4], e[5]);
+      if (err == hipSuccess) err = hipEventElapsedTime(&out[1], e[5], e[6]);
+      if (err == hipSuccess) err = hipEventElapsedTime(&out[2], e[6], e[7]);
+      out[0] += fix;  // the slab fix-up belongs to the Z pass
+    }
+  }
+  ReleaseTiming(ctx);
+  VGT_TRY_HIP(err, "read kernel timing");
+  return VGT_HIP_OK;
+}
+
 /* ------------------------------- SDF consumers ------------------------------- */
 
 int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
@@ -1146,11 +1233,14 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
   const int trc = timer.Init(kernel_ms != nullptr, 1);
   if (trc != VGT_HIP_OK) return trc;
   std::lock_guard<std::mutex> lock(ctx->mutex);
+  hipEvent_t* slot = kernel_ms ? nullptr : TimingSlot(ctx);
   VGT_TRY_HIP(timer.Mark(0, ctx->stream), "event record");
+  if (slot) VGT_TRY_HIP(hipEventRecord(slot[0], ctx->stream), "event record");
   VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(occupancy_dev, ws.t16, p,
                                             static_cast<vgt::SlabLineSummary*>(summary_dev),
                                             ctx->stream),
               "Z scan");
+  if (slot) VGT_TRY_HIP(hipEventRecord(slot[1], ctx->stream), "event record");
   VGT_TRY_HIP(timer.Mark(1, ctx->stream), "event record");
   return timer.Finish(ctx->stream, kernel_ms, 1);
 }
@@ -1178,15 +1268,24 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   if (trc != VGT_HIP_OK) return trc;
   std::lock_guard<std::mutex> lock(ctx->mutex);
   hipStream_t s = ctx->stream;
+  hipEvent_t* slot = kernel_ms ? nullptr : TimingSlot(ctx);
   VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
   VGT_TRY_HIP(timer.Mark(0, s), "event record");
+  if (slot) VGT_TRY_HIP(hipEventRecord(slot[4], s), "event record");
   VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
               "slab fix-up");
   VGT_TRY_HIP(timer.Mark(1, s), "event record");
+  if (slot) VGT_TRY_HIP(hipEventRecord(slot[5], s), "event record");
   VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.line_scratch, p, ctx->variant, s), "Y pass");
   VGT_TRY_HIP(timer.Mark(2, s), "event record");
+  if (slot) VGT_TRY_HIP(hipEventRecord(slot[6], s), "event record");
   VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.line_scratch, p, ctx->variant, s), "X pass");
   VGT_TRY_HIP(timer.Mark(3, s), "event record");
+  if (slot)
+  {
+    VGT_TRY_HIP(hipEventRecord(slot[7], s), "event record");
+    ctx->timing_kind[static_cast<size_t>(ctx->timing_used++)] = 2;
+  }
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
   return timer.Finish(s, kernel_ms, 3);
 }
