@@ -274,8 +274,9 @@ int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int6
  *   1. vgt_hip_sdf_slab_begin_dev   local Z scan + per-line summary of this slab
  *                                    (4 x int16 per line: global z of the first / last filled and
  *                                    first / last free voxel, -1 when absent)
- *   2. the caller exchanges the summaries (one RCCL all-gather; torch.distributed in
- *      voxelized_geometry_tools_amd/multi_gpu.py) and reduces them to per-line carries
+ *   2. the caller all-gathers the summaries (one RCCL all-gather; torch.distributed in
+ *      voxelized_geometry_tools_amd/multi_gpu.py) into [world][lines] records and
+ *      vgt_hip_sdf_slab_carries_dev reduces them to this slab's per-line carries
  *      (4 x int16: prev_filled, next_filled, prev_free, next_free as global z, -1 when absent)
  *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
  * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
@@ -286,6 +287,8 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
                                int64_t nz_local, int64_t z_offset, int unknown_is_filled,
                                void* workspace_dev, size_t workspace_bytes, void* summary_dev,
                                float* kernel_ms);
+int vgt_hip_sdf_slab_carries_dev(vgt_hip_ctx* ctx, const void* gathered_summaries_dev, int32_t world,
+                                 int32_t rank, int64_t nx, int64_t ny, void* carries_dev);
 int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_t nz_local,
                                 int64_t z_offset, int64_t nz_global, double resolution,
                                 int add_virtual_border, const void* carries_dev, float* sdf_dev,

@@ -305,3 +305,33 @@ def test_deferred_kernel_timing(ctx):
     assert np.all(ms > 0.0) and np.all(ms < 50.0)
     with pytest.raises(ValueError):
         ctx.timing_start(0)
+
+
+def test_slab_carry_kernel_matches_torch_reduction(ctx):
+    """vgt_hip_sdf_slab_carries_dev vs multi_gpu.carries_from_summaries (the torch restatement the gloo tests use)."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    rng = np.random.default_rng(17)
+    world, nx, ny = 5, 23, 31
+    lines = nx * ny
+    summaries = np.full((world, lines, 4), -1, dtype=np.int16)
+    for r in range(world):
+        z0 = r * 40
+        for col_first, col_last in ((multi_gpu.FIRST_FILLED, multi_gpu.LAST_FILLED),
+                                    (multi_gpu.FIRST_FREE, multi_gpu.LAST_FREE)):
+            has = rng.random(lines) < 0.6
+            a = rng.integers(0, 40, size=lines)
+            b = rng.integers(0, 40, size=lines)
+            summaries[r, :, col_first] = np.where(has, z0 + np.minimum(a, b), -1)
+            summaries[r, :, col_last] = np.where(has, z0 + np.maximum(a, b), -1)
+    gathered = torch.from_numpy(summaries).cuda()
+    ctx.set_stream(None)
+    try:
+        for rank in range(world):
+            want = multi_gpu.carries_from_summaries(torch, gathered, rank)
+            got = torch.empty((lines, 4), dtype=torch.int16, device="cuda")
+            ctx.sdf_slab_carries(gathered.data_ptr(), world, rank, nx, ny, got.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), rank
+    finally:
+        ctx.reset_stream()

@@ -393,6 +393,38 @@ __global__ __launch_bounds__(256) void SlabFixupKernel(int16_t* __restrict__ io,
   }
 }
 
+// Multi-GPU: per-line carries of slab `rank` from the gathered summaries of all slabs
+// (summaries[slab][line]): nearest filled / free voxel below = largest last_* of the slabs
+// before it, above = smallest first_* of the slabs after it (-1 when absent).
+__global__ __launch_bounds__(256) void SlabCarriesKernel(const SlabLineSummary* __restrict__ summaries,
+                                                        int world, int rank, int64_t lines,
+                                                        SlabLineCarry* __restrict__ carries)
+{
+  for (int64_t line = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; line < lines;
+       line += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    int prev_filled = -1, prev_free = -1, next_filled = -1, next_free = -1;
+    for (int r = 0; r < rank; r++)
+    {
+      const SlabLineSummary s = summaries[static_cast<int64_t>(r) * lines + line];
+      prev_filled = max(prev_filled, static_cast<int>(s.last_filled));
+      prev_free = max(prev_free, static_cast<int>(s.last_free));
+    }
+    for (int r = world - 1; r > rank; r--)
+    {
+      const SlabLineSummary s = summaries[static_cast<int64_t>(r) * lines + line];
+      if (s.first_filled >= 0) next_filled = s.first_filled;
+      if (s.first_free >= 0) next_free = s.first_free;
+    }
+    SlabLineCarry c;
+    c.prev_filled = static_cast<int16_t>(prev_filled);
+    c.next_filled = static_cast<int16_t>(next_filled);
+    c.prev_free = static_cast<int16_t>(prev_free);
+    c.next_free = static_cast<int16_t>(next_free);
+    carries[line] = c;
+  }
+}
+
 // Same, eight consecutive voxels of one line per thread (nz % 8 == 0): one 16-byte load, one
 // carry record, and a store only when a distance actually shrank.
 __global__ __launch_bounds__(256) void SlabFixupVecKernel(int16_t* __restrict__ io,
@@ -635,6 +667,14 @@ hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
 {
   hipLaunchKernelGGL(FinalizeCheckKernel, dim3(4096), dim3(256), 0, stream, first, count, resolution,
                      result_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines,
+                             SlabLineCarry* carries, hipStream_t stream)
+{
+  hipLaunchKernelGGL(SlabCarriesKernel, dim3(GridFor(lines, 256)), dim3(256), 0, stream, summaries, world, rank,
+                     lines, carries);
   return hipGetLastError();
 }
 

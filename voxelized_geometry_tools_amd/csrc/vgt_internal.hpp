@@ -61,6 +61,8 @@ hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfPar
 // Multi-GPU: folds the carries of the other slabs into the slab-local pass-1 distances, in place.
 hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
                                unsigned long long* result_dev, hipStream_t stream);
+hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines,
+                             SlabLineCarry* carries, hipStream_t stream);
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.

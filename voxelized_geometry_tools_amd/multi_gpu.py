@@ -104,6 +104,7 @@ class SlabSdf:
         assert capi.load().vgt_hip_sdf_slab_summary_bytes(*self.local_shape[:2]) == lines * 8
         self.summary = torch.empty((lines, 4), dtype=torch.int16, device=device)
         self.gathered = torch.empty((world, lines, 4), dtype=torch.int16, device=device)
+        self.carries = torch.empty((lines, 4), dtype=torch.int16, device=device)
         self.ms_begin = np.zeros(1, dtype=np.float32)
         self.ms_finish = np.zeros(3, dtype=np.float32)
 
@@ -114,8 +115,12 @@ class SlabSdf:
         self.ctx.sdf_slab_begin(occ.data_ptr(), self.local_shape, self.z_offset, ws.data_ptr(),
                                 ws.numel(), self.summary.data_ptr(), unknown_is_filled,
                                 self.ms_begin if timed else None)
-        carries = exchange_carries(torch, self.dist, self.summary, self.rank, self.world,
-                                   self.gathered)
+        # one all-gather of the 8-byte records (as int32 words), then the library's carry kernel
+        self.dist.all_gather_into_tensor(self.gathered.view(torch.int32).view(-1),
+                                         self.summary.view(torch.int32).view(-1))
+        carries = self.carries
+        self.ctx.sdf_slab_carries(self.gathered.data_ptr(), self.world, self.rank, self.local_shape[0],
+                                  self.local_shape[1], carries.data_ptr())
         self.ctx.sdf_slab_finish(self.local_shape, self.z_offset, self.full_shape[2], resolution,
                                  carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), ws.numel(),
                                  minmax.data_ptr(), add_virtual_border,
@@ -153,11 +158,12 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
                            summary.data_ptr(), unknown_is_filled)
         parts.append((local_shape, z0, local, ws, nbytes, summary))
     ctx.synchronize()
-    gathered = torch.stack([p[5] for p in parts])
+    gathered = torch.stack([p[5] for p in parts]).contiguous()
     out = torch.empty((nx, ny, nz), dtype=torch.float32, device=dev)
     extrema = []
     for r, (local_shape, z0, local, ws, nbytes, summary) in enumerate(parts):
-        carries = carries_from_summaries(torch, gathered, r)
+        carries = torch.empty((nx * ny, 4), dtype=torch.int16, device=dev)
+        ctx.sdf_slab_carries(gathered.data_ptr(), nslabs, r, nx, ny, carries.data_ptr())
         sdf = torch.empty(local_shape, dtype=torch.float32, device=dev)
         mm = torch.zeros(2, dtype=torch.float32, device=dev)
         ctx.sdf_slab_finish(local_shape, z0, nz, resolution, carries.data_ptr(), sdf.data_ptr(),
