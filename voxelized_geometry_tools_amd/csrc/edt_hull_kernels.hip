@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 // what matters beyond that is how many workgroups share the CU (they are in different phases,
 // which keeps the VALUs busy across barriers and load / store phases) without starving the row
 // segments.  Measured (ms per SDF, D1): n = 512: 32 lines 2.08, 16 lines 2.19, 8 lines 2.16;
-// n = 768: 8.97 / 9.52 / 6.88; n = 1024: 21.6 / 16.4 / 15.7; n = 2048 slabs: - / 8.26 / 7.70.
+// n = 768: 8.97 / 9.52 / 6.88; n = 1024: 21.6 / 16.4 / 15.7 (4 lines: 17.5); n = 2048 slabs: - / 8.26 / 7.70.
 // So: 32 lines (tile <= 64 KiB, two workgroups per CU) up to n = 512, 8 lines above (four or
 // more workgroups per CU up to n = 1024, two at 2048; the XCD-aware tile order lets the L2 merge
 // the short row segments of neighbouring tiles).  A line may have at most 64 mask words (one
@@ -1097,6 +1097,7 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   if (force_w == 32 && g.n <= 1024) W = 32;
   if (force_w == 16 && g.n <= 2048) W = 16;
   if (force_w == 8 && g.n <= 2048) W = 8;
+  if (force_w == 4 && g.n <= 2048) W = 4;
 #endif
   *handled = (W != 0);
   if (W == 0) return hipSuccess;
@@ -1107,7 +1108,7 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
 #else
   g.debug_skip = 0;
 #endif
-  constexpr int kVec = 16 / static_cast<int>(sizeof(InT));
+  constexpr int kVec = 16 / static_cast<int>(sizeof(InT));  // shorter rows load whole rows (W elements)
   g.vector_io = (g.nz % kVec == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0);
   if (outer_count * g.ztiles > 0x7fffffffLL)
   {
@@ -1117,6 +1118,12 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
   if (W == 32)
     return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
+#ifdef VGT_HULL_DEBUG
+  if (W == 4 && nwords <= 32)
+    return LaunchHull<InT, OutT, kFinal, 4, 32>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 4)
+    return LaunchHull<InT, OutT, kFinal, 4, 64>(in, out, minmax_enc, g, outer_count, stream);
+#endif
   if (W == 8 && nwords <= 32)
     return LaunchHull<InT, OutT, kFinal, 8, 32>(in, out, minmax_enc, g, outer_count, stream);
   if (W == 8)

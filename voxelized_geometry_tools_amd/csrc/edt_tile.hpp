@@ -42,12 +42,14 @@ __device__ __forceinline__ void LoadTile(const InT* __restrict__ in, int32_t* __
     int32_t* F;
   } t{F};
   {
-    constexpr int kVec = 16 / static_cast<int>(sizeof(InT));  // elements per 16-byte chunk
+    // elements per chunk: 16 bytes, or a whole row when the row is shorter than that
+    constexpr int kVec16 = 16 / static_cast<int>(sizeof(InT));
+    constexpr int kVec = (W < kVec16) ? W : kVec16;
     constexpr int kChunksPerRow = W / kVec;
     constexpr int kBatch = 4;
     if (g.vector_io && (z0 + W <= g.nz))
     {
-      using Chunk = __attribute__((__vector_size__(16))) int;
+      using Chunk = __attribute__((__vector_size__(kVec * sizeof(InT)))) int;
       const int total = n * kChunksPerRow;
       for (int c0 = threadIdx.x; c0 < total; c0 += blockDim.x * kBatch)
       {
