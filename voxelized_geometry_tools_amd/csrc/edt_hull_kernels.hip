@@ -213,6 +213,7 @@ __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int 
 }
 
 using HullGeom = TileGeom;
+constexpr bool kXBeforeY = false;  // see XBeforeY(): measured 15.13 vs 15.21 ms at 1024^3 (neutral), kept off
 constexpr int kChordMaxSpacing = 1;  // 2 (spacings 1 and 2) measured the same
 
 // Bytes of dynamic LDS for a tile of n rows x W lines.
@@ -1134,40 +1135,70 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
 }
 }  // namespace
 
-hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
-                           hipStream_t stream, bool* handled)
+namespace
+{
+// Geometry of a line pass along X (axis 0) or Y (axis 1) of the [x][y][z] grid.
+HullGeom PassGeometry(const SdfParams& p, int axis, int64_t* outer_count)
 {
   HullGeom g{};
-  g.n = static_cast<int>(p.ny);
   g.nz = static_cast<int>(p.nz);
-  g.row_stride = p.nz;
-  g.outer_stride = p.ny * p.nz;
   g.nx = static_cast<int>(p.nx);
   g.ny = static_cast<int>(p.ny);
-  g.pass_axis = 1;
+  g.pass_axis = axis;
+  if (axis == 0)
+  {
+    g.n = static_cast<int>(p.nx);
+    g.row_stride = p.ny * p.nz;
+    g.outer_stride = p.nz;
+    *outer_count = p.ny;
+  }
+  else
+  {
+    g.n = static_cast<int>(p.ny);
+    g.row_stride = p.nz;
+    g.outer_stride = p.ny * p.nz;
+    *outer_count = p.nx;
+  }
   g.resolution = p.resolution;
   g.add_virtual_border = p.add_virtual_border;
   g.z_offset = static_cast<int>(p.z_offset);
   g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
-  return DispatchHull<int16_t, int32_t, false>(in16, out32, nullptr, g, p.nx, stream, handled);
+  return g;
+}
+
+// The separable transform does not care which of X and Y goes first.  X lines are 4 MiB apart per
+// row at 1024^3 (a different page for every row segment), Y lines 4 KiB: running X as the MIDDLE
+// pass puts the hostile stride on its 2 + 4 bytes per voxel and leaves the final pass, which
+// writes the float field, with the friendly one.  Only when both axes fit the tiled kernel (the
+// fallback kernels are written for Y-then-X).
+bool XBeforeY(const SdfParams& p)
+{
+  // both passes must be taken by the tiled kernel (see DispatchHull), or neither is swapped
+  const int wx = LinesPerTile(p.nx), wy = LinesPerTile(p.ny);
+  if (wx == 0 || wy == 0) return false;
+  if (p.ny * ((p.nz + wx - 1) / wx) > 0x7fffffffLL || p.nx * ((p.nz + wy - 1) / wy) > 0x7fffffffLL) return false;
+#ifdef VGT_HULL_DEBUG
+  static const int order = getenv("VGT_HULL_ORDER") ? atoi(getenv("VGT_HULL_ORDER")) : -1;
+  if (order >= 0) return order == 1;
+#endif
+  return kXBeforeY;
+}
+}  // namespace
+
+hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
+                           hipStream_t stream, bool* handled)
+{
+  int64_t outer_count = 0;
+  const HullGeom g = PassGeometry(p, XBeforeY(p) ? 0 : 1, &outer_count);
+  return DispatchHull<int16_t, int32_t, false>(in16, out32, nullptr, g, outer_count, stream, handled);
 }
 
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    const SdfParams& p, hipStream_t stream, bool* handled)
 {
-  HullGeom g{};
-  g.n = static_cast<int>(p.nx);
-  g.nz = static_cast<int>(p.nz);
-  g.row_stride = p.ny * p.nz;
-  g.outer_stride = p.nz;
-  g.nx = static_cast<int>(p.nx);
-  g.ny = static_cast<int>(p.ny);
-  g.pass_axis = 0;
-  g.resolution = p.resolution;
-  g.add_virtual_border = p.add_virtual_border;
-  g.z_offset = static_cast<int>(p.z_offset);
-  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
-  return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, p.ny, stream, handled);
+  int64_t outer_count = 0;
+  const HullGeom g = PassGeometry(p, XBeforeY(p) ? 1 : 0, &outer_count);
+  return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, outer_count, stream, handled);
 }
 }  // namespace vgt
 
