@@ -9,6 +9,11 @@ SDF is left in HBM.  N = 1 runs BASELINE config 4 (1024^3, distribution D1 "sphe
 42, resolution 0.01).  N > 1 runs BASELINE config 5 (2048 x 2048 x 1024) partitioned into
 Z slabs, one process per GPU, with one RCCL exchange of per-line boundary summaries
 (voxelized_geometry_tools_amd/multi_gpu.py).  Rank 0 prints ONE JSON line.
+
+Launching: `python bench.py --gpus N` starts the N ranks itself (a `torch.distributed.run`
+child, started before this process touches the GPU) unless it already runs under a launcher
+(WORLD_SIZE set), in which case WORLD_SIZE must equal N -- a mismatch is an error, never a
+silent 1-GPU run.
 """
 import argparse
 import json
@@ -35,12 +40,12 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="cube edge for N=1 (default 1024)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
-    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2, 3 cross-check implementations)")
+    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 3 cross-check implementations)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
 
@@ -106,25 +111,67 @@ def cpu_baseline(budget_s):
     except Exception:
         lib = O.load()
     cores = int(lib.vgt_oracle_max_threads())
-    edge, rate = 96, None
+
+    def mem_ok(edge):  # the oracle holds two double fields + float in/out: ~28 B/voxel with slack
+        try:
+            with open("/proc/meminfo") as fh:
+                avail_kb = next(int(l.split()[1]) for l in fh if l.startswith("MemAvailable"))
+        except (OSError, StopIteration):
+            return edge <= 512
+        return 32.0 * edge ** 3 < 0.6 * avail_kb * 1024.0
+
+    # grow the sample towards the headline size (1024^3) while the extrapolated time fits the budget
+    edge, rate, dt = 128, None, 0.0
     while True:
         occ = synthetic.occupancy_spheres((edge,) * 3, 42)
         t0 = time.perf_counter()
         O.sdf_from_occupancy(occ, 0.01, True, False, 0, lib=lib)
         dt = time.perf_counter() - t0
         rate = occ.size / dt / 1e6
-        nxt = int(edge * 1.5) // 32 * 32
-        # EDT cost is ~linear in voxels; stop once the next size would blow the budget
-        if dt * (nxt / edge) ** 3 > budget_s or nxt > 640:
+        del occ
+        if edge >= 1024:
+            break
+        nxt = min(edge * 2, 1024)
+        # EDT cost is ~linear in voxels; stop once the next size would blow the budget or the host RAM
+        if dt * (nxt / edge) ** 3 > budget_s or not mem_ok(nxt):
             break
         edge = nxt
     return {"value": round(rate, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
             "sample": "%d^3 D1 spheres seed 42, res 0.01, %.2f s on %d OpenMP threads "
-                      "(oracle/vgt_oracle.c, -O3 -march=native)" % (edge, dt, cores)}
+                      "(oracle/vgt_oracle.c, -O3 -march=native)%s" % (
+                          edge, dt, cores, "" if edge == 1024 else
+                          "; 1024^3 did not fit the %.0f s budget / host RAM on this box" % budget_s)}
+
+
+def launch_ranks(args):
+    """`--gpus N` without a launcher: run this script under torch.distributed.run with N ranks.
+    Nothing in this (parent) process has initialised the GPU; the child is a subprocess, not an exec."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import torch
+        have = torch.cuda.device_count()  # does not initialise the GPU on this image
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, have))
+        raise SystemExit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%s: refusing to report a run of a different size"
+                         % (args.gpus, os.environ.get("WORLD_SIZE")))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,7 +210,7 @@ def main():
 
     occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape, args.salt_p)
     sdf = torch.empty(local_shape, dtype=torch.float32, device=device)
-    ws_bytes = capi.sdf_workspace_bytes(local_shape)
+    ws_bytes = capi.sdf_workspace_bytes(local_shape, args.variant)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     minmax = torch.zeros(2, dtype=torch.float32, device=device)
     ctx = capi.Context(local_rank)
@@ -201,6 +248,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_sum = per_step_ms.astype(np.float64).sum(axis=0) if len(per_step_ms) else np.zeros(3)
+    if dist_on:  # the slowest rank's kernels bound the step: report max over ranks
+        kt = torch.tensor(kernel_sum, dtype=torch.float64, device=device)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kernel_sum = kt.cpu().numpy()
 
     total_vox = float(np.prod(full_shape))
     ms_per_step = elapsed / args.steps * 1e3
@@ -216,7 +267,9 @@ def main():
         traffic, traffic_src = profiled_traffic(
             KERNEL_NAMES[dom], not dist_on and not args.size and args.dist == "spheres" and args.variant == 0)
         line = {
-            "metric": "Mvoxels/s for 1024^3 float SDF extract @1 GPU; % HBM roofline",
+            "metric": "Mvoxels/s for %s float SDF extract @%d GPU%s; %% HBM roofline%s" % (
+                "x".join(str(v) for v in full_shape) if len(set(full_shape)) > 1 else "%d^3" % full_shape[0],
+                world, "" if world == 1 else "s", " (per device, slowest rank)" if dist_on else ""),
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",

@@ -180,6 +180,9 @@ int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, 
  * in HBM, the caller provides the scratch workspace.  minmax_dev, if non-NULL, receives
  * {min, max} as two floats on the device after the call (stream-ordered). */
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
+/* As above for a context set to EDT variant `variant`: only the line-sweep cross-check variant (3)
+ * needs more (its per-line stacks, 8 B/voxel); every other variant returns the size above. */
+size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant);
 int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                     int64_t nz, double resolution, int unknown_is_filled,
                     int add_virtual_border, float* sdf_dev, void* workspace_dev,
@@ -192,8 +195,8 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
 /* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
  * 0 = default (LDS-tiled lower envelope: stack + merge), 1 = pruned outward search from HBM
- * (any size), 2 = LDS-tiled monotone-argmin search, 3 = line sweep (one lane per line, stacks in
- * the workspace). */
+ * (any size), 3 = line sweep (one lane per line, stacks in the workspace; needs
+ * vgt_hip_sdf_workspace_bytes_for_variant, otherwise the default passes run).  2 is not a variant. */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 /* Diagnostic: the final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation
  * with an exact fallback (csrc/edt_device.hpp); this runs both over d2 in
@@ -281,7 +284,10 @@ int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int6
  *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
  * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
  * in both calls.  kernel_ms (optional): begin -> [scan]; finish -> [fix-up, Y pass, X pass];
- * when given, the call blocks until the work has finished. */
+ * when given, the call blocks until the work has finished.
+ * Limits: summaries and carries hold GLOBAL z as int16, so the whole grid's Z extent (nz_global,
+ * and z_offset + nz_local of every slab) must not exceed 16384 -- the per-axis limit of every SDF
+ * entry point; larger values are rejected with VGT_HIP_ERR_INVALID_ARGUMENT. */
 size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny);
 int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                                int64_t nz_local, int64_t z_offset, int unknown_is_filled,

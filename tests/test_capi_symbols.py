@@ -38,10 +38,12 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_workspace_size(lib):
     assert lib.vgt_hip_abi_version() == 1
-    # int16 + int32 intermediates, a small min/max block, and the line passes' stacks (8 B per
-    # voxel) + sign words (one bit per voxel), 256-byte aligned pieces
+    # int16 + int32 intermediates and a small min/max block, 256-byte aligned pieces; only the
+    # line-sweep cross-check variant (3) adds its stacks (8 B per voxel) + sign words (one bit per voxel)
     n = 64 * 64 * 64
-    assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256 + n * 8 + n // 8 + 256
+    assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256
+    assert capi.sdf_workspace_bytes((64, 64, 64), 1) == n * 2 + n * 4 + 256
+    assert capi.sdf_workspace_bytes((64, 64, 64), 3) == n * 2 + n * 4 + 256 + n * 8 + n // 8 + 256
     assert capi.sdf_workspace_bytes((0, 4, 4)) == 0
 
 

@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 2, 3]  # tiled envelope, pruned search from HBM, tiled argmin search, line sweep
+VARIANTS = [0, 1, 3]  # tiled envelope, pruned search from HBM, line sweep
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -163,6 +163,62 @@ def test_z_slab_pipeline_matches_single_device(ctx, oracle, nslabs):
         got, lo, hi = multi_gpu.sdf_slabs_single_device(ctx, torch, occ_dev, nslabs, 0.02, True, vb)
         assert bits_equal(got.cpu().numpy(), want), (dist, nslabs)
         assert (lo, hi) == (wlo, whi), (dist, nslabs)
+
+
+def _host_ram_ok(voxels, bytes_per_voxel=40.0):
+    try:
+        with open("/proc/meminfo") as fh:
+            avail_kb = next(int(l.split()[1]) for l in fh if l.startswith("MemAvailable"))
+    except (OSError, StopIteration):
+        return False
+    return bytes_per_voxel * voxels < 0.7 * avail_kb * 1024.0
+
+
+@pytest.mark.parametrize("dist", ["spheres", "salt"])
+def test_headline_config_bit_exact_vs_oracle(ctx, oracle, dist):
+    """BASELINE config 4 exactly as bench.py times it (1024^3, D1 spheres seed 42 and D2 salt p = 0.01, res 0.01,
+    device-resident) against the CPU oracle, every voxel bit for bit, and the extrema."""
+    import torch
+    import bench
+    shape = (1024, 1024, 1024)
+    if not _host_ram_ok(float(np.prod(shape))):
+        pytest.skip("the oracle needs ~40 GiB of host RAM at 1024^3")
+    occ = bench.device_occupancy(torch, shape, dist, 42, torch.device("cuda", 0))
+    sdf = torch.empty(shape, dtype=torch.float32, device="cuda")
+    nbytes = capi.sdf_workspace_bytes(shape)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    minmax = torch.zeros(2, dtype=torch.float32, device="cuda")
+    ctx.set_stream(None)
+    try:
+        ctx.sdf_dev(occ.data_ptr(), shape, 0.01, sdf.data_ptr(), ws.data_ptr(), nbytes, minmax.data_ptr())
+        torch.cuda.synchronize()
+    finally:
+        ctx.reset_stream()
+    del ws
+    occ_host = occ.cpu().numpy()
+    del occ
+    want, wlo, whi = oracle.sdf_from_occupancy(occ_host, 0.01)
+    del occ_host
+    got = sdf.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), dist
+    mm = minmax.cpu().numpy()
+    assert (float(mm[0]), float(mm[1])) == (wlo, whi)
+
+
+@pytest.mark.parametrize("shape,nslabs", [((1100, 600, 384), 3), ((600, 1300, 96), 2), ((2048, 520, 64), 4)])
+def test_z_slab_pipeline_long_axes(ctx, oracle, shape, nslabs):
+    """The slab pipeline on axes that use the wide-line tiles of the envelope passes (rows > 512 and > 1024),
+    all slabs on this device, against the oracle."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    if not _host_ram_ok(float(np.prod(shape))):
+        pytest.skip("not enough host RAM for the oracle")
+    for dist, vb in (("spheres", False), ("salt", True)):
+        occ = synthetic.make_occupancy(shape, dist, seed=5)
+        want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.02, True, vb)
+        got, lo, hi = multi_gpu.sdf_slabs_single_device(ctx, torch, torch.from_numpy(occ).cuda(), nslabs, 0.02, True, vb)
+        assert bits_equal(got.cpu().numpy(), want), (dist, shape)
+        assert (lo, hi) == (wlo, whi), (dist, shape)
 
 
 @pytest.mark.parametrize("shape", [(1100, 6, 40), (5, 1500, 33), (2048, 4, 16), (3, 2049, 20),

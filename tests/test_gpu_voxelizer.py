@@ -249,3 +249,22 @@ def test_pointcloud2_ingestion(ctx, oracle, layout):
     if point_step % 4 == 0:
         with pytest.raises(ValueError):
             grids.raycast_pointcloud2(0, data, len(pts), point_step, 2, 2.0, xf, vs, ivs, sizes, counts)
+
+
+def test_context_destroyed_before_its_handles():
+    """A context destroyed while grids / filter grids / cell grids made from it are still alive (the RAII order
+    of a caller that declares the context last) must not be touched after it is freed: the library keeps the
+    context record until the last handle is destroyed."""
+    c = capi.Context(0)
+    grids = c.tracking_grids(512, 2)
+    fg = c.filter_grid(np.zeros((8, 8, 8), dtype=np.float32))
+    raw = c.handle
+    c.handle = None                      # keep Context.close() from closing the children first
+    c._lib.vgt_hip_destroy(raw)
+    grids.close()
+    fg.close()
+    # and the ordinary order through the binding: close() closes the children, then the context
+    c2 = capi.Context(0)
+    g2 = c2.tracking_grids(64, 1)
+    c2.close()
+    assert g2.handle is None

@@ -66,7 +66,14 @@ def _worker(rank, world, port, shape, seed, queue):
             mag = np.where(sel, np.minimum(mag, cand), mag)
         got = np.where(local, -mag, mag)
         want = _z_distance_reference(filled)[:, :, z0:z0 + local_shape[2]]
-        queue.put((rank, bool(np.array_equal(got, want)), None))
+        ok = bool(np.array_equal(got, want))
+        # extrema of the whole field: one two-element collective (multi_gpu.reduce_extrema)
+        per_rank = [(-0.5 - r, 2.0 + 3 * r) for r in range(world)]
+        per_rank[world - 1] = (float("-inf"), 1.0)
+        mm = torch.tensor(per_rank[rank], dtype=torch.float32)
+        multi_gpu.reduce_extrema(dist, mm)
+        ok = ok and mm.tolist() == [float("-inf"), max(h for _, h in per_rank)]
+        queue.put((rank, ok, None))
     except Exception as exc:  # pragma: no cover
         queue.put((rank, False, repr(exc)))
     finally:

@@ -5,6 +5,7 @@ include/vgt_hip/.  There is no CPU fallback here -- if the library is missing, o
 device is usable, the calls raise.
 """
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -59,6 +60,7 @@ SIGNATURES = {
     "vgt_hip_sdf_from_occupancy_f32": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hip_sdf_from_mask_u8": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _p, _p, _p]),
     "vgt_hip_sdf_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vgt_hip_sdf_workspace_bytes_for_variant": (_sz, [_i64, _i64, _i64, _int]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
@@ -158,9 +160,17 @@ class Context:
         h = _p()
         check(self._lib.vgt_hip_create(device, threads_per_block, ctypes.byref(h)))
         self.handle = h
+        self._children = weakref.WeakSet()   # grids / filter grids / cell grids created from this context
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def close(self):
+        """Destroys the context after the handles created from it (the library also tolerates the
+        other order: it keeps the context record alive until its last handle is destroyed)."""
         if getattr(self, "handle", None):
+            for child in list(self._children):
+                child.close()
             self._lib.vgt_hip_destroy(self.handle)
             self.handle = None
 
@@ -292,8 +302,9 @@ class Context:
         return FilterGrid(self, occupancy)
 
 
-def sdf_workspace_bytes(shape):
-    return int(load().vgt_hip_sdf_workspace_bytes(*[int(s) for s in shape]))
+def sdf_workspace_bytes(shape, variant=0):
+    """Workspace of the device-resident SDF entry points; only EDT variant 3 (line sweep) needs more."""
+    return int(load().vgt_hip_sdf_workspace_bytes_for_variant(*[int(s) for s in shape], int(variant)))
 
 
 class TrackingGrids:
@@ -304,6 +315,8 @@ class TrackingGrids:
         check(self._lib.vgt_hip_tracking_grids_create(ctx.handle, int(num_cells), int(num_grids),
                                                       ctypes.byref(h)))
         self.handle = h
+        ctx._adopt(self)
+        ctx._adopt(self)
         self.num_cells = int(num_cells)
         self.num_grids = int(num_grids)
 
@@ -390,6 +403,7 @@ class FilterGrid:
                                                    _ptr(occ) if occ.size else None,
                                                    ctypes.byref(h)))
         self.handle = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -444,6 +458,7 @@ class Cells:
         check(self._lib.vgt_hip_cells_create(ctx.handle, _ptr(rec), self.shape[0], self.shape[1], self.shape[2],
                                              rec.dtype.itemsize, int(object_id_offset), ctypes.byref(h)))
         self.handle = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "handle", None):

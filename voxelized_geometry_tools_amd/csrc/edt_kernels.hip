@@ -17,8 +17,8 @@
 //
 // This file holds the Z scan and the simple pruned-search line pass (EdtVariant::kBruteForce,
 // exact for any size, the fallback for axes longer than the tiled kernels support).  The
-// LDS-tiled line passes live in edt_hull_kernels.hip (default: lower envelope) and
-// edt_dc_kernels.hip (monotone-argmin search, cross-check variant).
+// LDS-tiled line passes live in edt_hull_kernels.hip (default: lower envelope), the line-sweep
+// cross-check variant in edt_line_kernels.hip.
 #include "edt_device.hpp"
 
 namespace vgt
@@ -561,11 +561,7 @@ int GridFor(int64_t work_items, int block)
 }
 }  // namespace
 
-// Defined in edt_dc_kernels.hip / edt_hull_kernels.hip.
-hipError_t LaunchPassYDc(const int16_t* in16, int32_t* out32, const SdfParams& p,
-                         hipStream_t stream, bool* handled);
-hipError_t LaunchPassXDcFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                                 const SdfParams& p, hipStream_t stream, bool* handled);
+// Defined in edt_line_kernels.hip / edt_hull_kernels.hip.
 hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                            hipStream_t stream);
 hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -702,9 +698,7 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, 
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err = (variant == EdtVariant::kSearch)
-                               ? LaunchPassYDc(in16, out32, p, stream, &handled)
-                               : LaunchPassYHull(in16, out32, p, stream, &handled);
+    const hipError_t err = LaunchPassYHull(in16, out32, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;
@@ -722,10 +716,7 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err =
-        (variant == EdtVariant::kSearch)
-            ? LaunchPassXDcFinalize(in32, sdf, minmax_enc, p, stream, &handled)
-            : LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
+    const hipError_t err = LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;

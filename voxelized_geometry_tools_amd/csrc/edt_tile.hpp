@@ -1,4 +1,4 @@
-// Pieces shared by the LDS-tiled line-pass kernels (edt_hull_kernels.hip, edt_dc_kernels.hip).
+// Pieces shared by the LDS-tiled line-pass kernels (edt_hull_kernels.hip).
 #pragma once
 
 #include "edt_device.hpp"

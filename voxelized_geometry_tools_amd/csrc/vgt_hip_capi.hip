@@ -5,6 +5,7 @@
 #include "vgt_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -29,11 +30,17 @@ struct vgt_hip_ctx
   std::vector<uint8_t> timing_kind;  // 1 = single-device call, 2 = slab begin + finish
   int timing_slots = 0;
   int timing_used = 0;
+  // Handles created from this context (grids, filter grids, cell grids) point back at it.  A
+  // context destroyed while handles are alive releases its device resources at once but keeps this
+  // struct until the last handle is gone, so handle destructors never touch freed memory.
+  std::atomic<int> children{0};
+  std::atomic<bool> destroyed{false};
 };
 
 struct vgt_hip_grids
 {
   vgt_hip_ctx* ctx = nullptr;
+  int device = -1;
   int32_t* dev = nullptr;
   int64_t num_cells = 0;
   int32_t num_grids = 0;
@@ -42,6 +49,7 @@ struct vgt_hip_grids
 struct vgt_hip_filter
 {
   vgt_hip_ctx* ctx = nullptr;
+  int device = -1;
   float* dev = nullptr;
   int64_t num_cells = 0;
 };
@@ -51,6 +59,7 @@ struct vgt_hip_filter
 struct vgt_hip_cells
 {
   vgt_hip_ctx* ctx = nullptr;
+  int device = -1;
   int64_t nx = 0, ny = 0, nz = 0;
   int cell_bytes = 0;
   int object_id_offset = -1;
@@ -81,6 +90,20 @@ int FailHip(const char* what, hipError_t err)
   return VGT_HIP_ERR_RUNTIME;
 }
 
+// A handle is being created from / destroyed after its context (see vgt_hip_ctx::children).
+void AdoptChild(vgt_hip_ctx* ctx) { ctx->children.fetch_add(1); }
+// Waits for the work that may still use the handle's buffers, then drops the handle's reference.
+void ReleaseChild(vgt_hip_ctx* ctx, int device)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(device);
+  if (ctx->destroyed.load())
+    (void)hipDeviceSynchronize();  // the context's stream is gone (vgt_hip_destroy drained it)
+  else
+    (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->children.fetch_sub(1) == 1 && ctx->destroyed.load()) delete ctx;
+}
+
 #define VGT_TRY_HIP(expr, what)                          \
   do                                                     \
   {                                                      \
@@ -99,7 +122,8 @@ struct SdfWorkspace
   size_t bytes;
 };
 
-SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
+// with_line_scratch: only the line-sweep cross-check variant (3) keeps its stacks in the workspace
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, bool with_line_scratch = false)
 {
   SdfWorkspace ws;
   const size_t n = static_cast<size_t>(nx * ny * nz);
@@ -110,8 +134,12 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
   off += 256;
-  ws.line_scratch = static_cast<char*>(base) + off;
-  off = AlignUp(off + vgt::LinePassScratchBytes(nx, ny, nz), 256);
+  ws.line_scratch = nullptr;
+  if (with_line_scratch)
+  {
+    ws.line_scratch = static_cast<char*>(base) + off;
+    off = AlignUp(off + vgt::LinePassScratchBytes(nx, ny, nz), 256);
+  }
   ws.bytes = off;
   return ws;
 }
@@ -140,7 +168,10 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
                    void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                    hipEvent_t* events)
 {
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
+  // the line-sweep cross-check variant keeps its stacks in the workspace; a workspace without that
+  // part (vgt_hip_sdf_workspace_bytes) runs the default passes instead
+  SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant == vgt::EdtVariant::kLine);
+  if (ws.line_scratch && workspace_bytes < ws.bytes) ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   hipStream_t s = ctx->stream;
@@ -170,7 +201,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   if (rc != VGT_HIP_OK) return rc;
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
-  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes(p.nx, p.ny, p.nz);
+  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes_for_variant(p.nx, p.ny, p.nz, static_cast<int>(ctx->variant));
   InT* in_dev = nullptr;
   float* sdf_dev = nullptr;
   void* ws_dev = nullptr;
@@ -325,7 +356,13 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   for (hipEvent_t e : ctx->timing_events)
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-  delete ctx;
+  ctx->stage = nullptr;
+  ctx->minmax_out = nullptr;
+  ctx->timing_events.clear();
+  ctx->own_stream = nullptr;
+  ctx->stream = nullptr;
+  ctx->destroyed.store(true);
+  if (ctx->children.load() == 0) delete ctx;  // otherwise the last handle's destroy frees it
 }
 
 int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream)
@@ -360,7 +397,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 3)
+  if (!ctx || variant < 0 || variant > 3 || variant == 2)  // 2 was the argmin-search experiment (removed)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
@@ -403,6 +440,7 @@ int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t n
   vgt_hip_grids* g = new (std::nothrow) vgt_hip_grids();
   if (!g) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
   g->ctx = ctx;
+  g->device = ctx->device;
   g->num_cells = num_cells;
   g->num_grids = num_grids;
   const size_t bytes = static_cast<size_t>(num_cells) * num_grids * 2 * sizeof(int32_t);
@@ -418,6 +456,7 @@ int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t n
     delete g;
     return FailHip("Failed to allocate tracking grids", err);
   }
+  AdoptChild(ctx);
   *out_grids = g;
   return VGT_HIP_OK;
 }
@@ -425,8 +464,7 @@ int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t n
 void vgt_hip_tracking_grids_destroy(vgt_hip_grids* grids)
 {
   if (!grids) return;
-  (void)hipSetDevice(grids->ctx->device);
-  (void)hipStreamSynchronize(grids->ctx->stream);
+  ReleaseChild(grids->ctx, grids->device);
   if (grids->dev) (void)hipFree(grids->dev);
   delete grids;
 }
@@ -633,6 +671,7 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
   vgt_hip_filter* f = new (std::nothrow) vgt_hip_filter();
   if (!f) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
   f->ctx = ctx;
+  f->device = ctx->device;
   f->num_cells = num_cells;
   const size_t bytes = static_cast<size_t>(num_cells) * sizeof(float);
   hipError_t err = hipMalloc(reinterpret_cast<void**>(&f->dev), bytes);
@@ -648,6 +687,7 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
     delete f;
     return FailHip("Failed to prepare filter grid", err);
   }
+  AdoptChild(ctx);
   *out_filter = f;
   return VGT_HIP_OK;
 }
@@ -655,8 +695,7 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
 void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter)
 {
   if (!filter) return;
-  (void)hipSetDevice(filter->ctx->device);
-  (void)hipStreamSynchronize(filter->ctx->stream);
+  ReleaseChild(filter->ctx, filter->device);
   if (filter->dev) (void)hipFree(filter->dev);
   delete filter;
 }
@@ -740,6 +779,12 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
   return CarveWorkspace(nullptr, nx, ny, nz).bytes;
+}
+
+size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
+{
+  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return CarveWorkspace(nullptr, nx, ny, nz, variant == static_cast<int>(vgt::EdtVariant::kLine)).bytes;
 }
 
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,
@@ -889,6 +934,7 @@ int vgt_hip_cells_create(vgt_hip_ctx* ctx, const void* cells_host, int64_t nx, i
   vgt_hip_cells* c = new (std::nothrow) vgt_hip_cells();
   if (!c) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
   c->ctx = ctx;
+  c->device = ctx->device;
   c->nx = nx;
   c->ny = ny;
   c->nz = nz;
@@ -913,6 +959,7 @@ int vgt_hip_cells_create(vgt_hip_ctx* ctx, const void* cells_host, int64_t nx, i
     FreeCells(c);
     return FailHip("upload cell records", err);
   }
+  AdoptChild(ctx);
   *out_cells = c;
   return VGT_HIP_OK;
 }
@@ -920,11 +967,7 @@ int vgt_hip_cells_create(vgt_hip_ctx* ctx, const void* cells_host, int64_t nx, i
 void vgt_hip_cells_destroy(vgt_hip_cells* cells)
 {
   if (!cells) return;
-  if (cells->ctx)
-  {
-    (void)hipSetDevice(cells->ctx->device);
-    (void)hipStreamSynchronize(cells->ctx->stream);
-  }
+  ReleaseChild(cells->ctx, cells->device);
   FreeCells(cells);
 }
 

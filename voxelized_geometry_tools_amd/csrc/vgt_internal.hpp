@@ -47,9 +47,9 @@ struct SlabLineCarry
 };
 
 // kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
-// straight from HBM; kSearch: LDS-tiled monotone-argmin search.  All three are exact; 1 and 2
-// exist for cross-checking and as the fallback for axes the tiled kernels do not cover.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kSearch = 2, kLine = 3 };
+// straight from HBM (also the fallback for axes the tiled kernels do not cover); kLine: line sweep
+// with stacks in the workspace.  All exact; 1 and 3 exist for cross-checking.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kLine = 3 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.

@@ -71,6 +71,15 @@ def exchange_carries(torch, dist, summary, rank, world, gathered=None):
     return carries_from_summaries(torch, gathered, rank)
 
 
+def reduce_extrema(dist, minmax):
+    """In place: minmax = (min over ranks of minmax[0], max over ranks of minmax[1]) with one collective
+    (min(a) = -max(-a); exact for floats, infinities included)."""
+    minmax[0:1].neg_()
+    dist.all_reduce(minmax, op=dist.ReduceOp.MAX)
+    minmax[0:1].neg_()
+    return minmax
+
+
 def summary_reference(filled, z_offset):
     """numpy restatement of the per-line slab summary (tests): filled = bool (nx, ny, nzl)."""
     nx, ny, nzl = filled.shape
@@ -125,12 +134,8 @@ class SlabSdf:
                                  carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), ws.numel(),
                                  minmax.data_ptr(), add_virtual_border,
                                  self.ms_finish if timed else None)
-        # the field's extrema are those of all slabs
-        lo, hi = minmax[0:1].clone(), minmax[1:2].clone()
-        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
-        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
-        minmax[0:1] = lo
-        minmax[1:2] = hi
+        # the field's extrema are those of all slabs: ONE two-element all-reduce, MAX over (-min, max)
+        reduce_extrema(self.dist, minmax)
         if timed:
             kernel_ms[0] = self.ms_begin[0] + self.ms_finish[0]
             kernel_ms[1] = self.ms_finish[1]
