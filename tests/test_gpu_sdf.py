@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 2, 3]  # tiled envelope, pruned search from HBM, sequential-band envelope, line sweep
+VARIANTS = [0, 1, 3]  # tiled envelope, pruned search from HBM, line sweep
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -68,6 +68,105 @@ DEFK(k_add3, I_ADD3) DEFK(k_lshladd, I_LSHLADD) DEFK(k_bfe, I_BFE) DEFK(k_perm, 
 DEFK(k_pkadd16, I_PKADD16) DEFK(k_pkmin16, I_PKMIN16) DEFK(k_pkmad16, I_PKMAD16) DEFK(k_mov, I_MOV) DEFK(k_dpp, I_DPP)
 DEFK(k_bperm, I_BPERM_NOWAIT)
 
+#define J_SUB(i) "v_sub_u32 %" #i ", %" #i ", %8\n"
+DEFK(k2_sub, J_SUB)
+#define J_OR(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+DEFK(k2_or, J_OR)
+#define J_XOR(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+DEFK(k2_xor, J_XOR)
+#define J_MINF(i) "v_min_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_minf, J_MINF)
+#define J_MAXF(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_maxf, J_MAXF)
+#define J_ADDF(i) "v_add_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_addf, J_ADDF)
+#define J_MULF(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_mulf, J_MULF)
+#define J_SUBF(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_subf, J_SUBF)
+#define J_MINU(i) "v_min_u32 %" #i ", %" #i ", %8\n"
+DEFK(k2_minu, J_MINU)
+#define J_MAXI(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+DEFK(k2_maxi, J_MAXI)
+#define J_LSHR(i) "v_lshrrev_b32 %" #i ", 1, %" #i "\n"
+DEFK(k2_lshr, J_LSHR)
+#define J_ASHR(i) "v_ashrrev_i32 %" #i ", 1, %" #i "\n"
+DEFK(k2_ashr, J_ASHR)
+#define J_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_andor, J_ANDOR)
+#define J_BFI(i) "v_bfi_b32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_bfi, J_BFI)
+#define J_NOT(i) "v_not_b32 %" #i ", %" #i "\n"
+DEFK(k2_not, J_NOT)
+#define J_MADI24(i) "v_mad_i32_i24 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_madi24, J_MADI24)
+#define J_FMAC(i) "v_fmac_f32 %" #i ", %8, %9\n"
+DEFK(k2_fmac, J_FMAC)
+#define J_CVTFU(i) "v_cvt_f32_u32 %" #i ", %" #i "\n"
+DEFK(k2_cvtfu, J_CVTFU)
+#define J_MIN3F(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_min3f, J_MIN3F)
+#define J_MED3F(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_med3f, J_MED3F)
+#define J_ALIGNBIT(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 3\n"
+DEFK(k2_alignbit, J_ALIGNBIT)
+#define J_CMPF(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n"
+DEFK(k2_cmpf, J_CMPF)
+#define J_CMPU(i) "v_cmp_lt_u32 vcc, %" #i ", %8\n"
+DEFK(k2_cmpu, J_CMPU)
+#define J_CMPI(i) "v_cmp_lt_i32 vcc, %" #i ", %8\n"
+DEFK(k2_cmpi, J_CMPI)
+#define J_CMPX(i) "v_cmp_lt_u32 s[20:21], %" #i ", %8\n"
+DEFK(k2_cmpx, J_CMPX)
+#define J_CNDSG(i) "v_cndmask_b32 %" #i ", %" #i ", %9, s[20:21]\n"
+DEFK(k2_cndsg, J_CNDSG)
+#define J_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 2, %9\n"
+DEFK(k2_lshlor, J_LSHLOR)
+#define J_OR3(i) "v_or3_b32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_or3, J_OR3)
+#define J_XAD(i) "v_xad_u32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_xad, J_XAD)
+#define J_ADDLSHL(i) "v_add_lshl_u32 %" #i ", %" #i ", %8, 1\n"
+DEFK(k2_addlshl, J_ADDLSHL)
+#define J_SUBREV(i) "v_subrev_u32 %" #i ", %8, %" #i "\n"
+DEFK(k2_subrev, J_SUBREV)
+#define J_BITOP3(i) "v_bitop3_b32 %" #i ", %" #i ", %8, %9 bitop3:0x80\n"
+DEFK(k2_bitop3, J_BITOP3)
+#define J_MAXF64(i) "v_max_f32 %" #i ", %" #i ", %" #i "\n"
+DEFK(k2_maxf64, J_MAXF64)
+#define J_RNDNE(i) "v_rndne_f32 %" #i ", %" #i "\n"
+DEFK(k2_rndne, J_RNDNE)
+#define J_FLOOR(i) "v_floor_f32 %" #i ", %" #i "\n"
+DEFK(k2_floor, J_FLOOR)
+#define J_MBCNT(i) "v_mbcnt_lo_u32_b32 %" #i ", %8, %" #i "\n"
+DEFK(k2_mbcnt, J_MBCNT)
+#define J_READLANE(i) "v_readfirstlane_b32 s20, %" #i "\n"
+DEFK(k2_readlane, J_READLANE)
+#define J_MUL_LEGACY(i) "v_mul_legacy_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_mul_legacy, J_MUL_LEGACY)
+#define J_LDEXP(i) "v_ldexp_f32 %" #i ", %" #i ", %8\n"
+DEFK(k2_ldexp, J_LDEXP)
+#define J_SAD(i) "v_sad_u32 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_sad, J_SAD)
+#define J_CVTPK(i) "v_cvt_pk_u16_u32 %" #i ", %" #i ", %8\n"
+DEFK(k2_cvtpk, J_CVTPK)
+#define J_PKMUL(i) "v_pk_mul_lo_u16 %" #i ", %" #i ", %8\n"
+DEFK(k2_pkmul, J_PKMUL)
+#define J_PKMAX(i) "v_pk_max_i16 %" #i ", %" #i ", %8\n"
+DEFK(k2_pkmax, J_PKMAX)
+#define J_PKLSHL(i) "v_pk_lshlrev_b16 %" #i ", 1, %" #i "\n"
+DEFK(k2_pklshl, J_PKLSHL)
+#define J_PKSUB(i) "v_pk_sub_i16 %" #i ", %" #i ", %8\n"
+DEFK(k2_pksub, J_PKSUB)
+#define J_DOT2(i) "v_dot2_u32_u16 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_dot2, J_DOT2)
+#define J_DOT4(i) "v_dot4_u32_u8 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_dot4, J_DOT4)
+#define J_MADU16(i) "v_mad_u32_u16 %" #i ", %" #i ", %8, %9\n"
+DEFK(k2_madu16, J_MADU16)
+#define J_ADDCO(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
+DEFK(k2_addco, J_ADDCO)
+
 // 64-bit / double forms: 4 chains of register pairs
 #define BODY4D(INS) \
   asm volatile(INS(0) INS(1) INS(2) INS(3) INS(0) INS(1) INS(2) INS(3) INS(0) INS(1) INS(2) INS(3) INS(0) INS(1) INS(2) INS(3) \
@@ -155,6 +254,55 @@ int main() {
     {"v_mad_u64_u32", k_mad64, 16, 0}, {"v_lshlrev_b64", k_lshl64, 16, 0}, {"v_rsq_f64", k_rsq64, 16, 0},
     {"v_sqrt_f64", k_sqrt64, 16, 0}, {"v_rcp_f64", k_rcp64, 16, 0}, {"v_cvt_f64_i32", k_cvt64, 16, 0},
     {"v_pk_fma_f32", k_pkfma32, 16, 0}, {"v_cmp_lt_f64", k_cmp64, 16, 0}, {"v_cmp_lt_u64", k_cmpu64, 16, 0},
+    {"v_sub_u32", k2_sub, 16, 0},
+    {"v_or_b32", k2_or, 16, 0},
+    {"v_xor_b32", k2_xor, 16, 0},
+    {"v_min_f32", k2_minf, 16, 0},
+    {"v_max_f32", k2_maxf, 16, 0},
+    {"v_add_f32", k2_addf, 16, 0},
+    {"v_mul_f32", k2_mulf, 16, 0},
+    {"v_sub_f32", k2_subf, 16, 0},
+    {"v_min_u32", k2_minu, 16, 0},
+    {"v_max_i32", k2_maxi, 16, 0},
+    {"v_lshrrev_b32", k2_lshr, 16, 0},
+    {"v_ashrrev_i32", k2_ashr, 16, 0},
+    {"v_and_or_b32", k2_andor, 16, 0},
+    {"v_bfi_b32", k2_bfi, 16, 0},
+    {"v_not_b32", k2_not, 16, 0},
+    {"v_mad_i32_i24", k2_madi24, 16, 0},
+    {"v_fmac_f32", k2_fmac, 16, 0},
+    {"v_cvt_f32_u32", k2_cvtfu, 16, 0},
+    {"v_min3_f32", k2_min3f, 16, 0},
+    {"v_med3_f32", k2_med3f, 16, 0},
+    {"v_alignbit_b32", k2_alignbit, 16, 0},
+    {"v_cmp_lt_f32", k2_cmpf, 16, 0},
+    {"v_cmp_lt_u32", k2_cmpu, 16, 0},
+    {"v_cmp_lt_i32", k2_cmpi, 16, 0},
+    {"v_cmp_lt_u32", k2_cmpx, 16, 0},
+    {"v_cndmask_b32", k2_cndsg, 16, 0},
+    {"v_lshl_or_b32", k2_lshlor, 16, 0},
+    {"v_or3_b32", k2_or3, 16, 0},
+    {"v_xad_u32", k2_xad, 16, 0},
+    {"v_add_lshl_u32", k2_addlshl, 16, 0},
+    {"v_subrev_u32", k2_subrev, 16, 0},
+    {"v_bitop3_b32", k2_bitop3, 16, 0},
+    {"v_max_f32", k2_maxf64, 16, 0},
+    {"v_rndne_f32", k2_rndne, 16, 0},
+    {"v_floor_f32", k2_floor, 16, 0},
+    {"v_mbcnt_lo_u32_b32", k2_mbcnt, 16, 0},
+    {"v_readfirstlane_b32", k2_readlane, 16, 0},
+    {"v_mul_legacy_f32", k2_mul_legacy, 16, 0},
+    {"v_ldexp_f32", k2_ldexp, 16, 0},
+    {"v_sad_u32", k2_sad, 16, 0},
+    {"v_cvt_pk_u16_u32", k2_cvtpk, 16, 0},
+    {"v_pk_mul_lo_u16", k2_pkmul, 16, 0},
+    {"v_pk_max_i16", k2_pkmax, 16, 0},
+    {"v_pk_lshlrev_b16", k2_pklshl, 16, 0},
+    {"v_pk_sub_i16", k2_pksub, 16, 0},
+    {"v_dot2_u32_u16", k2_dot2, 16, 0},
+    {"v_dot4_u32_u8", k2_dot4, 16, 0},
+    {"v_mad_u32_u16", k2_madu16, 16, 0},
+    {"v_add_co_u32", k2_addco, 16, 0},
     {"ds_read_b32 conflict-free", k_ldsread, 16, 16384}, {"ds_read_b32 F[row][8] pattern", k_ldsread_stride8, 16, 32768},
   };
   printf("%-32s", "cycles per wave-instr per SIMD");

@@ -562,10 +562,6 @@ int GridFor(int64_t work_items, int block)
 }  // namespace
 
 // Defined in edt_line_kernels.hip / edt_hull_kernels.hip.
-hipError_t LaunchPassYSeq(const int16_t* in16, int32_t* out32, const SdfParams& p,
-                          hipStream_t stream, bool* handled);
-hipError_t LaunchPassXSeqFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                                  const SdfParams& p, hipStream_t stream, bool* handled);
 hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                            hipStream_t stream);
 hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -702,8 +698,7 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, 
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err = (variant == EdtVariant::kSeq) ? LaunchPassYSeq(in16, out32, p, stream, &handled)
-                                                         : LaunchPassYHull(in16, out32, p, stream, &handled);
+    const hipError_t err = LaunchPassYHull(in16, out32, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;
@@ -721,9 +716,7 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
-    const hipError_t err = (variant == EdtVariant::kSeq)
-                               ? LaunchPassXSeqFinalize(in32, sdf, minmax_enc, p, stream, &handled)
-                               : LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
+    const hipError_t err = LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
     if (handled || err != hipSuccess) return err;
   }
   const int64_t total = p.nx * p.ny * p.nz;

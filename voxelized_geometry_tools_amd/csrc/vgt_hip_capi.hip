@@ -397,7 +397,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 3)
+  if (!ctx || variant < 0 || variant > 3 || variant == 2)  // 2 is not a variant
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;

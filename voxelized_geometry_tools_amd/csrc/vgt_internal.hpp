@@ -48,9 +48,8 @@ struct SlabLineCarry
 
 // kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
 // straight from HBM (also the fallback for axes the tiled kernels do not cover); kLine: line sweep
-// with stacks in the workspace; kSeq: second-generation LDS-tiled envelope passes
-// (edt_seq_kernels.hip).  All exact; 1 and 3 exist for cross-checking.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kSeq = 2, kLine = 3 };
+// with stacks in the workspace.  All exact; 1 and 3 exist for cross-checking.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kLine = 3 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
