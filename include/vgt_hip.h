@@ -301,6 +301,20 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
                                 void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                                 float* kernel_ms);
 
+/* ---- multi-GPU from ONE process, host buffers in and out: the large-grid branch of
+ *      OccupancyMap::ExtractSignedDistanceFieldFloat (S/occupancy_map.cpp:256-260;
+ *      I/occupancy_map.hpp:174-210).  The grid is cut into min(num_devices, nz) Z slabs, slab r runs
+ *      on devices[r]: strided upload of occupancy[:, :, z0:z1], the slab pipeline above, ONE exchange
+ *      of the per-line summaries (rccl ncclAllGather, one call per device in a group), download.
+ *      The N uploads / pipelines / downloads run concurrently on per-device streams; the caller's
+ *      arrays are page-locked for the duration of the call when possible.  A device may be listed
+ *      more than once (several slabs on one GPU); rccl cannot form a communicator then, and the
+ *      summaries are copied slab to slab instead.  Result and extrema are bit-identical to
+ *      vgt_hip_sdf_from_occupancy_f32 on one device.  Blocking. */
+int vgt_hipx_sdf_multi(const int* devices, int num_devices, const float* occupancy_host, int64_t nx,
+                       int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
+                       int add_virtual_border, float* sdf_host, float* out_min, float* out_max);
+
 #ifdef __cplusplus
 }
 #endif

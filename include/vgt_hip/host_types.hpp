@@ -241,6 +241,10 @@ struct SignedDistanceFieldGenerationParameters
   bool unknown_is_filled = true;
   bool add_virtual_border = false;
   int hip_device = 0;
+  // Large grids: when not empty, the field is extracted on these devices, one Z slab per entry
+  // (vgt_hipx_sdf_multi); a device may be listed more than once to cut the grid into more slabs
+  // than there are GPUs.
+  std::vector<int> hip_devices;
 };
 
 // SignedDistanceField<float>: values + the minimum / maximum cached by Lock()

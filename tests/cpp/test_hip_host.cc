@@ -115,6 +115,52 @@ static void SdfGenerationTests()
   }
 }
 
+// The large-grid branch (vgt_hipx_sdf_multi: one process, one Z slab per listed device).  With one GPU the
+// slabs share device 0 ({0, 0}, {0, 0, 0}: summaries copied slab to slab) or there is one slab ({0}: the RCCL
+// communicator path with one rank); every variant must reproduce the single-device field bit for bit.
+static void MultiDeviceSdfTests()
+{
+  OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 0.05, 2.0, 1.5, 3.0, 0.0f);
+  uint64_t state = 12345;
+  auto next = [&state]() {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    return static_cast<uint32_t>(state >> 33);
+  };
+  for (int64_t x = 0; x < m.NumXVoxels(); x++)
+    for (int64_t y = 0; y < m.NumYVoxels(); y++)
+      for (int64_t z = 0; z < m.NumZVoxels(); z++)
+      {
+        const uint32_t r = next() % 1000;
+        if (r < 15) m.SetIndex(x, y, z, 1.0f);
+        else if (r < 20) m.SetIndex(x, y, z, 0.5f);
+      }
+  FillBox(m, 5, 20, 3, 11, 20, 47);  // a solid that spans several slabs
+  for (const bool border : {false, true})
+  {
+    SignedDistanceFieldGenerationParameters single;
+    single.add_virtual_border = border;
+    const SignedDistanceField want = ExtractSignedDistanceField(m, single);
+    for (const std::vector<int>& devices : {std::vector<int>{0}, std::vector<int>{0, 0}, std::vector<int>{0, 0, 0}})
+    {
+      SignedDistanceFieldGenerationParameters multi = single;
+      multi.hip_devices = devices;
+      const SignedDistanceField got = ExtractSignedDistanceField(m, multi);
+      EXPECT_TRUE(got.locked);
+      EXPECT_TRUE(std::memcmp(got.grid.GetImmutableRawData().data(), want.grid.GetImmutableRawData().data(),
+                              want.grid.GetImmutableRawData().size() * sizeof(float)) == 0);
+      EXPECT_EQ(got.minimum, want.minimum);
+      EXPECT_EQ(got.maximum, want.maximum);
+    }
+  }
+  {
+    SignedDistanceFieldGenerationParameters bad;
+    bad.hip_devices = {9999};
+    bool threw = false;
+    try { (void)ExtractSignedDistanceField(m, bad); } catch (const std::runtime_error&) { threw = true; }
+    EXPECT_TRUE(threw);
+  }
+}
+
 // ---- test/pointcloud_voxelization_test.cpp ----
 class VectorPointCloudWrapper : public PointCloudWrapper
 {
@@ -347,6 +393,7 @@ int main(int argc, char** argv)
   if (!no_device)
   {
     SdfGenerationTests();
+    MultiDeviceSdfTests();
     TaggedObjectSdfTests();
     PointCloudVoxelizationTests(1);
     PointCloudVoxelizationTests(4);

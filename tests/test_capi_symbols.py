@@ -13,7 +13,7 @@ from voxelized_geometry_tools_amd import capi
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "vgt_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vgt_hip_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(vgt_hipx?_[a-z0-9_]+)\s*\(", text)))
 
 
 @pytest.fixture(scope="module")

@@ -221,6 +221,30 @@ def test_z_slab_pipeline_long_axes(ctx, oracle, shape, nslabs):
         assert (lo, hi) == (wlo, whi), (dist, shape)
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 7])
+def test_multi_device_entry_point(oracle, devices):
+    """vgt_hipx_sdf_multi (one process, one Z slab per listed device, host buffers) against the oracle.  On one
+    GPU the slabs share device 0: [0] runs the RCCL communicator path with a single rank, repeated devices the
+    slab-to-slab copies; more slabs than Z voxels are clamped."""
+    for shape, dist, vb in (((33, 47, 70), "spheres", False), ((40, 24, 96), "unknown_mix", True),
+                            ((9, 11, 5), "salt", False), ((16, 16, 40), "empty", False), ((1, 1, 3), "single", False)):
+        occ = synthetic.make_occupancy(shape, dist, seed=21)
+        want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.03, True, vb)
+        got, lo, hi = capi.sdf_multi(devices, occ, 0.03, True, vb)
+        assert bits_equal(got, want), (shape, dist, devices)
+        assert (lo, hi) == (wlo, whi), (shape, dist, devices)
+
+
+def test_multi_device_argument_errors():
+    occ = np.zeros((4, 4, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        capi.sdf_multi([0], occ, 0.0)
+    with pytest.raises(ValueError):
+        capi.sdf_multi([], occ, 0.1)
+    with pytest.raises(capi.VgtHipError):
+        capi.sdf_multi([0, 4096], occ, 0.1)
+
+
 @pytest.mark.parametrize("shape", [(1100, 6, 40), (5, 1500, 33), (2048, 4, 16), (3, 2049, 20),
                                    (2100, 3, 8), (4, 5, 1100), (2, 3, 2500)])
 def test_long_axes(ctx, oracle, shape):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vgt_hip_sdf_from_mask_u8": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _p, _p, _p]),
     "vgt_hip_sdf_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vgt_hip_sdf_workspace_bytes_for_variant": (_sz, [_i64, _i64, _i64, _int]),
+    "vgt_hipx_sdf_multi": (_int, [_p, _int, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
@@ -300,6 +301,22 @@ class Context:
 
     def filter_grid(self, occupancy):
         return FilterGrid(self, occupancy)
+
+
+def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtual_border=False):
+    """vgt_hipx_sdf_multi: one process, one Z slab per entry of `devices` (a device may repeat)."""
+    lib = load()
+    occ = np.ascontiguousarray(occupancy, dtype=np.float32)
+    if occ.ndim != 3:
+        raise ValueError("occupancy must be (nx, ny, nz)")
+    nx, ny, nz = occ.shape
+    devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+    out = np.empty(occ.shape, dtype=np.float32)
+    lo, hi = _f32(), _f32()
+    check(lib.vgt_hipx_sdf_multi(devs, len(devices), _ptr(occ) if occ.size else None, nx, ny, nz, float(resolution),
+                                 int(bool(unknown_is_filled)), int(bool(add_virtual_border)), _ptr(out),
+                                 ctypes.byref(lo), ctypes.byref(hi)))
+    return out, lo.value, hi.value
 
 
 def sdf_workspace_bytes(shape, variant=0):

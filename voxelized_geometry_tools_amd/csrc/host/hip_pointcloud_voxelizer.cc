@@ -176,14 +176,27 @@ SignedDistanceField ExtractSignedDistanceField(
     const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters)
 {
   if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
-  vgt_hip_ctx* ctx = nullptr;
-  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
-    throw std::runtime_error(std::string("HIP SDF backend is not available: ") +
-                             vgt_hip_last_error());
   SignedDistanceField sdf;
   sdf.oob_value = parameters.oob_value;
   sdf.grid = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
                        map.NumYVoxels(), map.NumZVoxels(), parameters.oob_value);
+  if (!parameters.hip_devices.empty())
+  {
+    // the large-grid branch: one Z slab per listed device, one process, one RCCL exchange
+    const int rc = vgt_hipx_sdf_multi(
+        parameters.hip_devices.data(), static_cast<int>(parameters.hip_devices.size()),
+        map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(), map.NumZVoxels(), map.Resolution(),
+        parameters.unknown_is_filled ? 1 : 0, parameters.add_virtual_border ? 1 : 0,
+        sdf.grid.GetMutableRawData().data(), &sdf.minimum, &sdf.maximum);
+    if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(vgt_hip_last_error());
+    if (rc != VGT_HIP_OK) throw std::runtime_error(std::string("HIP SDF backend: ") + vgt_hip_last_error());
+    sdf.locked = true;
+    return sdf;
+  }
+  vgt_hip_ctx* ctx = nullptr;
+  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
+    throw std::runtime_error(std::string("HIP SDF backend is not available: ") +
+                             vgt_hip_last_error());
   const int rc = vgt_hip_sdf_from_occupancy_f32(
       ctx, map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(), map.NumZVoxels(),
       map.Resolution(), parameters.unknown_is_filled ? 1 : 0,

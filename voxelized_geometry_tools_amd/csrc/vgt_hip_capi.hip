@@ -84,6 +84,13 @@ int Fail(int code, const std::string& msg)
   return code;
 }
 
+}  // namespace
+namespace vgt
+{
+void SetLastError(const std::string& message) { g_last_error = message; }
+}  // namespace vgt
+namespace
+{
 int FailHip(const char* what, hipError_t err)
 {
   g_last_error = std::string("[") + what + "] HIP error [" + hipGetErrorString(err) + "]";

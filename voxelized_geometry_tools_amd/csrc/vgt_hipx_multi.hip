@@ -1,0 +1,254 @@
+// vgt_hipx_sdf_multi: one process drives N devices through the Z-slab pipeline of vgt_hip.h
+// (slab scan + per-line summaries -> ONE all-gather -> carries -> fix-up -> Y / X passes).
+// This is the large-grid branch of OccupancyMap::ExtractSignedDistanceFieldFloat
+// (S/occupancy_map.cpp:256-260): the caller of the reference is a single process with the grid
+// in host memory, so the N > 1 path has to be reachable from C++ without torch.distributed.
+//
+// Data movement: the slab of device r is occupancy[:, :, z0_r : z1_r] -- nx*ny rows of nzl floats at
+// a pitch of nz floats in the caller's array -- moved by hipMemcpy2DAsync on the device's own
+// stream (the caller's arrays are page-locked with hipHostRegister for the duration of the call
+// when the driver allows it), so the N uploads, the N pipelines and the N downloads overlap.
+// Exchange: rccl's ncclAllGather (one call per device inside a group, 8 bytes per (x, y) line and
+// slab) when the devices are distinct; when one device appears more than once in `devices`
+// (several slabs on one GPU: the single-GPU test of this path, or a grid that does not fit one
+// GPU's workspace in one piece) rccl cannot form a communicator and the summaries are copied
+// slab to slab with hipMemcpyPeerAsync instead.  The field's extrema are reduced on the host: this
+// process already holds every device's (min, max) pair.
+#include "../../include/vgt_hip.h"
+
+#include "vgt_internal.hpp"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace
+{
+struct Slab
+{
+  int device = -1;
+  int64_t z0 = 0, nzl = 0;
+  vgt_hip_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t summary_ready = nullptr;
+  float* occ = nullptr;
+  float* sdf = nullptr;
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  void* summary = nullptr;
+  void* gathered = nullptr;
+  void* carries = nullptr;
+  float* minmax = nullptr;
+  float minmax_host[2] = {0.0f, 0.0f};
+};
+
+struct MultiState
+{
+  std::vector<Slab> slabs;
+  std::vector<ncclComm_t> comms;
+  bool registered_in = false, registered_out = false;
+  const void* host_in = nullptr;
+  void* host_out = nullptr;
+
+  ~MultiState()
+  {
+    for (Slab& s : slabs)
+    {
+      if (s.device < 0) continue;
+      (void)hipSetDevice(s.device);
+      if (s.stream) (void)hipStreamSynchronize(s.stream);
+    }
+    for (ncclComm_t c : comms)
+      if (c) (void)ncclCommDestroy(c);
+    for (Slab& s : slabs)
+    {
+      if (s.device < 0) continue;
+      (void)hipSetDevice(s.device);
+      if (s.ctx) vgt_hip_destroy(s.ctx);  // drains the stream it was given first
+      if (s.summary_ready) (void)hipEventDestroy(s.summary_ready);
+      if (s.stream) (void)hipStreamDestroy(s.stream);
+      for (void* p : {static_cast<void*>(s.occ), static_cast<void*>(s.sdf), s.workspace, s.summary, s.gathered,
+                      s.carries, static_cast<void*>(s.minmax)})
+        if (p) (void)hipFree(p);
+    }
+    if (registered_in) (void)hipHostUnregister(const_cast<void*>(host_in));
+    if (registered_out) (void)hipHostUnregister(host_out);
+  }
+};
+
+int FailMulti(int code, const std::string& msg)
+{
+  vgt::SetLastError(msg);
+  return code;
+}
+
+#define VGTX_HIP(expr, what)                                                                           \
+  do                                                                                                   \
+  {                                                                                                    \
+    const hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                              \
+      return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[") + (what) + "] HIP error [" + hipGetErrorString(e_) + "]"); \
+  } while (0)
+#define VGTX_NCCL(expr, what)                                                                          \
+  do                                                                                                   \
+  {                                                                                                    \
+    const ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess)                                                                             \
+      return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[") + (what) + "] RCCL error [" + ncclGetErrorString(r_) + "]"); \
+  } while (0)
+#define VGTX_CALL(expr)                  \
+  do                                     \
+  {                                      \
+    const int rc_ = (expr);              \
+    if (rc_ != VGT_HIP_OK) return rc_;   \
+  } while (0)
+}  // namespace
+
+extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const float* occupancy_host, int64_t nx,
+                                  int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
+                                  int add_virtual_border, float* sdf_host, float* out_min, float* out_max)
+{
+  if (!devices || !occupancy_host || !sdf_host) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (num_devices <= 0) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "num_devices must be > 0");
+  if (nx <= 0 || ny <= 0 || nz <= 0) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "grid extents must be positive");
+  if (nx > vgt::kMaxExtent || ny > vgt::kMaxExtent || nz > vgt::kMaxExtent)
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "grid extent exceeds 16384 voxels on an axis");
+  if (!(resolution > 0.0) || !std::isfinite(resolution))
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "Grid must have uniform, positive resolution");
+  int device_count = 0;
+  if (hipGetDeviceCount(&device_count) != hipSuccess || device_count <= 0)
+    return FailMulti(VGT_HIP_ERR_UNAVAILABLE, "no usable HIP device (libvgt_hip has no CPU fallback)");
+  for (int i = 0; i < num_devices; i++)
+    if (devices[i] < 0 || devices[i] >= device_count)
+      return FailMulti(VGT_HIP_ERR_UNAVAILABLE, "device " + std::to_string(devices[i]) + " out of range for " +
+                                                    std::to_string(device_count) + " devices");
+
+  // slabs along Z, as equal as possible, earlier slabs take the remainder (= multi_gpu.slab_bounds)
+  const int world = static_cast<int>(std::min<int64_t>(num_devices, nz));
+  MultiState st;
+  st.slabs.resize(static_cast<size_t>(world));
+  {
+    const int64_t share = nz / world, extra = nz % world;
+    int64_t z = 0;
+    for (int r = 0; r < world; r++)
+    {
+      st.slabs[r].device = devices[r];
+      st.slabs[r].z0 = z;
+      st.slabs[r].nzl = share + (r < extra ? 1 : 0);
+      z += st.slabs[r].nzl;
+    }
+  }
+  bool distinct = true;
+  for (int a = 0; a < world; a++)
+    for (int b = a + 1; b < world; b++)
+      if (st.slabs[a].device == st.slabs[b].device) distinct = false;
+
+  const size_t lines = static_cast<size_t>(nx * ny);
+  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(nx, ny);  // 8 bytes per line
+  const size_t total_bytes = static_cast<size_t>(nx * ny * nz) * sizeof(float);
+  // page-lock the caller's arrays so that the strided slab copies are true asynchronous DMA (best effort)
+  st.host_in = occupancy_host;
+  st.host_out = sdf_host;
+  st.registered_in = hipHostRegister(const_cast<float*>(occupancy_host), total_bytes, hipHostRegisterPortable) == hipSuccess;
+  st.registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
+  (void)hipGetLastError();
+
+  // per slab: context on its own stream, buffers, upload, slab scan + summary
+  for (Slab& s : st.slabs)
+  {
+    VGTX_HIP(hipSetDevice(s.device), "set device");
+    VGTX_CALL(vgt_hip_create(s.device, -1, &s.ctx));
+    VGTX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "create stream");
+    VGTX_HIP(hipEventCreateWithFlags(&s.summary_ready, hipEventDisableTiming), "create event");
+    VGTX_CALL(vgt_hip_set_stream(s.ctx, s.stream));
+    const size_t slab_voxels = lines * static_cast<size_t>(s.nzl);
+    s.workspace_bytes = vgt_hip_sdf_workspace_bytes(nx, ny, s.nzl);
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.occ), slab_voxels * sizeof(float)), "allocate slab occupancy");
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.sdf), slab_voxels * sizeof(float)), "allocate slab SDF");
+    VGTX_HIP(hipMalloc(&s.workspace, s.workspace_bytes), "allocate slab workspace");
+    VGTX_HIP(hipMalloc(&s.summary, record_bytes), "allocate slab summary");
+    VGTX_HIP(hipMalloc(&s.gathered, record_bytes * world), "allocate gathered summaries");
+    VGTX_HIP(hipMalloc(&s.carries, record_bytes), "allocate slab carries");
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.minmax), 256), "allocate extrema");
+    VGTX_HIP(hipMemcpy2DAsync(s.occ, static_cast<size_t>(s.nzl) * sizeof(float), occupancy_host + s.z0,
+                              static_cast<size_t>(nz) * sizeof(float), static_cast<size_t>(s.nzl) * sizeof(float), lines,
+                              hipMemcpyHostToDevice, s.stream),
+             "copy slab occupancy to device");
+    VGTX_CALL(vgt_hip_sdf_slab_begin_dev(s.ctx, s.occ, nx, ny, s.nzl, s.z0, unknown_is_filled, s.workspace,
+                                         s.workspace_bytes, s.summary, nullptr));
+    VGTX_HIP(hipEventRecord(s.summary_ready, s.stream), "record event");
+  }
+
+  // the one exchange: every slab receives every slab's per-line summary
+  if (distinct)
+  {
+    st.comms.assign(static_cast<size_t>(world), nullptr);
+    std::vector<int> devs(static_cast<size_t>(world));
+    for (int r = 0; r < world; r++) devs[r] = st.slabs[r].device;
+    VGTX_NCCL(ncclCommInitAll(st.comms.data(), world, devs.data()), "ncclCommInitAll");
+    VGTX_NCCL(ncclGroupStart(), "ncclGroupStart");
+    for (int r = 0; r < world; r++)
+    {
+      Slab& s = st.slabs[r];
+      // 8-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
+      const ncclResult_t res = ncclAllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
+                                             st.comms[r], s.stream);
+      if (res != ncclSuccess)
+      {
+        (void)ncclGroupEnd();
+        return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[ncclAllGather] RCCL error [") + ncclGetErrorString(res) + "]");
+      }
+    }
+    VGTX_NCCL(ncclGroupEnd(), "ncclGroupEnd");
+  }
+  else
+  {
+    for (int r = 0; r < world; r++)
+    {
+      Slab& dst = st.slabs[r];
+      VGTX_HIP(hipSetDevice(dst.device), "set device");
+      for (int q = 0; q < world; q++)
+      {
+        Slab& src = st.slabs[q];
+        VGTX_HIP(hipStreamWaitEvent(dst.stream, src.summary_ready, 0), "wait for summary");
+        char* to = static_cast<char*>(dst.gathered) + static_cast<size_t>(q) * record_bytes;
+        if (src.device == dst.device)
+          VGTX_HIP(hipMemcpyAsync(to, src.summary, record_bytes, hipMemcpyDeviceToDevice, dst.stream),
+                   "copy summary between slabs");
+        else
+          VGTX_HIP(hipMemcpyPeerAsync(to, dst.device, src.summary, src.device, record_bytes, dst.stream),
+                   "copy summary between slabs");
+      }
+    }
+  }
+
+  // per slab: carries, fix-up, Y and X passes, download
+  for (int r = 0; r < world; r++)
+  {
+    Slab& s = st.slabs[r];
+    VGTX_HIP(hipSetDevice(s.device), "set device");
+    VGTX_CALL(vgt_hip_sdf_slab_carries_dev(s.ctx, s.gathered, world, r, nx, ny, s.carries));
+    VGTX_CALL(vgt_hip_sdf_slab_finish_dev(s.ctx, nx, ny, s.nzl, s.z0, nz, resolution, add_virtual_border, s.carries,
+                                          s.sdf, s.workspace, s.workspace_bytes, s.minmax, nullptr));
+    VGTX_HIP(hipMemcpy2DAsync(sdf_host + s.z0, static_cast<size_t>(nz) * sizeof(float), s.sdf,
+                              static_cast<size_t>(s.nzl) * sizeof(float), static_cast<size_t>(s.nzl) * sizeof(float), lines,
+                              hipMemcpyDeviceToHost, s.stream),
+             "copy slab SDF to host");
+    VGTX_HIP(hipMemcpyAsync(s.minmax_host, s.minmax, 2 * sizeof(float), hipMemcpyDeviceToHost, s.stream),
+             "copy extrema to host");
+  }
+  float lo = INFINITY, hi = -INFINITY;
+  for (Slab& s : st.slabs)
+  {
+    VGTX_HIP(hipSetDevice(s.device), "set device");
+    VGTX_HIP(hipStreamSynchronize(s.stream), "wait for slab");
+    lo = std::min(lo, s.minmax_host[0]);
+    hi = std::max(hi, s.minmax_host[1]);
+  }
+  if (out_min) *out_min = lo;
+  if (out_max) *out_max = hi;
+  return VGT_HIP_OK;
+}

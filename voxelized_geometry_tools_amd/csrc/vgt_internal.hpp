@@ -7,8 +7,14 @@
 #include <cstddef>
 #include <cstdint>
 
+#include <string>
+
 namespace vgt
 {
+// Sets the calling thread's vgt_hip_last_error() message (for translation units other than
+// vgt_hip_capi.hip that implement parts of the C ABI).
+void SetLastError(const std::string& message);
+
 // Intermediate encodings of the signed Euclidean distance transform.
 //  pass 1 (Z scan)  -> int16: +d for a free voxel, -d for a filled voxel, d = distance in
 //                      voxels along Z to the nearest voxel of the OTHER class,
