@@ -45,6 +45,7 @@ def parse_args():
                     help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -141,6 +142,52 @@ def cpu_baseline(budget_s):
                       "(oracle/vgt_oracle.c, -O3 -march=native)%s" % (
                           edge, dt, cores, "" if edge == 1024 else
                           "; 1024^3 did not fit the %.0f s budget / host RAM on this box" % budget_s)}
+
+
+def end_to_end(ctx, torch, occ_dev, shape, res):
+    """SURVEY 8d "second number": the same extraction through the host-pointer entry point of the C ABI
+    (vgt_hip_sdf_from_occupancy_f32: H2D + three passes + D2H), once from ordinary pageable host memory (what a
+    caller of the reference holds; the library page-locks it for the call) and once from pinned host memory,
+    next to the PCIe rates of plain pinned copies measured here."""
+    nbytes = int(np.prod(shape)) * 4
+    occ_pinned = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+    out_pinned = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+    occ_pinned.copy_(occ_dev)
+    torch.cuda.synchronize()
+    scratch = torch.empty(shape, dtype=torch.float32, device=occ_dev.device)
+
+    def timed(fn, repeat=2):
+        best = None
+        for _ in range(repeat):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
+    h2d = timed(lambda: scratch.copy_(occ_pinned, non_blocking=True))
+    d2h = timed(lambda: out_pinned.copy_(scratch, non_blocking=True))
+    del scratch
+    occ_np = occ_pinned.numpy()
+    out_np = out_pinned.numpy()
+    ctx.sdf_from_occupancy(occ_np, res, out=out_np)          # warm: the context allocates its cached buffers
+    pinned = timed(lambda: ctx.sdf_from_occupancy(occ_np, res, out=out_np))
+    occ_pageable = np.array(occ_np, copy=True)
+    out_pageable = np.zeros(shape, dtype=np.float32)         # zeros: pages touched before the timed call
+    pageable = timed(lambda: ctx.sdf_from_occupancy(occ_pageable, res, out=out_pageable))
+    same = bool(np.array_equal(out_pageable.view(np.uint32), out_np.view(np.uint32)))
+    ctx.trim()
+    bound = h2d + d2h
+    return {"end_to_end_ms": round(pageable * 1e3, 2), "end_to_end_pinned_ms": round(pinned * 1e3, 2),
+            "pcie_lower_bound_ms": round(bound * 1e3, 2),
+            "pcie_GBps": {"h2d": round(nbytes / h2d / 1e9, 1), "d2h": round(nbytes / d2h / 1e9, 1),
+                          "end_to_end": round(2 * nbytes / pageable / 1e9, 1),
+                          "end_to_end_pinned": round(2 * nbytes / pinned / 1e9, 1)},
+            "vs_pcie_lower_bound": round(pinned / bound, 3), "host_results_identical": same,
+            "note": "host-pointer entry point: H2D + Z scan + Y pass + X pass + D2H; end_to_end_ms from pageable "
+                    "host memory (page-locked by the library for the call), end_to_end_pinned_ms from pinned memory"}
 
 
 def launch_ranks(args):
@@ -284,6 +331,11 @@ def main():
                          "whole_sdf_frac": round(whole / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes_per_voxel": {"per_pass": 8, "whole_sdf": 24}},
         }
+        if not dist_on and not args.no_end_to_end:
+            try:
+                line["host_path"] = end_to_end(ctx, torch, occ, local_shape, res)
+            except Exception as exc:  # the headline number must not depend on host RAM for pinned buffers
+                line["host_path"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and not dist_on:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

@@ -57,6 +57,11 @@ int vgt_hip_device_name(int device, char* buffer, size_t buffer_size);
  *      HIP_THREADS_PER_BLOCK of the C++ glue land here. */
 int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx);
 void vgt_hip_destroy(vgt_hip_ctx* ctx);
+/* A context keeps the device buffers of its host-pointer entry points (SDF input / field /
+ * workspace, point-cloud staging) across calls, growing them on demand, so that repeated calls do
+ * not pay for hipMalloc / hipFree (the reference allocates per call, S/cuda_voxelization_helpers.cu:
+ * 676-680).  vgt_hip_trim gives that memory back (waits for the context's stream first). */
+int vgt_hip_trim(vgt_hip_ctx* ctx);
 /* Run all work of this context on an externally owned hipStream_t (e.g. the caller's
  * framework stream); NULL is HIP's legacy default stream.  vgt_hip_reset_stream goes back to the
  * context's own (non-blocking) stream.  Both drain the stream in use first. */

@@ -59,6 +59,10 @@ private:
 // reference rejects, std::runtime_error when no HIP device can be used (no CPU fallback).
 SignedDistanceField ExtractSignedDistanceField(
     const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters);
+// The free-standing SDF entry points share one context per device for the life of the process; that
+// context keeps its device buffers between calls (no hipMalloc / hipFree per extraction).  This
+// returns the memory (e.g. after one very large grid).
+void ReleaseCachedDeviceMemory();
 
 // ---- the other three map types ----
 // OccupancyComponentMap::ExtractSignedDistanceField<float> (occupancy_component_map.hpp:270-306).

@@ -107,6 +107,67 @@ def test_synthetic_cloud_counts_bit_exact(ctx, oracle, sensor):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("sensor", [(2.56, 2.56, 2.56), (-1.0, 2.56, 2.56)])
+def test_config3_full_size_counts_bit_exact(ctx, oracle, sensor):
+    """BASELINE config 3 at full size: the 1M-point synthetic cloud (1 % NaN, clipped and unclipped rays) into a
+    256^3 grid, sensor inside the grid (cloud A) and outside it (cloud B, slab-entry branch); every tracking
+    count against the CPU oracle, and the filtered grid.  This is the size at which the direction sort and the
+    per-workgroup LDS accumulation are active."""
+    n = 256
+    counts = (n, n, n)
+    vs = np.float32(5.12 / n)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(1_000_000, seed=42)
+    xf = synthetic.translation_xform(*sensor).astype(np.float32)
+    grids = ctx.tracking_grids(n ** 3, 1)
+    grids.raycast_f32(0, pts, 3.0, xf, vs, ivs, sizes, counts)
+    got = grids.retrieve(0, counts)
+    want = oracle.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+    assert got.sum() == want.sum() and got.sum() > 0
+    assert np.array_equal(got, want)
+    env = np.zeros(counts, dtype=np.float32)
+    env[:, :, 0] = 1.0
+    fg = ctx.filter_grid(env)
+    fg.filter(grids, 1.0, 1, 1)
+    assert np.array_equal(fg.retrieve(), oracle.filter_grids(want[None], env, 1.0, 1, 1, False))
+    fg.close()
+    grids.close()
+
+
+@pytest.mark.parametrize("kind", ["one_direction", "two_points", "tiny_grid", "f64"])
+def test_accumulation_table_corner_cases(ctx, oracle, kind):
+    """Clouds that stress the per-workgroup LDS accumulation: every ray identical (one hot chain of cells),
+    two alternating points, a grid with fewer cells than table slots, and the double-precision kernel."""
+    rng = np.random.default_rng(5)
+    npts = 70_000
+    counts = (48, 40, 56)
+    vs = np.float32(0.05)
+    if kind == "one_direction":
+        pts = np.tile(np.array([[1.1, 0.7, 0.9]], dtype=np.float32), (npts, 1))
+    elif kind == "two_points":
+        pts = np.tile(np.array([[1.1, 0.7, 0.9], [-0.8, 0.3, 1.2]], dtype=np.float32), (npts // 2, 1))
+    elif kind == "tiny_grid":
+        counts = (6, 5, 7)
+        vs = np.float32(0.3)
+        pts = (rng.standard_normal((npts, 3)) * 1.5).astype(np.float32)
+    else:
+        pts = (rng.standard_normal((npts, 3)) * 1.2).astype(np.float32)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    xf = synthetic.translation_xform(float(sizes[0]) * 0.4, float(sizes[1]) * 0.5, float(sizes[2]) * 0.45)
+    grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+    if kind == "f64":
+        sizes64 = [float(c) * float(vs) for c in counts]
+        grids.raycast_f64(0, pts.astype(np.float64), 2.0, xf.astype(np.float64), float(vs), 1.0 / float(vs), sizes64, counts)
+        want = oracle.raycast_f64(pts.astype(np.float64), 2.0, xf.astype(np.float64), float(vs), 1.0 / float(vs), sizes64, counts)
+    else:
+        grids.raycast_f32(0, pts, 2.0, xf.astype(np.float32), vs, ivs, sizes, counts)
+        want = oracle.raycast_f32(pts, 2.0, xf.astype(np.float32), vs, ivs, sizes, counts)
+    assert np.array_equal(grids.retrieve(0, counts), want), kind
+    grids.close()
+
+
 def test_concurrent_raycasts_from_host_threads(ctx, oracle):
     """RaycastPoints is called concurrently on one helper with distinct grid indices
     (device_pointcloud_voxelization.cpp:147-149)."""

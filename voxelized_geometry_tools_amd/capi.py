@@ -30,6 +30,7 @@ SIGNATURES = {
     "vgt_hip_device_name": (_int, [_int, ctypes.c_char_p, _sz]),
     "vgt_hip_create": (_int, [_int, _int, ctypes.POINTER(_p)]),
     "vgt_hip_destroy": (None, [_p]),
+    "vgt_hip_trim": (_int, [_p]),
     "vgt_hip_set_stream": (_int, [_p, _p]),
     "vgt_hip_reset_stream": (_int, [_p]),
     "vgt_hip_synchronize": (_int, [_p]),
@@ -187,6 +188,10 @@ class Context:
     def __exit__(self, *exc):
         self.close()
 
+    def trim(self):
+        """Frees the device buffers the context caches between host-pointer calls."""
+        check(self._lib.vgt_hip_trim(self.handle))
+
     def set_stream(self, stream_ptr):
         """Run on an external hipStream_t; 0 / None = HIP's legacy default stream (torch's default)."""
         check(self._lib.vgt_hip_set_stream(self.handle, _ptr(stream_ptr) if stream_ptr else None))
@@ -238,12 +243,15 @@ class Context:
 
     # ---- SDF ----
     def sdf_from_occupancy(self, occupancy, resolution, unknown_is_filled=True,
-                           add_virtual_border=False):
+                           add_virtual_border=False, out=None):
         occ = np.ascontiguousarray(occupancy, dtype=np.float32)
         if occ.ndim != 3:
             raise ValueError("occupancy must be (nx, ny, nz)")
         nx, ny, nz = occ.shape
-        out = np.empty(occ.shape, dtype=np.float32)
+        if out is None:
+            out = np.empty(occ.shape, dtype=np.float32)
+        elif out.shape != occ.shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of the occupancy's shape")
         lo, hi = _f32(), _f32()
         check(self._lib.vgt_hip_sdf_from_occupancy_f32(
             self.handle, _ptr(occ), nx, ny, nz, float(resolution), int(bool(unknown_is_filled)),

@@ -172,6 +172,45 @@ VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
                           std::chrono::duration<double>(done_time - raycasted_time).count());
 }
 
+namespace
+{
+// One context per device for the free-standing SDF entry points, created on first use and kept for
+// the life of the process (deliberately never destroyed: static destruction order against the HIP
+// runtime is not defined).  The context caches its device buffers, so a caller that extracts
+// fields repeatedly pays for context creation and hipMalloc once; the C ABI serialises concurrent
+// calls on one context.
+vgt_hip_ctx* SharedSdfContext(int device)
+{
+  static std::mutex guard;
+  static std::map<int, vgt_hip_ctx*>* contexts = new std::map<int, vgt_hip_ctx*>();
+  std::lock_guard<std::mutex> lock(guard);
+  auto found = contexts->find(device);
+  if (found != contexts->end()) return found->second;
+  vgt_hip_ctx* ctx = nullptr;
+  if (vgt_hip_create(device, -1, &ctx) != VGT_HIP_OK)
+    throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
+  (*contexts)[device] = ctx;
+  return ctx;
+}
+}  // namespace
+
+void ReleaseCachedDeviceMemory()
+{
+  // best effort: the shared contexts exist only for devices that were used
+  int count = 0;
+  if (vgt_hip_device_count(&count) != VGT_HIP_OK) return;
+  for (int d = 0; d < count; d++)
+  {
+    try
+    {
+      (void)vgt_hip_trim(SharedSdfContext(d));
+    }
+    catch (const std::exception&)
+    {
+    }
+  }
+}
+
 SignedDistanceField ExtractSignedDistanceField(
     const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters)
 {
@@ -193,17 +232,13 @@ SignedDistanceField ExtractSignedDistanceField(
     sdf.locked = true;
     return sdf;
   }
-  vgt_hip_ctx* ctx = nullptr;
-  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
-    throw std::runtime_error(std::string("HIP SDF backend is not available: ") +
-                             vgt_hip_last_error());
+  vgt_hip_ctx* ctx = SharedSdfContext(parameters.hip_device);
   const int rc = vgt_hip_sdf_from_occupancy_f32(
       ctx, map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(), map.NumZVoxels(),
       map.Resolution(), parameters.unknown_is_filled ? 1 : 0,
       parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(), &sdf.minimum,
       &sdf.maximum);
   const std::string msg = (rc == VGT_HIP_OK) ? std::string() : std::string(vgt_hip_last_error());
-  vgt_hip_destroy(ctx);
   if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
   if (rc != VGT_HIP_OK) throw std::runtime_error(msg);
   sdf.locked = true;  // min / max were computed on the device: Lock() has nothing left to scan

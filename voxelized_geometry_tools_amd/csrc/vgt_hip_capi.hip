@@ -14,6 +14,20 @@
 #include <string>
 #include <vector>
 
+// Host point clouds are uploaded and raycast on one of a few "upload lanes" (own stream + own staging
+// buffer), so that concurrent RaycastPoints calls of the reference's parallel cloud dispatch
+// (S/device_pointcloud_voxelization.cpp:147-149) overlap: cloud i+1's H2D copy runs beside cloud
+// i's kernel, and kernels into different tracking grids run side by side.
+struct UploadLane
+{
+  std::mutex mutex;
+  hipStream_t stream = nullptr;
+  hipEvent_t after_ctx = nullptr;  // orders the lane behind what the context's stream holds (grid zeroing)
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+};
+constexpr int kUploadLanes = 4;
+
 struct vgt_hip_ctx
 {
   int device = -1;
@@ -21,8 +35,10 @@ struct vgt_hip_ctx
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mutex;              // serialises enqueues + the staging buffer
-  void* stage = nullptr;         // device staging for host point clouds
-  size_t stage_bytes = 0;
+  UploadLane lanes[kUploadLanes];
+  std::atomic<unsigned> next_lane{0};
+  void* ray_scratch = nullptr;   // sort scratch of raycasts of device-resident clouds (context stream)
+  size_t ray_scratch_bytes = 0;
   float* minmax_out = nullptr;   // 2 floats (device) for host-facing SDF calls
   vgt::EdtVariant variant = vgt::EdtVariant::kDefault;
   // deferred per-kernel timing (vgt_hip_timing_start / _stop): 8 events per SDF call
@@ -30,6 +46,15 @@ struct vgt_hip_ctx
   std::vector<uint8_t> timing_kind;  // 1 = single-device call, 2 = slab begin + finish
   int timing_slots = 0;
   int timing_used = 0;
+  // Device buffers of the host-pointer SDF entry points (input, field, workspace), kept across calls
+  // and grown on demand: a caller that extracts fields repeatedly pays for hipMalloc / hipFree once.
+  // vgt_hip_trim() gives them back.
+  void* sdf_in = nullptr;
+  size_t sdf_in_bytes = 0;
+  void* sdf_out = nullptr;
+  size_t sdf_out_bytes = 0;
+  void* sdf_ws = nullptr;
+  size_t sdf_ws_bytes = 0;
   // Handles created from this context (grids, filter grids, cell grids) point back at it.  A
   // context destroyed while handles are alive releases its device resources at once but keeps this
   // struct until the last handle is gone, so handle destructors never touch freed memory.
@@ -120,6 +145,57 @@ void ReleaseChild(vgt_hip_ctx* ctx, int device)
 
 size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Grow-only device buffer.
+hipError_t Reserve(void** ptr, size_t* have, size_t need)
+{
+  if (*have >= need && *ptr) return hipSuccess;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr;
+  *have = 0;
+  const hipError_t err = hipMalloc(ptr, need);
+  if (err == hipSuccess) *have = need;
+  return err;
+}
+
+void FreeCachedSdfBuffers(vgt_hip_ctx* ctx)
+{
+  for (void** p : {&ctx->sdf_in, &ctx->sdf_out, &ctx->sdf_ws, &ctx->ray_scratch})
+  {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = 0;
+}
+
+// Page-locks a caller-owned host range for the duration of a call, unless it already is pinned
+// (hipHostMalloc / hipHostRegister by the caller): copies from pageable memory go through the
+// runtime's bounce buffers at a fraction of the PCIe rate and are not asynchronous.  Best effort:
+// when the driver refuses (limits, odd mappings) the copy simply takes the pageable path.
+class ScopedHostPin
+{
+public:
+  ScopedHostPin(const void* ptr, size_t bytes)
+  {
+    if (!ptr || bytes < (size_t{1} << 20)) return;  // small copies: registration costs more than it saves
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type == hipMemoryTypeHost) return;  // pinned already
+    (void)hipGetLastError();
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
+      registered_ = const_cast<void*>(ptr);
+    else
+      (void)hipGetLastError();
+  }
+  ~ScopedHostPin()
+  {
+    if (registered_) (void)hipHostUnregister(registered_);
+  }
+  ScopedHostPin(const ScopedHostPin&) = delete;
+  ScopedHostPin& operator=(const ScopedHostPin&) = delete;
+
+private:
+  void* registered_ = nullptr;
+};
+
 struct SdfWorkspace
 {
   int16_t* t16;
@@ -209,46 +285,43 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
   const size_t ws_bytes = vgt_hip_sdf_workspace_bytes_for_variant(p.nx, p.ny, p.nz, static_cast<int>(ctx->variant));
-  InT* in_dev = nullptr;
-  float* sdf_dev = nullptr;
-  void* ws_dev = nullptr;
-  int result = VGT_HIP_OK;
-  hipError_t err = hipMalloc(reinterpret_cast<void**>(&in_dev), nvox * sizeof(InT));
-  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&sdf_dev), nvox * sizeof(float));
-  if (err == hipSuccess) err = hipMalloc(&ws_dev, ws_bytes);
+  const ScopedHostPin pin_in(input_host, nvox * sizeof(InT));
+  const ScopedHostPin pin_out(sdf_host, nvox * sizeof(float));
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  hipError_t err = Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, nvox * sizeof(InT));
+  if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float));
+  if (err == hipSuccess) err = Reserve(&ctx->sdf_ws, &ctx->sdf_ws_bytes, ws_bytes);
   if (err != hipSuccess)
-    result = FailHip("allocate SDF buffers", err);
-  else
   {
-    std::lock_guard<std::mutex> lock(ctx->mutex);
-    hipStream_t s = ctx->stream;
-    err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
-    if (err != hipSuccess)
-      result = FailHip("copy occupancy to device", err);
-    else
-      result = RunSdfPipeline<InT>(ctx, in_dev, p, sdf_dev, ws_dev, ws_bytes, ctx->minmax_out,
-                                   nullptr);
-    if (result == VGT_HIP_OK)
-    {
-      float mm[2] = {0.0f, 0.0f};
-      err = hipMemcpyAsync(sdf_host, sdf_dev, nvox * sizeof(float), hipMemcpyDeviceToHost, s);
-      if (err == hipSuccess)
-        err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, s);
-      if (err == hipSuccess) err = hipStreamSynchronize(s);
-      if (err != hipSuccess)
-        result = FailHip("copy SDF to host", err);
-      else
-      {
-        if (out_min) *out_min = mm[0];
-        if (out_max) *out_max = mm[1];
-      }
-    }
-    else
-      (void)hipStreamSynchronize(s);
+    FreeCachedSdfBuffers(ctx);
+    return FailHip("allocate SDF buffers", err);
   }
-  if (in_dev) (void)hipFree(in_dev);
-  if (sdf_dev) (void)hipFree(sdf_dev);
-  if (ws_dev) (void)hipFree(ws_dev);
+  InT* in_dev = static_cast<InT*>(ctx->sdf_in);
+  float* sdf_dev = static_cast<float*>(ctx->sdf_out);
+  hipStream_t s = ctx->stream;
+  int result = VGT_HIP_OK;
+  err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
+  if (err != hipSuccess)
+    result = FailHip("copy occupancy to device", err);
+  else
+    result = RunSdfPipeline<InT>(ctx, in_dev, p, sdf_dev, ctx->sdf_ws, ctx->sdf_ws_bytes, ctx->minmax_out, nullptr);
+  if (result == VGT_HIP_OK)
+  {
+    float mm[2] = {0.0f, 0.0f};
+    err = hipMemcpyAsync(sdf_host, sdf_dev, nvox * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    if (err != hipSuccess)
+      result = FailHip("copy SDF to host", err);
+    else
+    {
+      if (out_min) *out_min = mm[0];
+      if (out_max) *out_max = mm[1];
+    }
+  }
+  else
+    (void)hipStreamSynchronize(s);
   return result;
 }
 
@@ -269,20 +342,64 @@ int CheckRaycastArgs(const vgt_hip_ctx* ctx, const vgt_hip_grids* grids, size_t 
   return VGT_HIP_OK;
 }
 
-// Grows the context's staging buffer (caller holds the mutex).
-int EnsureStage(vgt_hip_ctx* ctx, size_t bytes)
+// Releases the upload lanes' device resources (the caller has made sure nothing runs on them).
+void FreeUploadLanes(vgt_hip_ctx* ctx, bool destroy_streams)
 {
-  if (ctx->stage_bytes >= bytes) return VGT_HIP_OK;
-  if (ctx->stage)
+  for (UploadLane& lane : ctx->lanes)
   {
-    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain before regrowing staging buffer");
-    VGT_TRY_HIP(hipFree(ctx->stage), "free staging buffer");
-    ctx->stage = nullptr;
-    ctx->stage_bytes = 0;
+    std::lock_guard<std::mutex> lock(lane.mutex);
+    if (lane.stream) (void)hipStreamSynchronize(lane.stream);
+    if (lane.stage) (void)hipFree(lane.stage);
+    lane.stage = nullptr;
+    lane.stage_bytes = 0;
+    if (destroy_streams)
+    {
+      if (lane.after_ctx) (void)hipEventDestroy(lane.after_ctx);
+      if (lane.stream) (void)hipStreamDestroy(lane.stream);
+      lane.after_ctx = nullptr;
+      lane.stream = nullptr;
+    }
   }
-  const size_t want = AlignUp(bytes + bytes / 4, 1 << 20);
-  VGT_TRY_HIP(hipMalloc(&ctx->stage, want), "allocate staging buffer");
-  ctx->stage_bytes = want;
+}
+
+// Uploads `bytes` from host memory on a free upload lane, runs `launch(device_copy, lane_stream)` behind the
+// copy and waits for it: the host buffer may be released by the caller as soon as this returns
+// (S/cuda_voxelization_helpers.cu:676-699 frees its device copy at scope exit).  Calls on different lanes
+// overlap; work queued on the context's stream before the call (the zeroing of new tracking grids) is
+// ordered before the lane's work by an event, work queued after it follows the return of this call.
+template <typename Launch>
+int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratch_bytes, Launch launch)
+{
+  UploadLane& lane = ctx->lanes[ctx->next_lane.fetch_add(1) % kUploadLanes];
+  std::lock_guard<std::mutex> lane_lock(lane.mutex);
+  if (!lane.stream)
+  {
+    VGT_TRY_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking), "create upload stream");
+    VGT_TRY_HIP(hipEventCreateWithFlags(&lane.after_ctx, hipEventDisableTiming), "create upload event");
+  }
+  // staging copy of the cloud, followed by the kernel's scratch (256-byte aligned)
+  const size_t scratch_at = AlignUp(bytes, 256);
+  if (lane.stage_bytes < scratch_at + scratch_bytes)
+  {
+    VGT_TRY_HIP(hipStreamSynchronize(lane.stream), "drain before regrowing staging buffer");
+    if (lane.stage) VGT_TRY_HIP(hipFree(lane.stage), "free staging buffer");
+    lane.stage = nullptr;
+    lane.stage_bytes = 0;
+    const size_t total = scratch_at + scratch_bytes;
+    const size_t want = AlignUp(total + total / 4, 1 << 20);
+    VGT_TRY_HIP(hipMalloc(&lane.stage, want), "allocate staging buffer");
+    lane.stage_bytes = want;
+  }
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    VGT_TRY_HIP(hipEventRecord(lane.after_ctx, ctx->stream), "record event");
+  }
+  VGT_TRY_HIP(hipStreamWaitEvent(lane.stream, lane.after_ctx, 0), "order upload lane");
+  VGT_TRY_HIP(hipMemcpyAsync(lane.stage, host, bytes, hipMemcpyHostToDevice, lane.stream),
+              "Failed to copy points to the device");
+  VGT_TRY_HIP(launch(lane.stage, static_cast<char*>(lane.stage) + scratch_at, lane.stream),
+              "Failed to dispatch raycast kernel");
+  VGT_TRY_HIP(hipStreamSynchronize(lane.stream), "raycast");
   return VGT_HIP_OK;
 }
 }  // namespace
@@ -358,18 +475,29 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->stage) (void)hipFree(ctx->stage);
+  FreeUploadLanes(ctx, true);
   if (ctx->minmax_out) (void)hipFree(ctx->minmax_out);
+  FreeCachedSdfBuffers(ctx);
   for (hipEvent_t e : ctx->timing_events)
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-  ctx->stage = nullptr;
   ctx->minmax_out = nullptr;
   ctx->timing_events.clear();
   ctx->own_stream = nullptr;
   ctx->stream = nullptr;
   ctx->destroyed.store(true);
   if (ctx->children.load() == 0) delete ctx;  // otherwise the last handle's destroy frees it
+}
+
+int vgt_hip_trim(vgt_hip_ctx* ctx)
+{
+  if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
+  FreeCachedSdfBuffers(ctx);
+  FreeUploadLanes(ctx, false);
+  return VGT_HIP_OK;
 }
 
 int vgt_hip_set_stream(vgt_hip_ctx* ctx, void* hip_stream)
@@ -534,8 +662,19 @@ int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   std::lock_guard<std::mutex> lock(ctx->mutex);
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, 3, g, tracking,
-                                    ctx->threads_per_block, ctx->stream),
+  // stream order protects the scratch: the next call's kernels queue behind this one's
+  const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
+  if (scratch_bytes > ctx->ray_scratch_bytes)
+  {
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain before regrowing raycast scratch");
+    if (ctx->ray_scratch) (void)hipFree(ctx->ray_scratch);
+    ctx->ray_scratch = nullptr;
+    ctx->ray_scratch_bytes = 0;
+    VGT_TRY_HIP(hipMalloc(&ctx->ray_scratch, scratch_bytes + scratch_bytes / 4), "allocate raycast scratch");
+    ctx->ray_scratch_bytes = scratch_bytes + scratch_bytes / 4;
+  }
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, 3, g, tracking, ctx->threads_per_block,
+                                    ctx->ray_scratch, ctx->ray_scratch_bytes, ctx->stream),
               "Failed to dispatch raycast kernel");
   return VGT_HIP_OK;
 }
@@ -566,19 +705,13 @@ int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(float);
-  std::lock_guard<std::mutex> lock(ctx->mutex);
-  const int src = EnsureStage(ctx, bytes);
-  if (src != VGT_HIP_OK) return src;
-  // Stream order protects the staging buffer: this copy queues behind the previous kernel.
-  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, points_xyz_host, bytes, hipMemcpyHostToDevice,
-                             ctx->stream),
-              "Failed to copy points to the device");
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(static_cast<const float*>(ctx->stage), num_points, 3, g, tracking,
-                                    ctx->threads_per_block, ctx->stream),
-              "Failed to dispatch raycast kernel");
-  // The host buffer may be released by the caller as soon as we return.
-  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
-  return VGT_HIP_OK;
+  const int threads = ctx->threads_per_block;
+  const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
+  return UploadAndRun(ctx, points_xyz_host, bytes, scratch_bytes,
+                      [&](const void* points_dev, void* scratch, hipStream_t stream) {
+                        return vgt::LaunchRaycastF32(static_cast<const float*>(points_dev), num_points, 3, g, tracking,
+                                                     threads, scratch, scratch_bytes, stream);
+                      });
 }
 
 int vgt_hip_raycast_pointcloud2_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
@@ -613,17 +746,15 @@ int vgt_hip_raycast_pointcloud2_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * static_cast<size_t>(point_step);
-  std::lock_guard<std::mutex> lock(ctx->mutex);
-  const int src = EnsureStage(ctx, bytes);
-  if (src != VGT_HIP_OK) return src;
-  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, cloud_data_host, bytes, hipMemcpyHostToDevice, ctx->stream),
-              "Failed to copy points to the device");
-  const float* first = reinterpret_cast<const float*>(static_cast<const uint8_t*>(ctx->stage) + xyz_offset);
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(first, num_points, point_step / 4, g, tracking, ctx->threads_per_block,
-                                    ctx->stream),
-              "Failed to dispatch raycast kernel");
-  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
-  return VGT_HIP_OK;
+  const int threads = ctx->threads_per_block;
+  const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
+  return UploadAndRun(ctx, cloud_data_host, bytes, scratch_bytes,
+                      [&](const void* cloud_dev, void* scratch, hipStream_t stream) {
+                        const float* first =
+                            reinterpret_cast<const float*>(static_cast<const uint8_t*>(cloud_dev) + xyz_offset);
+                        return vgt::LaunchRaycastF32(first, num_points, point_step / 4, g, tracking, threads, scratch,
+                                                     scratch_bytes, stream);
+                      });
 }
 
 int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
@@ -652,17 +783,13 @@ int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(double);
-  std::lock_guard<std::mutex> lock(ctx->mutex);
-  const int src = EnsureStage(ctx, bytes);
-  if (src != VGT_HIP_OK) return src;
-  VGT_TRY_HIP(hipMemcpyAsync(ctx->stage, points_xyz_host, bytes, hipMemcpyHostToDevice,
-                             ctx->stream),
-              "Failed to copy points to the device");
-  VGT_TRY_HIP(vgt::LaunchRaycastF64(static_cast<const double*>(ctx->stage), num_points, g,
-                                    tracking, ctx->threads_per_block, ctx->stream),
-              "Failed to dispatch raycast kernel");
-  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "raycast");
-  return VGT_HIP_OK;
+  const int threads = ctx->threads_per_block;
+  const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
+  return UploadAndRun(ctx, points_xyz_host, bytes, scratch_bytes,
+                      [&](const void* points_dev, void* scratch, hipStream_t stream) {
+                        return vgt::LaunchRaycastF64(static_cast<const double*>(points_dev), num_points, g, tracking,
+                                                     threads, scratch, scratch_bytes, stream);
+                      });
 }
 
 /* --------------------------------- filter ----------------------------------- */

@@ -115,12 +115,16 @@ struct RaycastGridF64
   double grid_size[3];
   int32_t counts[3];
 };
-// point_stride = floats between consecutive points (3 for packed xyz; PointCloud2: point_step / 4)
+// point_stride = floats between consecutive points (3 for packed xyz; PointCloud2: point_step / 4).
+// scratch_dev (optional, RaycastScratchBytes(num_points) bytes): lets large clouds be ordered by ray
+// direction and counted per workgroup in LDS (same counts, far fewer global atomics).
+size_t RaycastScratchBytes(int64_t num_points);
 hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t point_stride,
                             const RaycastGridF32& g, int32_t* tracking_dev, int threads_per_block,
-                            hipStream_t stream);
+                            void* scratch_dev, size_t scratch_bytes, hipStream_t stream);
 hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
-                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream);
+                            int32_t* tracking_dev, int threads_per_block, void* scratch_dev, size_t scratch_bytes,
+                            hipStream_t stream);
 hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
                         double percent_seen_free, int32_t outlier_points_threshold,
                         int32_t num_cameras_seen_free, bool ratio_in_double, float* occupancy_dev,

@@ -10,6 +10,16 @@
 // Differences from the reference kernels, none of which change results on grids the
 // reference can index: 64-bit cell indices (the reference's int32 index overflows at 2^30
 // cells), tracking counters addressed as (cell*2 + {0 free, 1 filled}).
+//
+// Accumulation.  The kernel is bound by scattered global atomics (about 25 G increments/s chip-wide,
+// profiles/r1/bench_raycast_config3.json), not by the walk.  All rays of a call leave from one point,
+// so rays of similar direction visit the same voxels for a long stretch: large clouds are first
+// ordered by direction (a counting sort over cube-map bins, Morton order inside a face), so that a
+// workgroup's rays form a narrow cone, and the workgroup counts its seen-free visits in an LDS hash
+// table (cell -> count) that it flushes with ONE global atomic per distinct cell at the end of every
+// segment of the walk.  Integer additions commute, so the tracking counts are bit-identical to the
+// one-atomic-per-visit formulation; a visit that finds no slot within a few probes (wide cones far
+// from the sensor, incoherent clouds) simply goes to global memory directly.
 #include "vgt_internal.hpp"
 
 #include <cmath>
@@ -84,123 +94,320 @@ __device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracki
   if (mine) atomicAdd(&tracking[index], 1);
 }
 
-// One thread per point.  Real = float reproduces the reference device kernels, Real = double
-// the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
+// ---- per-workgroup accumulation table (see the header) ----
+constexpr int kTableSlots = 4096;       // 32 KiB of LDS: keys + counts
+constexpr int kTableProbes = 6;
+constexpr int kWalkSegment = 96;        // steps between flushes
+constexpr uint32_t kEmptyKey = 0xffffffffu;
+
+struct VisitTable
+{
+  uint32_t* keys;
+  uint32_t* counts;
+  __device__ __forceinline__ void Clear()
+  {
+    for (int s = threadIdx.x; s < kTableSlots; s += blockDim.x)
+    {
+      keys[s] = kEmptyKey;
+      counts[s] = 0u;
+    }
+  }
+  // seen-free visit of `cell` (cell < 2^32 - 1)
+  __device__ __forceinline__ void Add(uint32_t cell, int32_t* __restrict__ tracking)
+  {
+    uint32_t slot = (cell * 2654435761u) >> 20;  // top 12 bits: kTableSlots = 4096
+#pragma unroll 1
+    for (int probe = 0; probe < kTableProbes; probe++)
+    {
+      uint32_t key = keys[slot];
+      if (key == kEmptyKey) key = atomicCAS(&keys[slot], kEmptyKey, cell);
+      if (key == cell || key == kEmptyKey)
+      {
+        atomicAdd(&counts[slot], 1u);
+        return;
+      }
+      slot = (slot + 1u) & (kTableSlots - 1);
+    }
+    atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
+  }
+  __device__ __forceinline__ void Flush(int32_t* __restrict__ tracking)
+  {
+    for (int s = threadIdx.x; s < kTableSlots; s += blockDim.x)
+    {
+      const uint32_t key = keys[s];
+      if (key != kEmptyKey)
+      {
+        atomicAdd(&tracking[static_cast<int64_t>(key) * 2], static_cast<int32_t>(counts[s]));
+        keys[s] = kEmptyKey;
+        counts[s] = 0u;
+      }
+    }
+  }
+};
+
+// ---- ordering of a cloud by ray direction (counting sort, see the header) ----
+constexpr int kFaceBits = 7;                                  // 128 x 128 cells per cube-map face
+constexpr int kSortBins = 6 << (2 * kFaceBits);               // 98304
+constexpr int64_t kSortMinPoints = 32768;                     // smaller clouds: three extra launches cost more than they save
+__device__ __forceinline__ uint32_t SpreadBits(uint32_t x)    // 0b..cba -> 0b..0c0b0a
+{
+  x &= 0xffffu;
+  x = (x | (x << 8)) & 0x00ff00ffu;
+  x = (x | (x << 4)) & 0x0f0f0f0fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
 template <typename Real>
-__global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_points,
-                              int64_t point_stride,  // elements between consecutive points (3 = packed xyz)
-                              const typename RaycastTraits<Real>::Grid g,
-                              int32_t* __restrict__ tracking)
+__global__ void DirectionBinKernel(const Real* __restrict__ points, int64_t num_points, int64_t point_stride,
+                                   const typename RaycastTraits<Real>::Grid g, uint32_t* __restrict__ bins,
+                                   uint32_t* __restrict__ histogram)
 {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= num_points) return;
-
-  const Real px = points[point_stride * i + 0];
-  const Real py = points[point_stride * i + 1];
-  const Real pz = points[point_stride * i + 2];
-  if (!isfinite(px) || !isfinite(py) || !isfinite(pz)) return;
-
-  const Real* T = g.xform;
-  // point and cloud origin in the grid frame
-  const Real gp[3] = {T[0] * px + T[4] * py + T[8] * pz + T[12],
-                      T[1] * px + T[5] * py + T[9] * pz + T[13],
-                      T[2] * px + T[6] * py + T[10] * pz + T[14]};
-  const Real origin[3] = {T[12], T[13], T[14]};
-
-  // clip the ray to max_range
-  const Real ray[3] = {gp[0] - origin[0], gp[1] - origin[1], gp[2] - origin[2]};
-  const Real length = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
-  const bool clipped = length > g.max_range;
-  Real last[3] = {gp[0], gp[1], gp[2]};
-  if (clipped)
+  const float px = static_cast<float>(points[point_stride * i + 0]);
+  const float py = static_cast<float>(points[point_stride * i + 1]);
+  const float pz = static_cast<float>(points[point_stride * i + 2]);
+  uint32_t bin = kSortBins - 1;
+  if (isfinite(px) && isfinite(py) && isfinite(pz))
   {
-    for (int a = 0; a < 3; a++) last[a] = origin[a] + (ray[a] * (g.max_range / length));
-  }
-
-  // entry point: the origin itself, or where the ray enters the grid's box
-  int32_t origin_idx[3];
-  for (int a = 0; a < 3; a++)
-    origin_idx[a] = static_cast<int32_t>(floor(origin[a] * g.inverse_voxel_size));
-  Real first[3] = {origin[0], origin[1], origin[2]};
-  if (!InGrid(origin_idx, g.counts))
-  {
-    Real tmin = Real(0);
-    Real tmax = g.max_range;
-    Real dir[3];
-    for (int a = 0; a < 3; a++) dir[a] = ray[a] / length;
-    for (int a = 0; a < 3; a++)
+    const Real* T = g.xform;
+    const float d[3] = {static_cast<float>(T[0]) * px + static_cast<float>(T[4]) * py + static_cast<float>(T[8]) * pz,
+                        static_cast<float>(T[1]) * px + static_cast<float>(T[5]) * py + static_cast<float>(T[9]) * pz,
+                        static_cast<float>(T[2]) * px + static_cast<float>(T[6]) * py + static_cast<float>(T[10]) * pz};
+    const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+    int axis = 0;
+    float major = ax;
+    if (ay > major)
     {
-      if (fabs(dir[a]) < RaycastTraits<Real>::kFlat)
+      axis = 1;
+      major = ay;
+    }
+    if (az > major)
+    {
+      axis = 2;
+      major = az;
+    }
+    bin = 0;
+    if (major > 0.0f && isfinite(major))
+    {
+      const float u = d[(axis + 1) % 3] / major, v = d[(axis + 2) % 3] / major;  // in [-1, 1]
+      const int cells = 1 << kFaceBits;
+      const int iu = min(cells - 1, max(0, static_cast<int>((u + 1.0f) * (0.5f * cells))));
+      const int iv = min(cells - 1, max(0, static_cast<int>((v + 1.0f) * (0.5f * cells))));
+      const uint32_t face = static_cast<uint32_t>(axis * 2 + (d[axis] < 0.0f ? 1 : 0));
+      bin = (face << (2 * kFaceBits)) | SpreadBits(static_cast<uint32_t>(iu)) | (SpreadBits(static_cast<uint32_t>(iv)) << 1);
+    }
+  }
+  bins[i] = bin;
+  atomicAdd(&histogram[bin], 1u);
+}
+
+// histogram -> exclusive prefix sums, in place (one workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void BinOffsetsKernel(uint32_t* __restrict__ histogram)
+{
+  __shared__ uint32_t partial[1024];
+  constexpr int kPerThread = kSortBins / 1024;  // 96
+  static_assert(kSortBins % 1024 == 0, "bins per thread");
+  const int first = threadIdx.x * kPerThread;
+  uint32_t sum = 0;
+  for (int k = 0; k < kPerThread; k++) sum += histogram[first + k];
+  partial[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1)
+  {
+    const uint32_t add = (threadIdx.x >= static_cast<unsigned>(d)) ? partial[threadIdx.x - d] : 0u;
+    __syncthreads();
+    partial[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t running = partial[threadIdx.x] - sum;
+  for (int k = 0; k < kPerThread; k++)
+  {
+    const uint32_t count = histogram[first + k];
+    histogram[first + k] = running;
+    running += count;
+  }
+}
+
+__global__ void ScatterOrderKernel(const uint32_t* __restrict__ bins, int64_t num_points,
+                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ order)
+{
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= num_points) return;
+  order[atomicAdd(&offsets[bins[i]], 1u)] = static_cast<uint32_t>(i);
+}
+
+// One thread per point.  Real = float reproduces the reference device kernels, Real = double
+// the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
+// kTable: seen-free visits go through the workgroup's LDS table (needs num_cells < 2^32 - 1); `order`
+// (optional) = the direction-sorted permutation of the points.
+template <typename Real, bool kTable>
+__global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_points,
+                              int64_t point_stride,  // elements between consecutive points (3 = packed xyz)
+                              const uint32_t* __restrict__ order,
+                              const typename RaycastTraits<Real>::Grid g,
+                              int32_t* __restrict__ tracking)
+{
+  __shared__ uint32_t table_words[kTable ? 2 * kTableSlots : 2];
+  VisitTable table{table_words, table_words + (kTable ? kTableSlots : 1)};
+  if constexpr (kTable) table.Clear();
+
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  bool walking = slot < num_points;
+  int32_t cur[3] = {0, 0, 0}, end[3] = {0, 0, 0}, step[3] = {0, 0, 0};
+  Real t[3] = {Real(0), Real(0), Real(0)}, dt[3] = {Real(0), Real(0), Real(0)};
+  if (walking)
+  {
+    const int64_t i = order ? static_cast<int64_t>(order[slot]) : slot;
+    const Real px = points[point_stride * i + 0];
+    const Real py = points[point_stride * i + 1];
+    const Real pz = points[point_stride * i + 2];
+    walking = isfinite(px) && isfinite(py) && isfinite(pz);
+    if (walking)
+    {
+      const Real* T = g.xform;
+      // point and cloud origin in the grid frame
+      const Real gp[3] = {T[0] * px + T[4] * py + T[8] * pz + T[12],
+                          T[1] * px + T[5] * py + T[9] * pz + T[13],
+                          T[2] * px + T[6] * py + T[10] * pz + T[14]};
+      const Real origin[3] = {T[12], T[13], T[14]};
+
+      // clip the ray to max_range
+      const Real ray[3] = {gp[0] - origin[0], gp[1] - origin[1], gp[2] - origin[2]};
+      const Real length = sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+      const bool clipped = length > g.max_range;
+      Real last[3] = {gp[0], gp[1], gp[2]};
+      if (clipped)
       {
-        if (!(origin[a] >= Real(0) && origin[a] < g.grid_size[a])) return;
+        for (int a = 0; a < 3; a++) last[a] = origin[a] + (ray[a] * (g.max_range / length));
       }
-      else
+
+      // entry point: the origin itself, or where the ray enters the grid's box
+      int32_t origin_idx[3];
+      for (int a = 0; a < 3; a++)
+        origin_idx[a] = static_cast<int32_t>(floor(origin[a] * g.inverse_voxel_size));
+      Real first[3] = {origin[0], origin[1], origin[2]};
+      if (!InGrid(origin_idx, g.counts))
       {
-        const Real ood = Real(1) / dir[a];
-        const Real tlow = (Real(0) - origin[a]) * ood;
-        const Real thigh = (g.grid_size[a] - origin[a]) * ood;
-        const Real t1 = (tlow <= thigh) ? tlow : thigh;
-        const Real t2 = (tlow <= thigh) ? thigh : tlow;
-        if (t1 > tmin) tmin = t1;
-        if (t2 > tmax) tmax = t2;  // as the reference (cuda_voxelization_helpers.cu:206-209)
-        if (tmin > tmax) return;
+        Real tmin = Real(0);
+        Real tmax = g.max_range;
+        Real dir[3];
+        for (int a = 0; a < 3; a++) dir[a] = ray[a] / length;
+        for (int a = 0; a < 3; a++)
+        {
+          if (!walking) break;
+          if (fabs(dir[a]) < RaycastTraits<Real>::kFlat)
+          {
+            if (!(origin[a] >= Real(0) && origin[a] < g.grid_size[a])) walking = false;
+          }
+          else
+          {
+            const Real ood = Real(1) / dir[a];
+            const Real tlow = (Real(0) - origin[a]) * ood;
+            const Real thigh = (g.grid_size[a] - origin[a]) * ood;
+            const Real t1 = (tlow <= thigh) ? tlow : thigh;
+            const Real t2 = (tlow <= thigh) ? thigh : tlow;
+            if (t1 > tmin) tmin = t1;
+            if (t2 > tmax) tmax = t2;  // as the reference (cuda_voxelization_helpers.cu:206-209)
+            if (tmin > tmax) walking = false;
+          }
+        }
+        for (int a = 0; a < 3; a++)
+          first[a] = origin[a] + (dir[a] * (tmin + RaycastTraits<Real>::kNudge));
+      }
+
+      if (walking)
+      {
+        const Real half = g.voxel_size * Real(0.5);
+        for (int a = 0; a < 3; a++)
+        {
+          cur[a] = static_cast<int32_t>(floor(first[a] * g.inverse_voxel_size));
+          end[a] = static_cast<int32_t>(floor(last[a] * g.inverse_voxel_size));
+          const int32_t diff = end[a] - cur[a];
+          step[a] = (diff > 0) - (diff < 0);
+          const Real centre = (static_cast<Real>(cur[a]) + Real(0.5)) * g.voxel_size;
+          t[a] = AxisT<Real>(first[a], ray[a], centre - half, centre + half);
+          dt[a] = fabs(g.voxel_size / ray[a]);
+        }
+        // the end voxel is recorded first: seen-free if the ray was clipped, seen-filled otherwise
+        if (InGrid(end, g.counts))
+          atomicAdd(&tracking[CellIndex(end, g.counts) * 2 + (clipped ? 0 : 1)], 1);
       }
     }
-    for (int a = 0; a < 3; a++)
-      first[a] = origin[a] + (dir[a] * (tmin + RaycastTraits<Real>::kNudge));
   }
 
-  int32_t cur[3], end[3], step[3];
-  Real t[3], dt[3];
-  const Real half = g.voxel_size * Real(0.5);
-  for (int a = 0; a < 3; a++)
+  // The walk, in segments of kWalkSegment steps; with the table, the workgroup flushes it between segments.
+  int walked = 0;
+  for (;;)
   {
-    cur[a] = static_cast<int32_t>(floor(first[a] * g.inverse_voxel_size));
-    end[a] = static_cast<int32_t>(floor(last[a] * g.inverse_voxel_size));
-    const int32_t diff = end[a] - cur[a];
-    step[a] = (diff > 0) - (diff < 0);
-    const Real centre = (static_cast<Real>(cur[a]) + Real(0.5)) * g.voxel_size;
-    t[a] = AxisT<Real>(first[a], ray[a], centre - half, centre + half);
-    dt[a] = fabs(g.voxel_size / ray[a]);
-  }
-
-  // the end voxel is recorded first: seen-free if the ray was clipped, seen-filled otherwise
-  if (InGrid(end, g.counts))
-    atomicAdd(&tracking[CellIndex(end, g.counts) * 2 + (clipped ? 0 : 1)], 1);
-
-  for (int walked = 0; cur[0] != end[0] || cur[1] != end[1] || cur[2] != end[2]; walked++)
-  {
-    if (!InGrid(cur, g.counts)) break;
-    // `walked` is the same for every lane still in the loop
-    if (walked < kAggregatedSteps)
-      AggregatedIncrement(tracking, CellIndex(cur, g.counts) * 2);
-    else
-      atomicAdd(&tracking[CellIndex(cur, g.counts) * 2], 1);
-    int a;
-    if (t[0] <= t[1] && t[0] <= t[2])
-      a = 0;
-    else if (t[1] <= t[0] && t[1] <= t[2])
-      a = 1;
-    else
-      a = 2;
-    // select without dynamically indexing the register arrays
-    if (a == 0)
+    if constexpr (kTable)
     {
-      if (cur[0] == end[0]) break;
-      cur[0] += step[0];
-      t[0] += dt[0];
+      if (!__syncthreads_or(walking ? 1 : 0)) break;  // also orders Clear() / Flush() before the next inserts
     }
-    else if (a == 1)
+    else if (!walking)
+      break;
+    if (walking)
     {
-      if (cur[1] == end[1]) break;
-      cur[1] += step[1];
-      t[1] += dt[1];
+      for (int s = 0; s < kWalkSegment; s++, walked++)
+      {
+        if ((cur[0] == end[0] && cur[1] == end[1] && cur[2] == end[2]) || !InGrid(cur, g.counts))
+        {
+          walking = false;
+          break;
+        }
+        const int64_t cell = CellIndex(cur, g.counts);
+        if constexpr (kTable)
+          table.Add(static_cast<uint32_t>(cell), tracking);
+        else if (walked < kAggregatedSteps)  // `walked` is the same for every lane still in the loop
+          AggregatedIncrement(tracking, cell * 2);
+        else
+          atomicAdd(&tracking[cell * 2], 1);
+        int a;
+        if (t[0] <= t[1] && t[0] <= t[2])
+          a = 0;
+        else if (t[1] <= t[0] && t[1] <= t[2])
+          a = 1;
+        else
+          a = 2;
+        // select without dynamically indexing the register arrays
+        if (a == 0)
+        {
+          if (cur[0] == end[0])
+          {
+            walking = false;
+            break;
+          }
+          cur[0] += step[0];
+          t[0] += dt[0];
+        }
+        else if (a == 1)
+        {
+          if (cur[1] == end[1])
+          {
+            walking = false;
+            break;
+          }
+          cur[1] += step[1];
+          t[1] += dt[1];
+        }
+        else
+        {
+          if (cur[2] == end[2])
+          {
+            walking = false;
+            break;
+          }
+          cur[2] += step[2];
+          t[2] += dt[2];
+        }
+      }
     }
-    else
+    if constexpr (kTable)
     {
-      if (cur[2] == end[2]) break;
-      cur[2] += step[2];
-      t[2] += dt[2];
+      __syncthreads();
+      table.Flush(tracking);
     }
   }
 }
@@ -243,27 +450,64 @@ __global__ void FilterKernel(const int32_t* __restrict__ tracking, int64_t num_c
 }
 }  // namespace
 
-hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t point_stride,
-                            const RaycastGridF32& g, int32_t* tracking_dev, int threads_per_block,
-                            hipStream_t stream)
+// Device scratch for one raycast call of `num_points` points: bin histogram + per-point bins + the
+// direction-sorted permutation.
+size_t RaycastScratchBytes(int64_t num_points)
+{
+  if (num_points < kSortMinPoints) return 0;
+  return (static_cast<size_t>(kSortBins) + 2 * static_cast<size_t>(num_points)) * sizeof(uint32_t);
+}
+
+namespace
+{
+template <typename Real>
+hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t point_stride,
+                         const typename RaycastTraits<Real>::Grid& g, int32_t* tracking_dev,
+                         int threads_per_block, void* scratch_dev, size_t scratch_bytes, hipStream_t stream)
 {
   if (num_points <= 0) return hipSuccess;
   const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
-  hipLaunchKernelGGL(RaycastKernel<float>, dim3(static_cast<unsigned>(blocks)),
-                     dim3(threads_per_block), 0, stream, points_dev, num_points, point_stride, g,
+  const int64_t num_cells = static_cast<int64_t>(g.counts[0]) * g.counts[1] * g.counts[2];
+  const size_t need = RaycastScratchBytes(num_points);
+  // Large clouds: order by direction and count visits per workgroup in LDS.  Needs the scratch, 32-bit
+  // point and cell indices.
+  if (need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL && num_cells < 0xffffffffLL)
+  {
+    uint32_t* histogram = static_cast<uint32_t*>(scratch_dev);
+    uint32_t* bins = histogram + kSortBins;
+    uint32_t* order = bins + num_points;
+    hipError_t err = hipMemsetAsync(histogram, 0, static_cast<size_t>(kSortBins) * sizeof(uint32_t), stream);
+    if (err != hipSuccess) return err;
+    const unsigned sort_blocks = static_cast<unsigned>((num_points + 255) / 256);
+    hipLaunchKernelGGL(DirectionBinKernel<Real>, dim3(sort_blocks), dim3(256), 0, stream, points_dev, num_points,
+                       point_stride, g, bins, histogram);
+    hipLaunchKernelGGL(BinOffsetsKernel, dim3(1), dim3(1024), 0, stream, histogram);
+    hipLaunchKernelGGL(ScatterOrderKernel, dim3(sort_blocks), dim3(256), 0, stream, bins, num_points, histogram, order);
+    hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
+                       stream, points_dev, num_points, point_stride, order, g, tracking_dev);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL((RaycastKernel<Real, false>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
+                     stream, points_dev, num_points, point_stride, static_cast<const uint32_t*>(nullptr), g,
                      tracking_dev);
   return hipGetLastError();
 }
+}  // namespace
+
+hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t point_stride,
+                            const RaycastGridF32& g, int32_t* tracking_dev, int threads_per_block,
+                            void* scratch_dev, size_t scratch_bytes, hipStream_t stream)
+{
+  return LaunchRaycast<float>(points_dev, num_points, point_stride, g, tracking_dev, threads_per_block, scratch_dev,
+                              scratch_bytes, stream);
+}
 
 hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
-                            int32_t* tracking_dev, int threads_per_block, hipStream_t stream)
+                            int32_t* tracking_dev, int threads_per_block, void* scratch_dev, size_t scratch_bytes,
+                            hipStream_t stream)
 {
-  if (num_points <= 0) return hipSuccess;
-  const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
-  hipLaunchKernelGGL(RaycastKernel<double>, dim3(static_cast<unsigned>(blocks)),
-                     dim3(threads_per_block), 0, stream, points_dev, num_points, int64_t{3}, g,
-                     tracking_dev);
-  return hipGetLastError();
+  return LaunchRaycast<double>(points_dev, num_points, int64_t{3}, g, tracking_dev, threads_per_block, scratch_dev,
+                               scratch_bytes, stream);
 }
 
 hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
