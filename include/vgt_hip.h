@@ -275,6 +275,47 @@ int vgt_hip_sdf_coarse_gradient_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int6
                                     const double* rotation, double* gradient_dev,
                                     uint8_t* has_value_dev);
 
+/* Batched point queries against a float SDF (x, y, z as 3 doubles per query, in the frame
+ * `grid_from_world` maps from: 16 doubles column-major = InverseOriginTransform, NULL = the grid
+ * frame itself).
+ *   vgt_hip_sdf_estimate_distance   SignedDistanceField::EstimateLocationDistance (trilinear estimate
+ *                                   over the eight surrounding cell centres, I/signed_distance_field.hpp:
+ *                                   808-833 over :259-378); distance[i] = NaN and has_value[i] = 0 for a
+ *                                   query outside the grid.
+ *   vgt_hip_sdf_fine_gradient       ::GetLocationFineGradient (:1050-1091 over :214-254): differences of
+ *                                   seven estimates at +-|nominal_window_size| along the query frame's
+ *                                   axes; 3 doubles per query.  A query in the grid whose window leaves it
+ *                                   on both sides of an axis is the reference's std::runtime_error
+ *                                   "Window size for fine gradient is too large for SDF": the call then
+ *                                   returns VGT_HIP_ERR_INVALID_ARGUMENT with that message.
+ * The one operation whose order the reference takes from common_robotics_utilities
+ * (TrilinearInterpolate) is evaluated along x, then y, then z, each as a*(1-t) + b*t in double
+ * (csrc/cell_kernels.hip); results therefore agree with the reference to rounding (tests: 1e-5). */
+int vgt_hip_sdf_estimate_distance(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                                  double resolution, const double* grid_from_world, const double* query_xyz_host,
+                                  int64_t num_queries, double* distance_host, uint8_t* has_value_host);
+int vgt_hip_sdf_estimate_distance_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      double resolution, const double* grid_from_world, const double* query_xyz_dev,
+                                      int64_t num_queries, double* distance_dev, uint8_t* has_value_dev);
+int vgt_hip_sdf_fine_gradient(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, const double* grid_from_world, const double* query_xyz_host,
+                              int64_t num_queries, double nominal_window_size, double* gradient_host,
+                              uint8_t* has_value_host);
+
+/* SignedDistanceField::ComputeLocalExtremaMap (I/signed_distance_field.hpp:1205-1231 over :385-541; consumed by
+ * TaggedObjectOccupancyComponentMap::UpdateSpatialSegments, S/tagged_object_occupancy_component_map.cpp:775-868):
+ * for every voxel the grid-frame location (3 doubles) of the cell its gradient chain ends at -- the chain follows
+ * the coarse gradient with edge gradients (rotated by `rotation`, 9 doubles row-major, NULL = none; the
+ * reference applies the origin transform's rotation) uphill outside obstacles and downhill inside, one of
+ * the 26 neighbours at a time -- or +infinity x3 when the chain leaves the grid.  Where chains run into a
+ * cycle the reference's answer depends on its X-major visiting order (the first walk that reaches the cycle fixes
+ * the cell every later walk inherits); the device formulation reproduces it: bit-identical results
+ * (csrc/cell_kernels.hip).  Grids below 2^31 cells. */
+int vgt_hip_sdf_local_extrema_map(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                                  double resolution, const double* rotation, double* extrema_host);
+int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      double resolution, const double* rotation, double* extrema_dev);
+
 /* ---- multi-GPU: the grid is cut into Z slabs, one device per slab (BASELINE.json config 5).
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
  * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest

@@ -50,6 +50,10 @@ def load(path=None):
                                                  ctypes.c_int, _p]
     lib.vgt_oracle_combine_free_and_named.argtypes = [_p, _p, _i64, _p, _p, _p]
     lib.vgt_oracle_coarse_gradient.argtypes = [_p, _i64, _i64, _i64, _f64, ctypes.c_int, _p, _p]
+    lib.vgt_oracle_local_extrema_map.argtypes = [_p, _i64, _i64, _i64, _f64, _p, _p]
+    lib.vgt_oracle_estimate_distance.argtypes = [_p, _i64, _i64, _i64, _f64, _p, _p, _i64, _p, _p]
+    lib.vgt_oracle_fine_gradient.argtypes = [_p, _i64, _i64, _i64, _f64, _p, _p, _i64, _f64, _p, _p]
+    lib.vgt_oracle_fine_gradient.restype = ctypes.c_int
     lib.vgt_oracle_raycast_f32.argtypes = [
         _p, _i64, _f32, _p, _f32, _f32, _f32, _f32, _f32, _i32, _i32, _i32, _p, ctypes.c_int]
     lib.vgt_oracle_raycast_f64.argtypes = [
@@ -153,6 +157,41 @@ def coarse_gradient(sdf, resolution, enable_edge_gradients=False):
     load().vgt_oracle_coarse_gradient(_ptr(field), nx, ny, nz, float(resolution), int(bool(enable_edge_gradients)),
                                       _ptr(grad), _ptr(has))
     return grad, has.astype(bool)
+
+
+def local_extrema_map(sdf, resolution, rotation=None):
+    """ComputeLocalExtremaMap: [nx, ny, nz, 3] float64."""
+    field = np.ascontiguousarray(sdf, dtype=np.float32)
+    rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+    out = np.empty(field.shape + (3,), dtype=np.float64)
+    load().vgt_oracle_local_extrema_map(_ptr(field), *field.shape, float(resolution),
+                                        _ptr(rot) if rot is not None else None, _ptr(out))
+    return out
+
+
+def estimate_distance(sdf, resolution, queries, grid_from_world=None):
+    """EstimateLocationDistance for query points [N, 3]: (distance [N] float64, has_value [N] bool)."""
+    field = np.ascontiguousarray(sdf, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+    xf = None if grid_from_world is None else np.ascontiguousarray(grid_from_world, dtype=np.float64).reshape(16)
+    out = np.empty(len(q), dtype=np.float64)
+    has = np.empty(len(q), dtype=np.uint8)
+    load().vgt_oracle_estimate_distance(_ptr(field), *field.shape, float(resolution), _ptr(xf) if xf is not None else None,
+                                        _ptr(q), len(q), _ptr(out), _ptr(has))
+    return out, has.astype(bool)
+
+
+def fine_gradient(sdf, resolution, queries, window, grid_from_world=None):
+    """GetLocationFineGradient for query points [N, 3]: (gradient [N, 3], has_value [N], window_too_large)."""
+    field = np.ascontiguousarray(sdf, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+    xf = None if grid_from_world is None else np.ascontiguousarray(grid_from_world, dtype=np.float64).reshape(16)
+    out = np.empty((len(q), 3), dtype=np.float64)
+    has = np.empty(len(q), dtype=np.uint8)
+    too_large = load().vgt_oracle_fine_gradient(_ptr(field), *field.shape, float(resolution),
+                                                _ptr(xf) if xf is not None else None, _ptr(q), len(q), float(window),
+                                                _ptr(out), _ptr(has))
+    return out, has.astype(bool), bool(too_large)
 
 
 def raycast_f32(points, max_range, xform, voxel_size, inverse_voxel_size,

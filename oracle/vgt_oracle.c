@@ -400,6 +400,345 @@ void vgt_oracle_combine_free_and_named(const float* free_sdf, const float* named
 }
 
 /* ------------------------------------------------------------------------- */
+/* SDF consumers: trilinear distance estimate, fine gradient.   */
+/* ------------------------------------------------------------------------- */
+
+/* GetAxisInterpolationIndices, signed_distance_field.hpp:276-313 */
+static void axis_interpolation_indices(int64_t initial_index, int64_t axis_size, double axis_offset,
+                                       int64_t* lower_out, int64_t* upper_out)
+{
+  int64_t lower = initial_index;
+  int64_t upper = initial_index;
+  if (axis_offset >= 0.0)
+  {
+    upper = initial_index + 1;
+    if (upper >= axis_size)
+    {
+      upper = initial_index;
+      lower = initial_index - 1;
+      if (lower < 0) lower = initial_index;
+    }
+  }
+  else
+  {
+    lower = initial_index - 1;
+    if (lower < 0)
+    {
+      upper = initial_index + 1;
+      lower = initial_index;
+      if (upper >= axis_size) upper = initial_index;
+    }
+  }
+  *lower_out = lower;
+  *upper_out = upper;
+}
+
+/* GetCorrectedCenterDistance, :259-273 */
+static double corrected_center_distance(const float* sdf, int64_t ny, int64_t nz, int64_t x, int64_t y, int64_t z,
+                                        double resolution)
+{
+  const double nominal_sdf_distance = (double)sdf[(x * ny + y) * nz + z];
+  const double cell_center_distance_offset = resolution * 0.5;
+  if (nominal_sdf_distance >= 0.0) return nominal_sdf_distance - cell_center_distance_offset;
+  return nominal_sdf_distance + cell_center_distance_offset;
+}
+
+static double lerp(double a, double b, double t) { return a * (1.0 - t) + b * t; }
+
+/* EstimateLocationDistance4d (:822-833) -> EstimateDistanceInterpolateFromNeighbors (:316-378).  The trilinear
+ * interpolation itself is common_robotics_utilities::math::TrilinearInterpolate, whose source is not in the
+ * container: evaluated here along x, then y, then z, each a*(1-t) + b*t (the order csrc/cell_kernels.hip
+ * documents).  Returns 0 when the location is outside the grid. */
+static int estimate_location_distance(const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                      const double* grid_from_world, double x, double y, double z, double* out)
+{
+  double g[3] = {x, y, z};
+  if (grid_from_world)
+  {
+    const double* M = grid_from_world;
+    g[0] = M[0] * x + M[4] * y + M[8] * z + M[12];
+    g[1] = M[1] * x + M[5] * y + M[9] * z + M[13];
+    g[2] = M[2] * x + M[6] * y + M[10] * z + M[14];
+  }
+  const double inv = 1.0 / resolution;
+  const double fx = floor(g[0] * inv), fy = floor(g[1] * inv), fz = floor(g[2] * inv);
+  if (!(fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny && fz >= 0.0 && fz < (double)nz)) return 0;
+  const int64_t x_idx = (int64_t)fx, y_idx = (int64_t)fy, z_idx = (int64_t)fz;
+  const double cx = ((double)x_idx + 0.5) * resolution;
+  const double cy = ((double)y_idx + 0.5) * resolution;
+  const double cz = ((double)z_idx + 0.5) * resolution;
+  int64_t lx, ux, ly, uy, lz, uz;
+  axis_interpolation_indices(x_idx, nx, g[0] - cx, &lx, &ux);
+  axis_interpolation_indices(y_idx, ny, g[1] - cy, &ly, &uy);
+  axis_interpolation_indices(z_idx, nz, g[2] - cz, &lz, &uz);
+#define CCD(a, b, c) corrected_center_distance(sdf, ny, nz, (a), (b), (c), resolution)
+  const double mxmymz = CCD(lx, ly, lz), mxmypz = CCD(lx, ly, uz), mxpymz = CCD(lx, uy, lz), mxpypz = CCD(lx, uy, uz);
+  const double pxmymz = CCD(ux, ly, lz), pxmypz = CCD(ux, ly, uz), pxpymz = CCD(ux, uy, lz), pxpypz = CCD(ux, uy, uz);
+#undef CCD
+  const double low_x = ((double)lx + 0.5) * resolution;
+  const double low_y = ((double)ly + 0.5) * resolution;
+  const double low_z = ((double)lz + 0.5) * resolution;
+  const double tx = (g[0] - low_x) / ((low_x + resolution) - low_x);
+  const double ty = (g[1] - low_y) / ((low_y + resolution) - low_y);
+  const double tz = (g[2] - low_z) / ((low_z + resolution) - low_z);
+  const double mm = lerp(mxmymz, pxmymz, tx), mp = lerp(mxmypz, pxmypz, tx);
+  const double pm = lerp(mxpymz, pxpymz, tx), pp = lerp(mxpypz, pxpypz, tx);
+  const double lo = lerp(mm, pm, ty), hi = lerp(mp, pp, ty);
+  *out = lerp(lo, hi, tz);
+  return 1;
+}
+
+void vgt_oracle_estimate_distance(const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                  const double* grid_from_world, const double* queries, int64_t num_queries,
+                                  double* distance, uint8_t* has_value)
+{
+  for (int64_t i = 0; i < num_queries; i++)
+  {
+    double v = NAN;
+    const int ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, queries[3 * i],
+                                              queries[3 * i + 1], queries[3 * i + 2], &v);
+    distance[i] = ok ? v : NAN;
+    if (has_value) has_value[i] = (uint8_t)ok;
+  }
+}
+
+/* ComputeAxisFineGradient, :214-254; returns 0 where the reference throws */
+static int axis_fine_gradient(int point_ok, double point, int minus_ok, double minus, int plus_ok, double plus,
+                              double query_point_axis_value, double minus_point_axis_value,
+                              double plus_point_axis_value, double* out)
+{
+  if (point_ok && minus_ok && plus_ok)
+  {
+    const double window_size = plus_point_axis_value - minus_point_axis_value;
+    const double distance_delta = plus - minus;
+    *out = distance_delta / window_size;
+  }
+  else if (point_ok && minus_ok)
+  {
+    const double window_size = query_point_axis_value - minus_point_axis_value;
+    const double distance_delta = point - minus;
+    *out = distance_delta / window_size;
+  }
+  else if (point_ok && plus_ok)
+  {
+    const double window_size = plus_point_axis_value - query_point_axis_value;
+    const double distance_delta = plus - point;
+    *out = distance_delta / window_size;
+  }
+  else
+    return 0;
+  return 1;
+}
+
+/* GetLocationFineGradient, :1050-1091.  Return value: 1 if some query made the reference throw
+ * "Window size for fine gradient is too large for SDF" (its entries are NaN / has_value 0). */
+int vgt_oracle_fine_gradient(const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                             const double* grid_from_world, const double* queries, int64_t num_queries,
+                             double nominal_window_size, double* gradient, uint8_t* has_value)
+{
+  const double ideal_window_size = fabs(nominal_window_size);
+  int too_large = 0;
+  for (int64_t i = 0; i < num_queries; i++)
+  {
+    const double x = queries[3 * i], y = queries[3 * i + 1], z = queries[3 * i + 2];
+    double g[3] = {NAN, NAN, NAN};
+    double point = 0.0;
+    int ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, x, y, z, &point);
+    if (ok)
+    {
+      const double min_x = x - ideal_window_size, max_x = x + ideal_window_size;
+      const double min_y = y - ideal_window_size, max_y = y + ideal_window_size;
+      const double min_z = z - ideal_window_size, max_z = z + ideal_window_size;
+      double mx = 0, px = 0, my = 0, py = 0, mz = 0, pz = 0;
+      const int mx_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, min_x, y, z, &mx);
+      const int px_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, max_x, y, z, &px);
+      const int my_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, x, min_y, z, &my);
+      const int py_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, x, max_y, z, &py);
+      const int mz_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, x, y, min_z, &mz);
+      const int pz_ok = estimate_location_distance(sdf, nx, ny, nz, resolution, grid_from_world, x, y, max_z, &pz);
+      const int fine = axis_fine_gradient(1, point, mx_ok, mx, px_ok, px, x, min_x, max_x, &g[0]) &&
+                       axis_fine_gradient(1, point, my_ok, my, py_ok, py, y, min_y, max_y, &g[1]) &&
+                       axis_fine_gradient(1, point, mz_ok, mz, pz_ok, pz, z, min_z, max_z, &g[2]);
+      if (!fine)
+      {
+        too_large = 1;
+        ok = 0;
+        g[0] = g[1] = g[2] = NAN;
+      }
+    }
+    gradient[3 * i] = g[0];
+    gradient[3 * i + 1] = g[1];
+    gradient[3 * i + 2] = g[2];
+    if (has_value) has_value[i] = (uint8_t)ok;
+  }
+  return too_large;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SDF consumer: ComputeLocalExtremaMap.                        */
+/* ------------------------------------------------------------------------- */
+
+/* GetIndexCoarseGradient(x, y, z, true): the grid-aligned gradient with edge gradients
+ * (signed_distance_field.hpp:923-1004) rotated by the origin transform (:906-921; rotation = 9 doubles
+ * row-major or NULL). */
+static void coarse_gradient_with_edges(const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                       const double* rotation, int64_t x_index, int64_t y_index, int64_t z_index,
+                                       double g[3])
+{
+#define SDF_AT(xi, yi, zi) sdf[((xi) * ny + (yi)) * nz + (zi)]
+  double gx = 0.0, gy = 0.0, gz = 0.0;
+  if ((x_index > 0) && (y_index > 0) && (z_index > 0) && (x_index < (nx - 1)) && (y_index < (ny - 1)) &&
+      (z_index < (nz - 1)))
+  {
+    const double inv_twice_resolution = 1.0 / (2.0 * resolution);
+    const float dx = SDF_AT(x_index + 1, y_index, z_index) - SDF_AT(x_index - 1, y_index, z_index);
+    const float dy = SDF_AT(x_index, y_index + 1, z_index) - SDF_AT(x_index, y_index - 1, z_index);
+    const float dz = SDF_AT(x_index, y_index, z_index + 1) - SDF_AT(x_index, y_index, z_index - 1);
+    gx = dx * inv_twice_resolution;
+    gy = dy * inv_twice_resolution;
+    gz = dz * inv_twice_resolution;
+  }
+  else
+  {
+    const int64_t low_x_index = (x_index - 1 > 0) ? x_index - 1 : 0;
+    const int64_t high_x_index = (x_index + 1 < nx - 1) ? x_index + 1 : nx - 1;
+    const int64_t low_y_index = (y_index - 1 > 0) ? y_index - 1 : 0;
+    const int64_t high_y_index = (y_index + 1 < ny - 1) ? y_index + 1 : ny - 1;
+    const int64_t low_z_index = (z_index - 1 > 0) ? z_index - 1 : 0;
+    const int64_t high_z_index = (z_index + 1 < nz - 1) ? z_index + 1 : nz - 1;
+    const double x_increment = (double)(high_x_index - low_x_index) * resolution;
+    const double y_increment = (double)(high_y_index - low_y_index) * resolution;
+    const double z_increment = (double)(high_z_index - low_z_index) * resolution;
+    if (x_increment > 0.0)
+      gx = ((double)SDF_AT(high_x_index, y_index, z_index) - (double)SDF_AT(low_x_index, y_index, z_index)) *
+           (1.0 / x_increment);
+    if (y_increment > 0.0)
+      gy = ((double)SDF_AT(x_index, high_y_index, z_index) - (double)SDF_AT(x_index, low_y_index, z_index)) *
+           (1.0 / y_increment);
+    if (z_increment > 0.0)
+      gz = ((double)SDF_AT(x_index, y_index, high_z_index) - (double)SDF_AT(x_index, y_index, low_z_index)) *
+           (1.0 / z_increment);
+  }
+#undef SDF_AT
+  if (rotation)
+  {
+    const double wx = rotation[0] * gx + rotation[1] * gy + rotation[2] * gz;
+    const double wy = rotation[3] * gx + rotation[4] * gy + rotation[5] * gz;
+    const double wz = rotation[6] * gx + rotation[7] * gy + rotation[8] * gz;
+    gx = wx;
+    gy = wy;
+    gz = wz;
+  }
+  g[0] = gx;
+  g[1] = gy;
+  g[2] = gz;
+}
+
+/* GradientIsEffectiveFlat, :482-497 */
+static int gradient_is_effective_flat(const double g[3], double resolution)
+{
+  const double step_resolution = resolution * 0.06125;
+  return (fabs(g[0]) <= step_resolution && fabs(g[1]) <= step_resolution && fabs(g[2]) <= step_resolution);
+}
+
+/* GetNextFromGradient, :499-541 */
+static void next_from_gradient(const float* sdf, int64_t ny, int64_t nz, double resolution, const int64_t index[3],
+                               const double gradient[3], int64_t next_index[3])
+{
+  const float stored_distance = sdf[(index[0] * ny + index[1]) * nz + index[2]];
+  double working_gradient[3] = {gradient[0], gradient[1], gradient[2]};
+  if (stored_distance < 0.0)
+  {
+    for (int a = 0; a < 3; a++) working_gradient[a] = gradient[a] * -1.0;
+  }
+  const double step_resolution = resolution * 0.06125;
+  for (int a = 0; a < 3; a++)
+  {
+    next_index[a] = index[a];
+    if (working_gradient[a] > step_resolution)
+      next_index[a] += 1;
+    else if (working_gradient[a] < -step_resolution)
+      next_index[a] -= 1;
+  }
+}
+
+/* ComputeLocalExtremaMap (:1205-1231) with FollowGradientsToLocalExtremaUnsafe (:385-480), literally: cells are
+ * visited in X-major order, a walk stops at a flat cell, off the grid, at a cell already stored, or at a cell of
+ * its own path, and every cell of the path receives the result.  extrema: 3 doubles per cell, the default value
+ * (-inf x 3) never survives. */
+void vgt_oracle_local_extrema_map(const float* sdf, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                  const double* rotation, double* extrema)
+{
+  const int64_t total = nx * ny * nz;
+  for (int64_t i = 0; i < 3 * total; i++) extrema[i] = -INFINITY;
+  int64_t* path = (int64_t*)malloc((size_t)(total + 1) * sizeof(int64_t));
+  int64_t* stamp = (int64_t*)calloc((size_t)total, sizeof(int64_t)); /* walk id that last put the cell on its path */
+  int64_t walk = 0;
+  for (int64_t x_idx = 0; x_idx < nx; x_idx++)
+    for (int64_t y_idx = 0; y_idx < ny; y_idx++)
+      for (int64_t z_idx = 0; z_idx < nz; z_idx++)
+      {
+        const int64_t start = (x_idx * ny + y_idx) * nz + z_idx;
+        if (extrema[3 * start] != -INFINITY && extrema[3 * start + 1] != -INFINITY && extrema[3 * start + 2] != -INFINITY)
+          continue; /* already found for this cell */
+        double gradient_vector[3];
+        coarse_gradient_with_edges(sdf, nx, ny, nz, resolution, rotation, x_idx, y_idx, z_idx, gradient_vector);
+        if (gradient_is_effective_flat(gradient_vector, resolution))
+        {
+          extrema[3 * start] = ((double)x_idx + 0.5) * resolution;
+          extrema[3 * start + 1] = ((double)y_idx + 0.5) * resolution;
+          extrema[3 * start + 2] = ((double)z_idx + 0.5) * resolution;
+          continue;
+        }
+        walk++;
+        int64_t path_length = 0;
+        int64_t current_index[3] = {x_idx, y_idx, z_idx};
+        path[path_length++] = start;
+        stamp[start] = walk;
+        double local_extrema[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (;;)
+        {
+          int64_t next_index[3];
+          next_from_gradient(sdf, ny, nz, resolution, current_index, gradient_vector, next_index);
+          for (int a = 0; a < 3; a++) current_index[a] = next_index[a];
+          const int in_bounds = current_index[0] >= 0 && current_index[0] < nx && current_index[1] >= 0 &&
+                                current_index[1] < ny && current_index[2] >= 0 && current_index[2] < nz;
+          const int64_t current = in_bounds ? (current_index[0] * ny + current_index[1]) * nz + current_index[2] : -1;
+          if (in_bounds && stamp[current] == walk)
+          {
+            /* we have been here on this walk: done */
+            for (int a = 0; a < 3; a++) local_extrema[a] = ((double)current_index[a] + 0.5) * resolution;
+            break;
+          }
+          if (!in_bounds)
+          {
+            for (int a = 0; a < 3; a++) local_extrema[a] = INFINITY;
+            break;
+          }
+          path[path_length++] = current;
+          stamp[current] = walk;
+          if (extrema[3 * current] != -INFINITY && extrema[3 * current + 1] != -INFINITY &&
+              extrema[3 * current + 2] != -INFINITY)
+          {
+            for (int a = 0; a < 3; a++) local_extrema[a] = extrema[3 * current + a];
+            break;
+          }
+          coarse_gradient_with_edges(sdf, nx, ny, nz, resolution, rotation, current_index[0], current_index[1],
+                                     current_index[2], gradient_vector);
+          if (gradient_is_effective_flat(gradient_vector, resolution))
+          {
+            for (int a = 0; a < 3; a++) local_extrema[a] = ((double)current_index[a] + 0.5) * resolution;
+            break;
+          }
+        }
+        for (int64_t k = 0; k < path_length; k++)
+          for (int a = 0; a < 3; a++) extrema[3 * path[k] + a] = local_extrema[a];
+      }
+  free(path);
+  free(stamp);
+}
+
+/* ------------------------------------------------------------------------- */
 /* SDF consumer: coarse gradient.                               */
 /* ------------------------------------------------------------------------- */
 

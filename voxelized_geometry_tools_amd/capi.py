@@ -62,6 +62,11 @@ SIGNATURES = {
     "vgt_hip_sdf_from_mask_u8": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _p, _p, _p]),
     "vgt_hip_sdf_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "vgt_hip_sdf_workspace_bytes_for_variant": (_sz, [_i64, _i64, _i64, _int]),
+    "vgt_hip_sdf_estimate_distance": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p, _i64, _p, _p]),
+    "vgt_hip_sdf_estimate_distance_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p, _i64, _p, _p]),
+    "vgt_hip_sdf_fine_gradient": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p, _i64, _f64, _p, _p]),
+    "vgt_hip_sdf_local_extrema_map": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p]),
+    "vgt_hip_sdf_local_extrema_map_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p]),
     "vgt_hipx_sdf_multi": (_int, [_p, _int, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
@@ -187,6 +192,37 @@ class Context:
 
     def __exit__(self, *exc):
         self.close()
+
+    def sdf_estimate_distance(self, sdf, resolution, queries, grid_from_world=None):
+        """EstimateLocationDistance for a batch of query points [N, 3] -> (distance [N] float64, has_value [N] bool)."""
+        field = np.ascontiguousarray(sdf, dtype=np.float32)
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+        xf = None if grid_from_world is None else np.ascontiguousarray(grid_from_world, dtype=np.float64).reshape(16)
+        out = np.empty(len(q), dtype=np.float64)
+        has = np.empty(len(q), dtype=np.uint8)
+        check(self._lib.vgt_hip_sdf_estimate_distance(self.handle, _ptr(field), *field.shape, float(resolution), _ptr(xf),
+                                                      _ptr(q), len(q), _ptr(out), _ptr(has)))
+        return out, has.astype(bool)
+
+    def sdf_fine_gradient(self, sdf, resolution, queries, window, grid_from_world=None):
+        """GetLocationFineGradient for a batch of query points [N, 3] -> (gradient [N, 3] float64, has_value [N] bool)."""
+        field = np.ascontiguousarray(sdf, dtype=np.float32)
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, 3)
+        xf = None if grid_from_world is None else np.ascontiguousarray(grid_from_world, dtype=np.float64).reshape(16)
+        out = np.empty((len(q), 3), dtype=np.float64)
+        has = np.empty(len(q), dtype=np.uint8)
+        check(self._lib.vgt_hip_sdf_fine_gradient(self.handle, _ptr(field), *field.shape, float(resolution), _ptr(xf),
+                                                  _ptr(q), len(q), float(window), _ptr(out), _ptr(has)))
+        return out, has.astype(bool)
+
+    def sdf_local_extrema_map(self, sdf, resolution, rotation=None):
+        """ComputeLocalExtremaMap: [nx, ny, nz, 3] float64 (grid-frame extremum location per voxel, +inf = off the grid)."""
+        field = np.ascontiguousarray(sdf, dtype=np.float32)
+        rot = None if rotation is None else np.ascontiguousarray(rotation, dtype=np.float64).reshape(9)
+        out = np.empty(field.shape + (3,), dtype=np.float64)
+        check(self._lib.vgt_hip_sdf_local_extrema_map(self.handle, _ptr(field), *field.shape, float(resolution),
+                                                      _ptr(rot), _ptr(out)))
+        return out
 
     def trim(self):
         """Frees the device buffers the context caches between host-pointer calls."""

@@ -244,6 +244,218 @@ __global__ __launch_bounds__(256) void CoarseGradientKernel(const float* __restr
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// SDF consumers, batched queries: SignedDistanceField::EstimateLocationDistance (trilinear estimate,
+// signed_distance_field.hpp:808-833 over :300-378) and ::GetLocationFineGradient (:1050-1091 over
+// :214-254).  One thread per query point.
+//
+// Operation order (the part of the reference that lives in common_robotics_utilities, whose source is
+// not available here, is TrilinearInterpolate; this is the order used, in double, no FMA contraction):
+//   g        = M * (x, y, z, 1), M = grid_from_world (InverseOriginTransform, column-major), row by row,
+//              left to right (identity when M is NULL)
+//   index    = floor(g * (1 / resolution)) per axis; out of bounds -> no value
+//   centre   = (index + 0.5) * resolution; offset = g - centre; (lower, upper) per axis by
+//              GetAxisInterpolationIndices (:276-313)
+//   corners  = double(sdf) -/+ resolution * 0.5 (GetCorrectedCenterDistance, :259-273)
+//   low      = (lower + 0.5) * resolution; t = (g - low) / ((low + resolution) - low) per axis
+//   along x first, then y, then z, each as a * (1 - t) + b * t.
+// Agreement with the reference is therefore to rounding (tests: 1e-5 absolute, the tolerance of
+// BASELINE.json), bit-exact against the oracle's restatement of the same order.
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+struct GridFromWorld
+{
+  double m[16];
+  int enabled;
+};
+
+struct EstimateResult
+{
+  double value;
+  bool has_value;
+};
+
+__device__ __forceinline__ void AxisInterpolationIndices(int initial, int size, double offset, int& lower, int& upper)
+{
+  lower = initial;
+  upper = initial;
+  if (offset >= 0.0)
+  {
+    upper = initial + 1;
+    if (upper >= size)
+    {
+      upper = initial;
+      lower = initial - 1;
+      if (lower < 0) lower = initial;
+    }
+  }
+  else
+  {
+    lower = initial - 1;
+    if (lower < 0)
+    {
+      upper = initial + 1;
+      lower = initial;
+      if (upper >= size) upper = initial;
+    }
+  }
+}
+
+__device__ __forceinline__ double CorrectedCenterDistance(const float* __restrict__ sdf, int64_t index, double resolution)
+{
+  const double nominal = static_cast<double>(sdf[index]);
+  const double offset = resolution * 0.5;
+  return (nominal >= 0.0) ? nominal - offset : nominal + offset;
+}
+
+__device__ __forceinline__ double Lerp(double a, double b, double t) { return a * (1.0 - t) + b * t; }
+
+__device__ EstimateResult EstimateDistance(const float* __restrict__ sdf, int nx, int ny, int nz, double resolution,
+                                           const GridFromWorld& xf, double x, double y, double z)
+{
+  EstimateResult r{0.0, false};
+  double g[3] = {x, y, z};
+  if (xf.enabled)
+  {
+    const double* M = xf.m;
+    g[0] = M[0] * x + M[4] * y + M[8] * z + M[12];
+    g[1] = M[1] * x + M[5] * y + M[9] * z + M[13];
+    g[2] = M[2] * x + M[6] * y + M[10] * z + M[14];
+  }
+  const double inv = 1.0 / resolution;
+  const double fx = floor(g[0] * inv), fy = floor(g[1] * inv), fz = floor(g[2] * inv);
+  if (!(fx >= 0.0 && fx < nx && fy >= 0.0 && fy < ny && fz >= 0.0 && fz < nz)) return r;  // also rejects NaN
+  const int ix = static_cast<int>(fx), iy = static_cast<int>(fy), iz = static_cast<int>(fz);
+  const double cx = (static_cast<double>(ix) + 0.5) * resolution;
+  const double cy = (static_cast<double>(iy) + 0.5) * resolution;
+  const double cz = (static_cast<double>(iz) + 0.5) * resolution;
+  int lx, ux, ly, uy, lz, uz;
+  AxisInterpolationIndices(ix, nx, g[0] - cx, lx, ux);
+  AxisInterpolationIndices(iy, ny, g[1] - cy, ly, uy);
+  AxisInterpolationIndices(iz, nz, g[2] - cz, lz, uz);
+  const int64_t sx = static_cast<int64_t>(ny) * nz, sy = nz;
+  auto at = [&](int a, int b, int c) { return CorrectedCenterDistance(sdf, a * sx + b * sy + c, resolution); };
+  const double mmm = at(lx, ly, lz), mmp = at(lx, ly, uz), mpm = at(lx, uy, lz), mpp = at(lx, uy, uz);
+  const double pmm = at(ux, ly, lz), pmp = at(ux, ly, uz), ppm = at(ux, uy, lz), ppp = at(ux, uy, uz);
+  const double low_x = (static_cast<double>(lx) + 0.5) * resolution;
+  const double low_y = (static_cast<double>(ly) + 0.5) * resolution;
+  const double low_z = (static_cast<double>(lz) + 0.5) * resolution;
+  const double tx = (g[0] - low_x) / ((low_x + resolution) - low_x);
+  const double ty = (g[1] - low_y) / ((low_y + resolution) - low_y);
+  const double tz = (g[2] - low_z) / ((low_z + resolution) - low_z);
+  const double mm = Lerp(mmm, pmm, tx), mp = Lerp(mmp, pmp, tx), pm = Lerp(mpm, ppm, tx), pp = Lerp(mpp, ppp, tx);
+  const double lo = Lerp(mm, pm, ty), hi = Lerp(mp, pp, ty);
+  r.value = Lerp(lo, hi, tz);
+  r.has_value = true;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void EstimateDistanceKernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                             double resolution, const GridFromWorld xf,
+                                                             const double* __restrict__ queries, int64_t num_queries,
+                                                             double* __restrict__ distance,
+                                                             uint8_t* __restrict__ has_value)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_queries;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const EstimateResult r = EstimateDistance(sdf, nx, ny, nz, resolution, xf, queries[3 * i], queries[3 * i + 1],
+                                              queries[3 * i + 2]);
+    distance[i] = r.has_value ? r.value : __longlong_as_double(0x7ff8000000000000ll);
+    if (has_value) has_value[i] = r.has_value ? 1 : 0;
+  }
+}
+
+// ComputeAxisFineGradient (:214-254); returns false for the reference's "window too large" throw
+__device__ __forceinline__ bool AxisFineGradient(const EstimateResult& point, const EstimateResult& minus,
+                                                 const EstimateResult& plus, double q, double lo, double hi,
+                                                 double& gradient)
+{
+  if (point.has_value && minus.has_value && plus.has_value)
+    gradient = (plus.value - minus.value) / (hi - lo);
+  else if (point.has_value && minus.has_value)
+    gradient = (point.value - minus.value) / (q - lo);
+  else if (point.has_value && plus.has_value)
+    gradient = (plus.value - point.value) / (hi - q);
+  else
+    return false;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void FineGradientKernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                         double resolution, const GridFromWorld xf,
+                                                         const double* __restrict__ queries, int64_t num_queries,
+                                                         double window, double* __restrict__ gradient,
+                                                         uint8_t* __restrict__ has_value,
+                                                         uint32_t* __restrict__ window_too_large)
+{
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_queries;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const double x = queries[3 * i], y = queries[3 * i + 1], z = queries[3 * i + 2];
+    const EstimateResult point = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x, y, z);
+    double gx = nan, gy = nan, gz = nan;
+    bool ok = point.has_value;  // CheckLocationInBounds == the estimate has a value
+    if (ok)
+    {
+      const EstimateResult mx = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x - window, y, z);
+      const EstimateResult px = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x + window, y, z);
+      const EstimateResult my = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x, y - window, z);
+      const EstimateResult py = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x, y + window, z);
+      const EstimateResult mz = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x, y, z - window);
+      const EstimateResult pz = EstimateDistance(sdf, nx, ny, nz, resolution, xf, x, y, z + window);
+      const bool fine = AxisFineGradient(point, mx, px, x, x - window, x + window, gx) &&
+                        AxisFineGradient(point, my, py, y, y - window, y + window, gy) &&
+                        AxisFineGradient(point, mz, pz, z, z - window, z + window, gz);
+      if (!fine)
+      {
+        atomicOr(window_too_large, 1u);
+        ok = false;
+        gx = gy = gz = nan;
+      }
+    }
+    gradient[3 * i] = gx;
+    gradient[3 * i + 1] = gy;
+    gradient[3 * i + 2] = gz;
+    if (has_value) has_value[i] = ok ? 1 : 0;
+  }
+}
+
+GridFromWorld MakeGridFromWorld(const double* grid_from_world_host)
+{
+  GridFromWorld xf;
+  xf.enabled = grid_from_world_host ? 1 : 0;
+  for (int k = 0; k < 16; k++) xf.m[k] = grid_from_world_host ? grid_from_world_host[k] : 0.0;
+  return xf;
+}
+}  // namespace
+
+hipError_t LaunchEstimateDistance(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                  const double* grid_from_world_host, const double* queries_dev, int64_t num_queries,
+                                  double* distance_dev, uint8_t* has_value_dev, hipStream_t stream)
+{
+  if (num_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(EstimateDistanceKernel, dim3(CellGrid(num_queries)), dim3(256), 0, stream, sdf_dev,
+                     static_cast<int>(nx), static_cast<int>(ny), static_cast<int>(nz), resolution,
+                     MakeGridFromWorld(grid_from_world_host), queries_dev, num_queries, distance_dev, has_value_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchFineGradient(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              const double* grid_from_world_host, const double* queries_dev, int64_t num_queries,
+                              double nominal_window_size, double* gradient_dev, uint8_t* has_value_dev,
+                              uint32_t* window_too_large_dev, hipStream_t stream)
+{
+  if (num_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(FineGradientKernel, dim3(CellGrid(num_queries)), dim3(256), 0, stream, sdf_dev,
+                     static_cast<int>(nx), static_cast<int>(ny), static_cast<int>(nz), resolution,
+                     MakeGridFromWorld(grid_from_world_host), queries_dev, num_queries, fabs(nominal_window_size),
+                     gradient_dev, has_value_dev, window_too_large_dev);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCoarseGradient(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
                                 int enable_edge_gradients, const double* rotation_host, double* gradient_dev,
                                 uint8_t* has_value_dev, hipStream_t stream)
@@ -256,4 +468,240 @@ hipError_t LaunchCoarseGradient(const float* sdf_dev, int64_t nx, int64_t ny, in
                      enable_edge_gradients, rot, gradient_dev, has_value_dev);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// SDF consumer: SignedDistanceField::ComputeLocalExtremaMap (signed_distance_field.hpp:1205-1231 over
+// FollowGradientsToLocalExtremaUnsafe :385-480, GradientIsEffectiveFlat :482-497, GetNextFromGradient
+// :499-541).  The reference follows, from every cell in X-major order, the coarse gradient (edge gradients
+// on, rotated by the origin transform) one cell at a time -- up the field outside obstacles, down inside --
+// until it meets a flat cell, leaves the grid, meets a cell whose answer is known, or revisits a cell of its
+// own path, and stores the grid-frame location of the cell it ended at in every cell of the path.
+//
+// Every cell has exactly one successor, so the cells form a functional graph and the stored value of a cell
+// is a property of where its chain ends:
+//   * a cell that is its own successor (flat gradient, or no component beyond the step threshold): its location;
+//   * a successor outside the grid: +infinity in all three components;
+//   * a cycle of two or more cells: the reference stores the location of the cycle cell at which the FIRST walk
+//     that reaches the cycle entered it, and walks start in X-major order, so that is the entry cell of the
+//     chain from the smallest cell index of the cycle's basin.
+// Device formulation: successor table -> pointer doubling to a representative of every chain's end ->
+// cycles are walked once for their smallest member and membership marks -> per cycle the smallest basin
+// index (atomicMin) -> its chain is walked to the entry cell -> labels.
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+constexpr int32_t kOffGrid = -2;
+
+__device__ __forceinline__ bool EffectiveFlat(double gx, double gy, double gz, double step)
+{
+  return fabs(gx) <= step && fabs(gy) <= step && fabs(gz) <= step;
+}
+
+__global__ __launch_bounds__(256) void ExtremaSuccessorKernel(const float* __restrict__ sdf, int nx, int ny, int nz,
+                                                             double resolution, const Rotation rot,
+                                                             int32_t* __restrict__ next)
+{
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  const int64_t sx = static_cast<int64_t>(ny) * nz, sy = nz;
+  const double step = resolution * 0.06125;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int z = static_cast<int>(i % nz);
+    const int y = static_cast<int>((i / nz) % ny);
+    const int x = static_cast<int>(i / sx);
+    // GetGridAlignedIndexCoarseGradient with edge gradients (:923-1016), then the rotation (:906-921)
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    if (x > 0 && y > 0 && z > 0 && x < nx - 1 && y < ny - 1 && z < nz - 1)
+    {
+      const double inv_twice_resolution = 1.0 / (2.0 * resolution);
+      gx = static_cast<double>(sdf[i + sx] - sdf[i - sx]) * inv_twice_resolution;
+      gy = static_cast<double>(sdf[i + sy] - sdf[i - sy]) * inv_twice_resolution;
+      gz = static_cast<double>(sdf[i + 1] - sdf[i - 1]) * inv_twice_resolution;
+    }
+    else
+    {
+      const int lx = max(0, x - 1), hx = min(nx - 1, x + 1);
+      const int ly = max(0, y - 1), hy = min(ny - 1, y + 1);
+      const int lz = max(0, z - 1), hz = min(nz - 1, z + 1);
+      const double x_increment = static_cast<double>(hx - lx) * resolution;
+      const double y_increment = static_cast<double>(hy - ly) * resolution;
+      const double z_increment = static_cast<double>(hz - lz) * resolution;
+      if (x_increment > 0.0)
+        gx = (static_cast<double>(sdf[i + (hx - x) * sx]) - static_cast<double>(sdf[i - (x - lx) * sx])) *
+             (1.0 / x_increment);
+      if (y_increment > 0.0)
+        gy = (static_cast<double>(sdf[i + (hy - y) * sy]) - static_cast<double>(sdf[i - (y - ly) * sy])) *
+             (1.0 / y_increment);
+      if (z_increment > 0.0)
+        gz = (static_cast<double>(sdf[i + (hz - z)]) - static_cast<double>(sdf[i - (z - lz)])) * (1.0 / z_increment);
+    }
+    if (rot.enabled)
+    {
+      const double wx = rot.m[0] * gx + rot.m[1] * gy + rot.m[2] * gz;
+      const double wy = rot.m[3] * gx + rot.m[4] * gy + rot.m[5] * gz;
+      const double wz = rot.m[6] * gx + rot.m[7] * gy + rot.m[8] * gz;
+      gx = wx;
+      gy = wy;
+      gz = wz;
+    }
+    int32_t successor = static_cast<int32_t>(i);
+    if (!EffectiveFlat(gx, gy, gz, step))
+    {
+      // GetNextFromGradient: downhill inside an obstacle, uphill outside
+      if (sdf[i] < 0.0f)
+      {
+        gx = gx * -1.0;
+        gy = gy * -1.0;
+        gz = gz * -1.0;
+      }
+      int tx = x, ty = y, tz = z;
+      if (gx > step) tx += 1; else if (gx < -step) tx -= 1;
+      if (gy > step) ty += 1; else if (gy < -step) ty -= 1;
+      if (gz > step) tz += 1; else if (gz < -step) tz -= 1;
+      if (tx < 0 || tx >= nx || ty < 0 || ty >= ny || tz < 0 || tz >= nz)
+        successor = kOffGrid;
+      else
+        successor = static_cast<int32_t>(tx * sx + ty * sy + tz);
+    }
+    next[i] = successor;
+  }
+}
+
+// one round of pointer doubling, in place (an entry read mid-update is still a valid, farther jump)
+__global__ __launch_bounds__(256) void ExtremaJumpKernel(int32_t* __restrict__ jump, int64_t total)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int32_t j = jump[i];
+    if (j >= 0)
+    {
+      const int32_t jj = jump[j];
+      if (jj != j) jump[i] = jj;
+    }
+  }
+}
+
+// representatives that sit on a cycle of two or more cells: walk the cycle once for its smallest member, once
+// more to mark every member with it (idempotent: representatives of the same cycle write the same values)
+__global__ __launch_bounds__(256) void ExtremaCycleKernel(const int32_t* __restrict__ next,
+                                                         const int32_t* __restrict__ jump, int64_t total,
+                                                         int32_t* __restrict__ cycle_id)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int32_t r = jump[i];
+    if (r < 0 || next[r] == r) continue;  // chain leaves the grid or ends at a fixed cell
+    if (cycle_id[r] >= 0) continue;       // another thread has taken this cycle (it finishes within this launch)
+    int32_t smallest = r;
+    for (int32_t w = next[r]; w != r; w = next[w]) smallest = min(smallest, w);
+    cycle_id[r] = smallest;
+    for (int32_t w = next[r]; w != r; w = next[w]) cycle_id[w] = smallest;
+  }
+}
+
+__global__ __launch_bounds__(256) void ExtremaBasinMinKernel(const int32_t* __restrict__ jump,
+                                                            const int32_t* __restrict__ cycle_id, int64_t total,
+                                                            int32_t* __restrict__ basin_min)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int32_t r = jump[i];
+    if (r < 0) continue;
+    const int32_t c = cycle_id[r];
+    if (c >= 0) atomicMin(&basin_min[c], static_cast<int32_t>(i));
+  }
+}
+
+// per cycle (thread of its smallest member): the cycle cell at which the chain from the basin's smallest cell enters
+__global__ __launch_bounds__(256) void ExtremaEntryKernel(const int32_t* __restrict__ next,
+                                                         const int32_t* __restrict__ cycle_id,
+                                                         const int32_t* __restrict__ basin_min, int64_t total,
+                                                         int32_t* __restrict__ entry)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    if (cycle_id[i] != static_cast<int32_t>(i)) continue;
+    int32_t w = basin_min[i];
+    while (cycle_id[w] != static_cast<int32_t>(i)) w = next[w];
+    entry[i] = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void ExtremaLabelKernel(const int32_t* __restrict__ next,
+                                                         const int32_t* __restrict__ jump,
+                                                         const int32_t* __restrict__ cycle_id,
+                                                         const int32_t* __restrict__ entry, int nx, int ny, int nz,
+                                                         double resolution, double* __restrict__ extrema)
+{
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  const int64_t sx = static_cast<int64_t>(ny) * nz;
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const int32_t r = jump[i];
+    double ex = inf, ey = inf, ez = inf;
+    if (r >= 0)
+    {
+      const int32_t c = cycle_id[r];
+      const int32_t cell = (c >= 0) ? entry[c] : r;
+      // GridIndexToLocationInGridFrame: the cell centre
+      ex = (static_cast<double>(cell / sx) + 0.5) * resolution;
+      ey = (static_cast<double>((cell / nz) % ny) + 0.5) * resolution;
+      ez = (static_cast<double>(cell % nz) + 0.5) * resolution;
+    }
+    extrema[3 * i] = ex;
+    extrema[3 * i + 1] = ey;
+    extrema[3 * i + 2] = ez;
+  }
+}
+
+__global__ __launch_bounds__(256) void FillInt32Kernel(int32_t* __restrict__ p, int64_t total, int32_t value)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    p[i] = value;
+}
+}  // namespace
+
+size_t LocalExtremaScratchBytes(int64_t num_cells) { return static_cast<size_t>(num_cells) * 5 * sizeof(int32_t); }
+
+// scratch_dev: LocalExtremaScratchBytes(nx * ny * nz) bytes.  num_cells must be below 2^31.
+hipError_t LaunchLocalExtremaMap(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                 const double* rotation_host, double* extrema_dev, void* scratch_dev,
+                                 hipStream_t stream)
+{
+  const int64_t total = nx * ny * nz;
+  int32_t* next = static_cast<int32_t*>(scratch_dev);
+  int32_t* jump = next + total;
+  int32_t* cycle_id = jump + total;
+  int32_t* basin_min = cycle_id + total;
+  int32_t* entry = basin_min + total;
+  Rotation rot;
+  rot.enabled = rotation_host ? 1 : 0;
+  for (int k = 0; k < 9; k++) rot.m[k] = rotation_host ? rotation_host[k] : 0.0;
+  const dim3 grid(CellGrid(total)), block(256);
+  hipLaunchKernelGGL(ExtremaSuccessorKernel, grid, block, 0, stream, sdf_dev, static_cast<int>(nx),
+                     static_cast<int>(ny), static_cast<int>(nz), resolution, rot, next);
+  hipError_t err = hipMemcpyAsync(jump, next, static_cast<size_t>(total) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+  if (err != hipSuccess) return err;
+  // after k rounds every entry has advanced at least 2^k steps along its chain (or reached its end)
+  int rounds = 1;
+  while ((int64_t{1} << rounds) < total) rounds++;
+  for (int k = 0; k < rounds; k++) hipLaunchKernelGGL(ExtremaJumpKernel, grid, block, 0, stream, jump, total);
+  hipLaunchKernelGGL(FillInt32Kernel, grid, block, 0, stream, cycle_id, total, int32_t{-1});
+  hipLaunchKernelGGL(FillInt32Kernel, grid, block, 0, stream, basin_min, total, int32_t{0x7fffffff});
+  hipLaunchKernelGGL(ExtremaCycleKernel, grid, block, 0, stream, next, jump, total, cycle_id);
+  hipLaunchKernelGGL(ExtremaBasinMinKernel, grid, block, 0, stream, jump, cycle_id, total, basin_min);
+  hipLaunchKernelGGL(ExtremaEntryKernel, grid, block, 0, stream, next, cycle_id, basin_min, total, entry);
+  hipLaunchKernelGGL(ExtremaLabelKernel, grid, block, 0, stream, next, jump, cycle_id, entry, static_cast<int>(nx),
+                     static_cast<int>(ny), static_cast<int>(nz), resolution, extrema_dev);
+  return hipGetLastError();
+}
+
 }  // namespace vgt

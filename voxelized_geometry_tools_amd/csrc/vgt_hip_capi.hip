@@ -402,6 +402,54 @@ int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratc
   VGT_TRY_HIP(hipStreamSynchronize(lane.stream), "raycast");
   return VGT_HIP_OK;
 }
+// Shared body of the batched SDF queries: `run(sdf_dev, queries_dev, out_dev, has_dev, flag_dev)` enqueues the
+// kernel.  Host variant: uploads field and queries, downloads the results.  out_doubles = doubles per query.
+template <typename Run>
+int SdfQueriesHost(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                   const double* query_xyz_host, int64_t num_queries, int out_doubles, double* out_host,
+                   uint8_t* has_value_host, const char* what, Run run)
+{
+  if (!ctx || !sdf_host || !out_host || num_queries < 0 || (num_queries > 0 && !query_xyz_host))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_queries == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const size_t n = static_cast<size_t>(nx * ny * nz), q = static_cast<size_t>(num_queries);
+  float* sdf_dev = nullptr;
+  double* queries_dev = nullptr;
+  double* out_dev = nullptr;
+  uint8_t* has_dev = nullptr;
+  uint32_t* flag_dev = nullptr;
+  uint32_t flag = 0;
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&sdf_dev), n * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&queries_dev), q * 3 * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&out_dev), q * out_doubles * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&has_dev), q);
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&flag_dev), 256);
+  if (err == hipSuccess)
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    hipStream_t s = ctx->stream;
+    err = hipMemcpyAsync(sdf_dev, sdf_host, n * sizeof(float), hipMemcpyHostToDevice, s);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(queries_dev, query_xyz_host, q * 3 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) err = hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), s);
+    if (err == hipSuccess) err = run(sdf_dev, queries_dev, out_dev, has_dev, flag_dev, s);
+    if (err == hipSuccess)
+      err = hipMemcpyAsync(out_host, out_dev, q * out_doubles * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess && has_value_host) err = hipMemcpyAsync(has_value_host, has_dev, q, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipMemcpyAsync(&flag, flag_dev, sizeof(flag), hipMemcpyDeviceToHost, s);
+    const hipError_t sync = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = sync;
+  }
+  for (void* p : {static_cast<void*>(sdf_dev), static_cast<void*>(queries_dev), static_cast<void*>(out_dev),
+                  static_cast<void*>(has_dev), static_cast<void*>(flag_dev)})
+    if (p) (void)hipFree(p);
+  VGT_TRY_HIP(err, what);
+  if (flag) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "Window size for fine gradient is too large for SDF");
+  return VGT_HIP_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1342,6 +1390,111 @@ int vgt_hip_sdf_coarse_gradient(vgt_hip_ctx* ctx, const float* sdf_host, int64_t
   if (grad_dev) (void)hipFree(grad_dev);
   if (has_dev) (void)hipFree(has_dev);
   VGT_TRY_HIP(err, "coarse gradient");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_sdf_estimate_distance_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      double resolution, const double* grid_from_world, const double* query_xyz_dev,
+                                      int64_t num_queries, double* distance_dev, uint8_t* has_value_dev)
+{
+  if (!ctx || !sdf_dev || !distance_dev || num_queries < 0 || (num_queries > 0 && !query_xyz_dev))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(vgt::LaunchEstimateDistance(sdf_dev, nx, ny, nz, resolution, grid_from_world, query_xyz_dev, num_queries,
+                                          distance_dev, has_value_dev, ctx->stream),
+              "estimate distance");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_sdf_estimate_distance(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                                  double resolution, const double* grid_from_world, const double* query_xyz_host,
+                                  int64_t num_queries, double* distance_host, uint8_t* has_value_host)
+{
+  return SdfQueriesHost(ctx, sdf_host, nx, ny, nz, resolution, query_xyz_host, num_queries, 1, distance_host,
+                        has_value_host, "estimate distance",
+                        [&](const float* sdf_dev, const double* queries_dev, double* out_dev, uint8_t* has_dev,
+                            uint32_t*, hipStream_t s) {
+                          return vgt::LaunchEstimateDistance(sdf_dev, nx, ny, nz, resolution, grid_from_world,
+                                                             queries_dev, num_queries, out_dev, has_dev, s);
+                        });
+}
+
+int vgt_hip_sdf_fine_gradient(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                              double resolution, const double* grid_from_world, const double* query_xyz_host,
+                              int64_t num_queries, double nominal_window_size, double* gradient_host,
+                              uint8_t* has_value_host)
+{
+  if (!std::isfinite(nominal_window_size) || nominal_window_size == 0.0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "the fine-gradient window must be finite and non-zero");
+  return SdfQueriesHost(ctx, sdf_host, nx, ny, nz, resolution, query_xyz_host, num_queries, 3, gradient_host,
+                        has_value_host, "fine gradient",
+                        [&](const float* sdf_dev, const double* queries_dev, double* out_dev, uint8_t* has_dev,
+                            uint32_t* flag_dev, hipStream_t s) {
+                          return vgt::LaunchFineGradient(sdf_dev, nx, ny, nz, resolution, grid_from_world, queries_dev,
+                                                         num_queries, nominal_window_size, out_dev, has_dev, flag_dev,
+                                                         s);
+                        });
+}
+
+int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      double resolution, const double* rotation, double* extrema_dev)
+{
+  if (!ctx || !sdf_dev || !extrema_dev) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  if (nx * ny * nz >= 0x7fffffffLL)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "the local extrema map supports grids below 2^31 cells");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  void* scratch = nullptr;
+  VGT_TRY_HIP(hipMalloc(&scratch, vgt::LocalExtremaScratchBytes(nx * ny * nz)), "allocate extrema scratch");
+  hipError_t err;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    err = vgt::LaunchLocalExtremaMap(sdf_dev, nx, ny, nz, resolution, rotation, extrema_dev, scratch, ctx->stream);
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);  // the scratch is freed below
+    if (err == hipSuccess) err = sync;
+  }
+  (void)hipFree(scratch);
+  VGT_TRY_HIP(err, "local extrema map");
+  return VGT_HIP_OK;
+}
+
+int vgt_hip_sdf_local_extrema_map(vgt_hip_ctx* ctx, const float* sdf_host, int64_t nx, int64_t ny, int64_t nz,
+                                  double resolution, const double* rotation, double* extrema_host)
+{
+  if (!ctx || !sdf_host || !extrema_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const size_t n = static_cast<size_t>(nx * ny * nz);
+  float* sdf_dev = nullptr;
+  double* out_dev = nullptr;
+  hipError_t err = hipMalloc(reinterpret_cast<void**>(&sdf_dev), n * sizeof(float));
+  if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&out_dev), n * 3 * sizeof(double));
+  int result = VGT_HIP_OK;
+  if (err == hipSuccess)
+  {
+    {
+      std::lock_guard<std::mutex> lock(ctx->mutex);
+      err = hipMemcpyAsync(sdf_dev, sdf_host, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (err == hipSuccess)
+      result = vgt_hip_sdf_local_extrema_map_dev(ctx, sdf_dev, nx, ny, nz, resolution, rotation, out_dev);
+    if (err == hipSuccess && result == VGT_HIP_OK)
+    {
+      std::lock_guard<std::mutex> lock(ctx->mutex);
+      err = hipMemcpyAsync(extrema_host, out_dev, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      const hipError_t sync = hipStreamSynchronize(ctx->stream);
+      if (err == hipSuccess) err = sync;
+    }
+  }
+  if (sdf_dev) (void)hipFree(sdf_dev);
+  if (out_dev) (void)hipFree(out_dev);
+  if (result != VGT_HIP_OK) return result;
+  VGT_TRY_HIP(err, "local extrema map");
   return VGT_HIP_OK;
 }
 

@@ -98,6 +98,23 @@ hipError_t LaunchCoarseGradient(const float* sdf_dev, int64_t nx, int64_t ny, in
                                 int enable_edge_gradients, const double* rotation_host, double* gradient_dev,
                                 uint8_t* has_value_dev, hipStream_t stream);
 
+// SDF consumers, batched queries (3 doubles per query point): trilinear distance estimate and fine gradient.
+// grid_from_world_host: 16 doubles column-major (InverseOriginTransform) or nullptr = identity.
+hipError_t LaunchEstimateDistance(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                  const double* grid_from_world_host, const double* queries_dev, int64_t num_queries,
+                                  double* distance_dev, uint8_t* has_value_dev, hipStream_t stream);
+hipError_t LaunchFineGradient(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                              const double* grid_from_world_host, const double* queries_dev, int64_t num_queries,
+                              double nominal_window_size, double* gradient_dev, uint8_t* has_value_dev,
+                              uint32_t* window_too_large_dev, hipStream_t stream);
+
+// SignedDistanceField::ComputeLocalExtremaMap: 3 doubles per voxel (grid-frame location of the extremum the
+// voxel's gradient chain ends at, +inf when it leaves the grid).  scratch_dev: LocalExtremaScratchBytes bytes.
+size_t LocalExtremaScratchBytes(int64_t num_cells);
+hipError_t LaunchLocalExtremaMap(const float* sdf_dev, int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                 const double* rotation_host, double* extrema_dev, void* scratch_dev,
+                                 hipStream_t stream);
+
 // --- launchers (voxelizer_kernels.hip) ---
 struct RaycastGridF32
 {
