@@ -64,6 +64,32 @@ SignedDistanceField ExtractSignedDistanceField(
 // returns the memory (e.g. after one very large grid).
 void ReleaseCachedDeviceMemory();
 
+// ---- SDF consumers on the device, batched: one call for many query points / all voxels ----
+// Results carry the reference's query semantics: has_value[i] == 0 <=> the reference's query object is empty.
+struct DistanceEstimates
+{
+  std::vector<double> distance;     // EstimateDistanceQuery::Value()
+  std::vector<uint8_t> has_value;   // EstimateDistanceQuery::HasValue()
+};
+struct Gradients
+{
+  std::vector<double> gradient;     // 3 per query / voxel: GradientQuery::Value().head<3>()
+  std::vector<uint8_t> has_value;
+};
+// SignedDistanceField::EstimateLocationDistance for every point of `locations_xyz` (3 doubles per point, in the
+// frame the field's origin transform maps to), signed_distance_field.hpp:808-833.
+DistanceEstimates EstimateLocationDistances(const SignedDistanceField& sdf, const std::vector<double>& locations_xyz,
+                                            int hip_device = 0);
+// SignedDistanceField::GetLocationFineGradient (:1050-1091); throws std::runtime_error("Window size for fine
+// gradient is too large for SDF") exactly when the reference does for one of the points.
+Gradients GetLocationFineGradients(const SignedDistanceField& sdf, const std::vector<double>& locations_xyz,
+                                   double nominal_window_size, int hip_device = 0);
+// SignedDistanceField::GetIndexCoarseGradient at every voxel (:906-1016), X-major / Z fastest.
+Gradients GetIndexCoarseGradients(const SignedDistanceField& sdf, bool enable_edge_gradients = false,
+                                  int hip_device = 0);
+// SignedDistanceField::ComputeLocalExtremaMap (:1205-1231): 3 doubles per voxel.
+std::vector<double> ComputeLocalExtremaMap(const SignedDistanceField& sdf, int hip_device = 0);
+
 // ---- the other three map types ----
 // OccupancyComponentMap::ExtractSignedDistanceField<float> (occupancy_component_map.hpp:270-306).
 SignedDistanceField ExtractSignedDistanceField(

@@ -161,6 +161,37 @@ static void MultiDeviceSdfTests()
   }
 }
 
+// SDF consumers through the C++ layer: on the field of one filled voxel the estimate at a cell centre is the stored
+// distance moved half a cell towards the surface, the fine and coarse gradients point away from the voxel, every
+// gradient chain outside ends off the grid or at a flat cell, and an oversized window throws like the reference.
+static void SdfConsumerTests()
+{
+  OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Translation(1.0, -2.0, 0.5), "test_frame", 0.5, 4.0, 4.0, 4.0, 0.0f);
+  m.SetIndex(3, 4, 2, 1.0f);
+  const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+  // world location of the centre of cell (6, 4, 2): origin translation + (idx + 0.5) * res
+  const std::vector<double> q = {1.0 + 6.5 * 0.5, -2.0 + 4.5 * 0.5, 0.5 + 2.5 * 0.5, 100.0, 0.0, 0.0};
+  const DistanceEstimates est = EstimateLocationDistances(sdf, q);
+  EXPECT_EQ(est.has_value[0], 1);
+  EXPECT_EQ(est.has_value[1], 0);
+  EXPECT_TRUE(std::abs(est.distance[0] - (3.0 * 0.5 - 0.25)) < 1e-6);
+  const Gradients fine = GetLocationFineGradients(sdf, {q[0], q[1], q[2]}, 0.1);
+  EXPECT_EQ(fine.has_value[0], 1);
+  EXPECT_TRUE(fine.gradient[0] > 0.9 && std::abs(fine.gradient[1]) < 1e-6 && std::abs(fine.gradient[2]) < 1e-6);
+  const Gradients coarse = GetIndexCoarseGradients(sdf, true);
+  const size_t cell = static_cast<size_t>((6 * 8 + 4) * 8 + 2);
+  EXPECT_EQ(coarse.has_value[cell], 1);
+  EXPECT_TRUE(std::abs(coarse.gradient[3 * cell] - 1.0) < 1e-6);
+  bool threw = false;
+  try { (void)GetLocationFineGradients(sdf, {q[0], q[1], q[2]}, 50.0); } catch (const std::runtime_error&) { threw = true; }
+  EXPECT_TRUE(threw);
+  const std::vector<double> extrema = ComputeLocalExtremaMap(sdf);
+  EXPECT_EQ(extrema.size(), static_cast<size_t>(3 * 8 * 8 * 8));
+  bool all_set = true;
+  for (const double v : extrema) all_set = all_set && !(v == -std::numeric_limits<double>::infinity()) && !std::isnan(v);
+  EXPECT_TRUE(all_set);
+}
+
 // ---- test/pointcloud_voxelization_test.cpp ----
 class VectorPointCloudWrapper : public PointCloudWrapper
 {
@@ -394,6 +425,7 @@ int main(int argc, char** argv)
   {
     SdfGenerationTests();
     MultiDeviceSdfTests();
+    SdfConsumerTests();
     TaggedObjectSdfTests();
     PointCloudVoxelizationTests(1);
     PointCloudVoxelizationTests(4);

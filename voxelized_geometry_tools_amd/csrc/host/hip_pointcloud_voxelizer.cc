@@ -3,6 +3,7 @@
 #include "../../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstddef>
@@ -245,8 +246,6 @@ SignedDistanceField ExtractSignedDistanceField(
   return sdf;
 }
 
-// ---- the other three map types (SURVEY.md 8f F2) ----
-
 namespace
 {
 [[noreturn]] void ThrowForCode(int rc, const std::string& msg)
@@ -254,7 +253,87 @@ namespace
   if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
   throw std::runtime_error(msg);
 }
+
+// rotation block of the field's origin transform, row-major (what the reference multiplies gradients with)
+std::array<double, 9> RotationOf(const Isometry3& t)
+{
+  std::array<double, 9> r{};
+  for (int row = 0; row < 3; row++)
+    for (int col = 0; col < 3; col++) r[static_cast<size_t>(row * 3 + col)] = t(row, col);
+  return r;
+}
 }  // namespace
+
+// ---- SDF consumers ----
+
+DistanceEstimates EstimateLocationDistances(const SignedDistanceField& sdf, const std::vector<double>& locations_xyz,
+                                            int hip_device)
+{
+  if (locations_xyz.size() % 3 != 0) throw std::invalid_argument("locations_xyz must hold 3 doubles per point");
+  const int64_t n = static_cast<int64_t>(locations_xyz.size() / 3);
+  DistanceEstimates out;
+  out.distance.resize(static_cast<size_t>(n));
+  out.has_value.resize(static_cast<size_t>(n));
+  const DenseGrid& g = sdf.grid;
+  const int rc = vgt_hip_sdf_estimate_distance(SharedSdfContext(hip_device), g.GetImmutableRawData().data(), g.NumXVoxels(),
+                                               g.NumYVoxels(), g.NumZVoxels(), g.Resolution(),
+                                               g.InverseOriginTransform().m.data(), locations_xyz.data(), n,
+                                               out.distance.data(), out.has_value.data());
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  return out;
+}
+
+Gradients GetLocationFineGradients(const SignedDistanceField& sdf, const std::vector<double>& locations_xyz,
+                                   double nominal_window_size, int hip_device)
+{
+  if (locations_xyz.size() % 3 != 0) throw std::invalid_argument("locations_xyz must hold 3 doubles per point");
+  const int64_t n = static_cast<int64_t>(locations_xyz.size() / 3);
+  Gradients out;
+  out.gradient.resize(static_cast<size_t>(3 * n));
+  out.has_value.resize(static_cast<size_t>(n));
+  const DenseGrid& g = sdf.grid;
+  const int rc = vgt_hip_sdf_fine_gradient(SharedSdfContext(hip_device), g.GetImmutableRawData().data(), g.NumXVoxels(),
+                                           g.NumYVoxels(), g.NumZVoxels(), g.Resolution(),
+                                           g.InverseOriginTransform().m.data(), locations_xyz.data(), n,
+                                           nominal_window_size, out.gradient.data(), out.has_value.data());
+  if (rc != VGT_HIP_OK)
+  {
+    const std::string msg = vgt_hip_last_error();
+    // the reference throws std::runtime_error for a window that leaves the field on both sides
+    if (msg.find("Window size") != std::string::npos) throw std::runtime_error(msg);
+    ThrowForCode(rc, msg);
+  }
+  return out;
+}
+
+Gradients GetIndexCoarseGradients(const SignedDistanceField& sdf, bool enable_edge_gradients, int hip_device)
+{
+  const DenseGrid& g = sdf.grid;
+  const size_t n = static_cast<size_t>(g.NumTotalVoxels());
+  Gradients out;
+  out.gradient.resize(3 * n);
+  out.has_value.resize(n);
+  const std::array<double, 9> rotation = RotationOf(g.OriginTransform());
+  const int rc = vgt_hip_sdf_coarse_gradient(SharedSdfContext(hip_device), g.GetImmutableRawData().data(), g.NumXVoxels(),
+                                             g.NumYVoxels(), g.NumZVoxels(), g.Resolution(), enable_edge_gradients ? 1 : 0,
+                                             rotation.data(), out.gradient.data(), out.has_value.data());
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  return out;
+}
+
+std::vector<double> ComputeLocalExtremaMap(const SignedDistanceField& sdf, int hip_device)
+{
+  const DenseGrid& g = sdf.grid;
+  std::vector<double> extrema(3 * static_cast<size_t>(g.NumTotalVoxels()));
+  const std::array<double, 9> rotation = RotationOf(g.OriginTransform());
+  const int rc = vgt_hip_sdf_local_extrema_map(SharedSdfContext(hip_device), g.GetImmutableRawData().data(),
+                                               g.NumXVoxels(), g.NumYVoxels(), g.NumZVoxels(), g.Resolution(),
+                                               rotation.data(), extrema.data());
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  return extrema;
+}
+
+// ---- the other three map types (SURVEY.md 8f F2) ----
 
 SignedDistanceField ExtractSignedDistanceField(
     const OccupancyComponentMap& map, const SignedDistanceFieldGenerationParameters& parameters)

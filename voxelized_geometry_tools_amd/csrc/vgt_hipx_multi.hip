@@ -18,7 +18,9 @@
 
 #include "vgt_internal.hpp"
 
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded on first use (below)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -27,6 +29,48 @@
 
 namespace
 {
+// librccl is half a gigabyte of code objects: linking it would make every user of libvgt_hip.so -- also the
+// single-GPU ones -- load and register it at start-up.  It is opened when the first multi-device extraction
+// with distinct devices asks for a communicator.
+struct Rccl
+{
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;  // why it is unavailable (empty = loaded)
+};
+
+const Rccl& GetRccl()
+{
+  static const Rccl api = [] {
+    Rccl r;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib)
+    {
+      r.error = std::string("librccl.so.1 could not be loaded: ") + dlerror();
+      return r;
+    }
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(lib, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.GetErrorString)
+      r.error = "librccl.so.1 lacks a required entry point";
+    return r;
+  }();
+  return api;
+}
+
 struct Slab
 {
   int device = -1;
@@ -62,7 +106,7 @@ struct MultiState
       if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
     for (ncclComm_t c : comms)
-      if (c) (void)ncclCommDestroy(c);
+      if (c) (void)GetRccl().CommDestroy(c);
     for (Slab& s : slabs)
     {
       if (s.device < 0) continue;
@@ -97,7 +141,7 @@ int FailMulti(int code, const std::string& msg)
   {                                                                                                    \
     const ncclResult_t r_ = (expr);                                                                    \
     if (r_ != ncclSuccess)                                                                             \
-      return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[") + (what) + "] RCCL error [" + ncclGetErrorString(r_) + "]"); \
+      return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[") + (what) + "] RCCL error [" + GetRccl().GetErrorString(r_) + "]"); \
   } while (0)
 #define VGTX_CALL(expr)                  \
   do                                     \
@@ -185,24 +229,27 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   // the one exchange: every slab receives every slab's per-line summary
   if (distinct)
   {
+    const Rccl& rccl = GetRccl();
+    if (!rccl.error.empty()) return FailMulti(VGT_HIP_ERR_UNAVAILABLE, rccl.error);
     st.comms.assign(static_cast<size_t>(world), nullptr);
     std::vector<int> devs(static_cast<size_t>(world));
     for (int r = 0; r < world; r++) devs[r] = st.slabs[r].device;
-    VGTX_NCCL(ncclCommInitAll(st.comms.data(), world, devs.data()), "ncclCommInitAll");
-    VGTX_NCCL(ncclGroupStart(), "ncclGroupStart");
+    VGTX_NCCL(rccl.CommInitAll(st.comms.data(), world, devs.data()), "ncclCommInitAll");
+    VGTX_NCCL(rccl.GroupStart(), "ncclGroupStart");
     for (int r = 0; r < world; r++)
     {
       Slab& s = st.slabs[r];
       // 8-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
-      const ncclResult_t res = ncclAllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
-                                             st.comms[r], s.stream);
+      const ncclResult_t res = rccl.AllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
+                                              st.comms[r], s.stream);
       if (res != ncclSuccess)
       {
-        (void)ncclGroupEnd();
-        return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[ncclAllGather] RCCL error [") + ncclGetErrorString(res) + "]");
+        (void)rccl.GroupEnd();
+        return FailMulti(VGT_HIP_ERR_RUNTIME,
+                         std::string("[ncclAllGather] RCCL error [") + rccl.GetErrorString(res) + "]");
       }
     }
-    VGTX_NCCL(ncclGroupEnd(), "ncclGroupEnd");
+    VGTX_NCCL(rccl.GroupEnd(), "ncclGroupEnd");
   }
   else
   {
