@@ -14,6 +14,8 @@ EXPECTED = {"ScanZ": "4 GiB read (float occupancy) + 2 GiB write (int16)",
 
 
 def classify(name):
+    if "vgt::" not in name:
+        return None
     if "ScanZ" in name:
         return "ScanZ"
     if "PassKernel" in name or "LinePass" in name or "Pass" in name:
@@ -54,6 +56,47 @@ def main():
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(out, "rocprof_kernel_stats.csv"), "w") as fh:
             csv.writer(fh).writerows(rows[:12])
+    # SQ counters of the three SDF kernels (one pass, 8 SQ slots)
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(out, "pmc_sq", "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            k = classify(row["Kernel_Name"])
+            if k:
+                sq[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if sq:
+        doc = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU "
+                          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python3 bench.py --steps 1 "
+                          "--warmup 1 (1024^3 D1)",
+               "units": "averages per launch, in 1e9; SQ_INSTS_* = wave-instructions, SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                        "SQ_ACTIVE_INST_* = quad-cycles (MI355X_MICROARCH.md)",
+               "kernels": {k: {c: round(sum(v) / len(v) / 1e9, 4) for c, v in d.items()} for k, d in sq.items()}}
+        for k, d in doc["kernels"].items():
+            if "SQ_INSTS_VALU" in d:
+                d["valu_lane_instructions_per_voxel"] = round(d["SQ_INSTS_VALU"] * 1e9 * 64 / 2 ** 30, 1)
+        json.dump(doc, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
+    # raycaster
+    rstats = glob.glob(os.path.join(out, "raycast_stats", "*", "*kernel_stats.csv"))
+    if rstats:
+        rows = list(csv.reader(open(rstats[0])))
+        with open(os.path.join(out, "rocprof_kernel_stats_raycast.csv"), "w") as fh:
+            csv.writer(fh).writerows(rows[:12])
+    atomic = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(out, "raycast_pmc_atomic", "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"]
+            if "vgt::" in name:
+                short = next((k for k in ("RaycastKernel", "DirectionBinKernel", "BinOffsetsKernel", "ScatterOrderKernel",
+                                          "FilterKernel") if k in name), "other")
+                atomic[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if atomic:
+        json.dump({"command": "rocprofv3 --pmc <TCC atomic request counters> --kernel-trace -- python3 bench_raycast.py "
+                              "--no-check (config 3, clouds A then B)",
+                   "note": "TCC_ATOMIC = atomic requests that reach the L2 (summed over its channels), per launch; the "
+                           "launches alternate cloud A (sensor inside the grid, 155.2 M seen-free visits + 1 M end voxels) "
+                           "and cloud B (sensor outside, 14.6 M visits).  One request per visit would be 156 M / 15.6 M.",
+                   "kernels": {k: {c: {"per_launch": [round(x) for x in v]} for c, v in d.items()}
+                               for k, d in atomic.items()}},
+                  open(os.path.join(out, "raycast_atomic_counters.json"), "w"), indent=1)
     print(json.dumps(summary["kernels"], indent=1))
 
 
