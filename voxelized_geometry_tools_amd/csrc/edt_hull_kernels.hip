@@ -959,60 +959,76 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         owner_rest = t.A2[lo * W + t.w] & ~LowMask(pos + 1);
       }
     }
-    bool neg = false;
-    int prev_opp = -1, next_opp = n, run_a = 0;
-    OutT* dst = out + (base + static_cast<int64_t>(r0) * g.row_stride + t.w);
-    for (int r = r0; r < r1; r++, dst += g.row_stride)
+    // Sentinels instead of validity selects: a missing owner has the value kNoValue, a missing bounding row lies
+    // kFarRows rows away, so every candidate is a plain square-plus-value and anything at or above kRealLimit means
+    // "no site at all".  An owner that belongs to an earlier run needs no check either: it lies at or beyond the
+    // bounding row of the other class, whose candidate is never larger.
+    constexpr int32_t kNoValue = 0x60000000;    // above every real squared distance, + 2047^2 stays below 2^31
+    constexpr int32_t kFarRows = 36000;         // 36000^2 > 3 * 16384^2, (36000 + 2048)^2 < 2^31
+    constexpr int32_t kRealLimit = 0x40000000;
+    if (cur < 0)
     {
-      if (r > r0 && ((tw >> (r - r0)) & 1u))
+      cur = r0;
+      fcur = kNoValue;
+    }
+    bool neg = false;
+    int prev_opp = -kFarRows, next_opp = n + kFarRows;
+    const uint32_t row_mask = LowMask(r1 - r0);
+    // bit k set: row k starts a run (row 0 always does)
+    const uint32_t run_starts = ((sbits ^ (sbits << 1)) | 1u) & row_mask;
+    const int wi = band * W + t.w;
+    OutT* dst = out + (base + static_cast<int64_t>(r0) * g.row_stride + t.w);
+#pragma unroll
+    for (int k = 0; k < kBandRows; k++)
+    {
+      if (k < r1 - r0)
       {
-        // every start bit has its owner: the next bit of A2 (sumA2 lists the non-empty words exactly)
-        if (owner_rest == 0u)
+        const int r = r0 + k;
+        if (k > 0 && ((tw >> k) & 1u))
         {
-          uint64_t above = t.sumA2[t.w];
-          if (owner_word >= 0) above &= ~((2ull << owner_word) - 1ull);
-          owner_word = __ffsll(static_cast<long long>(above)) - 1;
-          owner_rest = t.A2[owner_word * W + t.w];
+          // every start bit has its owner: the next bit of A2 (sumA2 lists the non-empty words exactly)
+          if (owner_rest == 0u)
+          {
+            uint64_t above = t.sumA2[t.w];
+            if (owner_word >= 0) above &= ~((2ull << owner_word) - 1ull);
+            owner_word = __ffsll(static_cast<long long>(above)) - 1;
+            owner_rest = t.A2[owner_word * W + t.w];
+          }
+          cur = (owner_word << 5) + __ffs(static_cast<int>(owner_rest)) - 1;
+          owner_rest &= owner_rest - 1u;
+          fcur = t.Mag(cur);
         }
-        cur = (owner_word << 5) + __ffs(static_cast<int>(owner_rest)) - 1;
-        owner_rest &= owner_rest - 1u;
-        fcur = t.Mag(cur);
-      }
-      const bool sneg = (sbits >> (r - r0)) & 1u;
-      if (r == r0 || sneg != neg)
-      {
-        // bounding rows of the other class: inside the band from the sign word in registers,
-        // outside it from the per-word carries of phase 1b
-        neg = sneg;
-        const int wi = band * W + t.w;
-        prev_opp = (r == r0) ? static_cast<int>(neg ? t.last_pos[wi] : t.last_neg[wi]) : r - 1;
-        const uint32_t other_above = (neg ? ~sbits : sbits) & LowMask(r1 - r0) & ~LowMask(r - r0 + 1);
-        next_opp = other_above ? r0 + __ffs(static_cast<int>(other_above)) - 1
-                               : static_cast<int>(neg ? t.next_pos[wi] : t.next_neg[wi]);
-        run_a = prev_opp + 1;
-      }
-      // three candidates, all computed and then selected (no branches): the owner's parabola and
-      // the two rows of the other class that bound the run
-      const int32_t via_owner = SqPlusAsm(r - cur, fcur);
-      const int32_t via_prev = SqAsm(r - prev_opp);
-      const int32_t via_next = SqAsm(next_opp - r);
-      int32_t best = (cur >= run_a) ? via_owner : kInf32;
-      best = (prev_opp >= 0) ? min(best, via_prev) : best;
-      best = (next_opp < n) ? min(best, via_next) : best;
-      if constexpr (kFinal)
-      {
-        const int x = (g.pass_axis == 0) ? r : outer;
-        const int y = (g.pass_axis == 0) ? outer : r;
-        if (g.add_virtual_border) best = ClampToVirtualBorder(best, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
-        if (!VGT_SKIP(1024) || best == 123456789) *dst = DistanceToSdf(best, neg, g.resolution);
-        // the SDF value is monotone in the signed squared distance: track that, convert once
-        const int32_t key = neg ? -best : best;
-        lo_key = min(lo_key, key);
-        hi_key = max(hi_key, key);
-      }
-      else
-      {
-        *dst = neg ? -best : best;
+        if ((run_starts >> k) & 1u)
+        {
+          // bounding rows of the other class: inside the band from the sign word in registers,
+          // outside it from the per-word carries of phase 1b
+          neg = (sbits >> k) & 1u;
+          int below = r - 1;
+          if (k == 0) below = neg ? t.last_pos[wi] : t.last_neg[wi];
+          const uint32_t other_above = (neg ? ~sbits : sbits) & row_mask & ~LowMask(k + 1);
+          const int above = other_above ? r0 + __ffs(static_cast<int>(other_above)) - 1
+                                        : static_cast<int>(neg ? t.next_pos[wi] : t.next_neg[wi]);
+          prev_opp = (below >= 0) ? below : -kFarRows;
+          next_opp = (above < n) ? above : n + kFarRows;
+        }
+        int32_t best = min(SqPlusAsm(r - cur, fcur), min(SqAsm(r - prev_opp), SqAsm(next_opp - r)));
+        best = (best >= kRealLimit) ? kInf32 : best;
+        if constexpr (kFinal)
+        {
+          const int x = (g.pass_axis == 0) ? r : outer;
+          const int y = (g.pass_axis == 0) ? outer : r;
+          if (g.add_virtual_border) best = ClampToVirtualBorder(best, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
+          if (!VGT_SKIP(1024) || best == 123456789) *dst = DistanceToSdf(best, neg, g.resolution);
+          // the SDF value is monotone in the signed squared distance: track that, convert once
+          const int32_t key = neg ? -best : best;
+          lo_key = min(lo_key, key);
+          hi_key = max(hi_key, key);
+        }
+        else
+        {
+          *dst = neg ? -best : best;
+        }
+        dst += g.row_stride;
       }
     }
   }
