@@ -105,3 +105,26 @@ def test_argument_errors(ctx):
     with pytest.raises(ValueError):
         cells.sdf(0.0)                                            # resolution must be positive
     cells.close()
+
+
+def test_object_ids_one_pass_many_ids(ctx):
+    """vgt_hip_cells_object_ids collects the distinct ids in one pass (a device hash set): many ids, every cell its
+    own id, the extreme id values, and a grid without any."""
+    rng = np.random.default_rng(12)
+    shape = (24, 20, 30)
+    for kind in ("many", "all_distinct", "extremes", "none"):
+        rec = np.zeros(shape, dtype=np.dtype([("occupancy", np.float32), ("object_id", np.uint32)]))
+        rec["occupancy"] = (rng.random(shape) < 0.3).astype(np.float32)
+        if kind == "many":
+            rec["object_id"] = rng.integers(0, 5000, size=shape, dtype=np.uint32)
+        elif kind == "all_distinct":
+            rec["object_id"] = (np.arange(rec.size, dtype=np.uint32) * np.uint32(2654435761) | np.uint32(1)).reshape(shape)
+        elif kind == "extremes":
+            rec["object_id"] = rng.choice(np.array([0, 1, 2, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], dtype=np.uint32),
+                                          size=shape)
+        cells = capi.Cells(ctx, rec, shape)
+        want = np.unique(rec["object_id"])
+        want = want[want > 0]
+        got = cells.object_ids()
+        assert got.dtype == np.uint32 and np.array_equal(got, want), kind
+        cells.close()

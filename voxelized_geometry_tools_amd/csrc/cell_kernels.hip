@@ -69,6 +69,52 @@ __global__ __launch_bounds__(kCellBlock) void CellMaskKernel(const uint8_t* __re
   }
 }
 
+// The distinct object ids > 0 of a grid in ONE pass (MakeAllObjectSDFs' std::set, tagged_object_occupancy_map.hpp:
+// 268-289): a hash set in device memory (0 = empty slot: valid ids are > 0).  Objects are contiguous in space, so a
+// lane whose id equals its left neighbour's leaves the insert to it.  count_overflow[1] is set when a key finds no
+// slot within the probe limit (more distinct ids than the table can hold): the caller then falls back to the
+// one-id-per-launch scan below.
+constexpr int kIdProbes = 128;
+__global__ __launch_bounds__(kCellBlock) void DistinctIdsKernel(const uint8_t* __restrict__ cells, int64_t num_cells,
+                                                               int cell_bytes, int object_id_offset,
+                                                               uint32_t* __restrict__ table, int table_log2,
+                                                               uint32_t* __restrict__ count_overflow)
+{
+  const uint32_t mask = (1u << table_log2) - 1u;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t rounds = (num_cells + stride - 1) / stride;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (int64_t round = 0; round < rounds; round++, i += stride)
+  {
+    const uint32_t id =
+        (i < num_cells) ? *reinterpret_cast<const uint32_t*>(cells + i * cell_bytes + object_id_offset) : 0u;
+    const uint32_t left = static_cast<uint32_t>(__shfl_up(static_cast<int>(id), 1));
+    if (id == 0u || ((threadIdx.x & (kWaveSize - 1)) != 0 && left == id)) continue;
+    uint32_t slot = (id * 2654435761u) >> (32 - table_log2);
+    bool placed = false;
+    for (int probe = 0; probe < kIdProbes && !placed; probe++)
+    {
+      uint32_t key = table[slot];
+      if (key == 0u) key = atomicCAS(&table[slot], 0u, id);
+      placed = (key == id) || (key == 0u);
+      slot = (slot + 1u) & mask;
+    }
+    if (!placed) atomicOr(&count_overflow[1], 1u);
+  }
+}
+
+__global__ __launch_bounds__(kCellBlock) void CompactIdsKernel(const uint32_t* __restrict__ table, int64_t slots,
+                                                              uint32_t* __restrict__ ids,
+                                                              uint32_t* __restrict__ count_overflow)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < slots;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const uint32_t key = table[i];
+    if (key != 0u) ids[atomicAdd(&count_overflow[0], 1u)] = key;
+  }
+}
+
 // Smallest object id strictly greater than `after`: MakeAllObjectSDFs' scan for the distinct
 // ids (tagged_object_occupancy_map.hpp:268-289), one id per launch.  result[0] = the id,
 // result[1] = 1 if one was found (so that id 0xffffffff is not mistaken for "none").
@@ -143,6 +189,18 @@ hipError_t LaunchCellMask(const void* cells_dev, int64_t num_cells, int cell_byt
   hipLaunchKernelGGL(CellMaskKernel, dim3(CellGrid(num_cells)), dim3(kCellBlock), 0, stream,
                      static_cast<const uint8_t*>(cells_dev), num_cells, cell_bytes, object_id_offset, mode,
                      objects_dev, num_objects, unknown_is_filled, mask_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchDistinctObjectIds(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                                   uint32_t* table_dev, int table_log2, uint32_t* ids_dev, uint32_t* count_overflow_dev,
+                                   hipStream_t stream)
+{
+  hipLaunchKernelGGL(DistinctIdsKernel, dim3(CellGrid(num_cells)), dim3(kCellBlock), 0, stream,
+                     static_cast<const uint8_t*>(cells_dev), num_cells, cell_bytes, object_id_offset, table_dev,
+                     table_log2, count_overflow_dev);
+  hipLaunchKernelGGL(CompactIdsKernel, dim3(CellGrid(int64_t{1} << table_log2)), dim3(kCellBlock), 0, stream, table_dev,
+                     int64_t{1} << table_log2, ids_dev, count_overflow_dev);
   return hipGetLastError();
 }
 

@@ -1165,6 +1165,48 @@ int vgt_hip_cells_object_ids(vgt_hip_ctx* ctx, vgt_hip_cells* cells, uint32_t* i
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   std::lock_guard<std::mutex> lock(ctx->mutex);
   const int64_t n = cells->nx * cells->ny * cells->nz;
+  // One pass: every id goes into a device hash set, the set is compacted and sorted on the host (the reference
+  // collects a std::set, tagged_object_occupancy_map.hpp:268-289).  Only a grid with more distinct ids than the
+  // table can hold falls back to the one-id-per-launch scan.
+  {
+    // at least two slots per cell (every cell could carry its own id), 2^10 .. 2^27 slots
+    int table_log2 = 10;
+    while (table_log2 < 27 && (int64_t{1} << table_log2) < 2 * n) table_log2++;
+    const int kTableLog2 = table_log2;
+    const size_t slots = size_t{1} << kTableLog2;
+    uint32_t* table = nullptr;
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&table), (2 * slots + 64) * sizeof(uint32_t));
+    if (err == hipSuccess)
+    {
+      uint32_t* ids_dev = table + slots;
+      uint32_t* count_overflow = ids_dev + slots;
+      uint32_t header[2] = {0u, 1u};
+      std::vector<uint32_t> ids;
+      err = hipMemsetAsync(table, 0, (2 * slots + 64) * sizeof(uint32_t), ctx->stream);
+      if (err == hipSuccess)
+        err = vgt::LaunchDistinctObjectIds(cells->records, n, cells->cell_bytes, cells->object_id_offset, table, kTableLog2,
+                                           ids_dev, count_overflow, ctx->stream);
+      if (err == hipSuccess)
+        err = hipMemcpyAsync(header, count_overflow, sizeof(header), hipMemcpyDeviceToHost, ctx->stream);
+      if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+      if (err == hipSuccess && header[1] == 0u && header[0] > 0u)
+      {
+        ids.resize(header[0]);
+        err = hipMemcpy(ids.data(), ids_dev, ids.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      }
+      (void)hipFree(table);
+      VGT_TRY_HIP(err, "object id scan");
+      if (header[1] == 0u)
+      {
+        std::sort(ids.begin(), ids.end());
+        *count = static_cast<int64_t>(ids.size());
+        for (int64_t k = 0; k < *count && k < capacity; k++) ids_out[k] = ids[static_cast<size_t>(k)];
+        return VGT_HIP_OK;
+      }
+    }
+    else
+      (void)hipGetLastError();
+  }
   uint32_t after = 0;  // ids > 0 only (tagged_object_occupancy_map.hpp:279-283)
   for (;;)
   {

@@ -88,6 +88,11 @@ hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hip
 hipError_t LaunchCellMask(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
                           int mode, const uint32_t* objects_dev, int num_objects, int unknown_is_filled,
                           uint8_t* mask_dev, hipStream_t stream);
+// Distinct object ids > 0 in one pass: table_dev = 2^table_log2 zeroed uint32 slots, ids_dev = room for as many ids,
+// count_overflow_dev = {number of ids, 1 if the table overflowed} (zeroed by the caller).
+hipError_t LaunchDistinctObjectIds(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                                   uint32_t* table_dev, int table_log2, uint32_t* ids_dev, uint32_t* count_overflow_dev,
+                                   hipStream_t stream);
 hipError_t LaunchNextObjectId(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
                               uint32_t after, uint32_t* result_dev, hipStream_t stream);
 hipError_t LaunchCombineFreeAndNamed(const float* free_sdf_dev, const float* named_sdf_dev, int64_t num_cells,
