@@ -1018,6 +1018,11 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
           const int x = (g.pass_axis == 0) ? r : outer;
           const int y = (g.pass_axis == 0) ? outer : r;
           if (g.add_virtual_border) best = ClampToVirtualBorder(best, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
+#ifdef VGT_HULL_DEBUG
+          if (VGT_SKIP(2048))  // timing experiment: what a plain float conversion would cost (results are NOT exact)
+            *dst = (neg ? -1.0f : 1.0f) * __fsqrt_rn(static_cast<float>(best)) * static_cast<float>(g.resolution);
+          else
+#endif
           if (!VGT_SKIP(1024) || best == 123456789) *dst = DistanceToSdf(best, neg, g.resolution);
           // the SDF value is monotone in the signed squared distance: track that, convert once
           const int32_t key = neg ? -best : best;

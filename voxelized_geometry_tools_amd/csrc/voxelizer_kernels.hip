@@ -146,8 +146,14 @@ struct VisitTable
 };
 
 // ---- ordering of a cloud by ray direction (counting sort, see the header) ----
-constexpr int kFaceBits = 7;                                  // 128 x 128 cells per cube-map face
-constexpr int kSortBins = 6 << (2 * kFaceBits);               // 98304
+// Bins: 6 cube-map faces x 64 x 64 cells, Morton order inside a face (a workgroup's 256 consecutive rays then
+// span a compact patch of neighbouring cells).  The sort keeps every atomic in LDS: each workgroup counts a chunk of
+// kSortChunk rays per bin in an LDS histogram and publishes it as column `workgroup` of a [bin][workgroup]
+// table; a prefix over each bin's row gives the workgroup's offset inside the bin and the bin's total; the
+// workgroups then scan the 24576 bin totals in LDS and place their rays with LDS atomics on those bases.
+constexpr int kFaceBits = 6;
+constexpr int kSortBins = 6 << (2 * kFaceBits);               // 24576
+constexpr int kSortChunk = 16384;                             // rays per workgroup of the counting / placing kernels
 constexpr int64_t kSortMinPoints = 32768;                     // smaller clouds: three extra launches cost more than they save
 __device__ __forceinline__ uint32_t SpreadBits(uint32_t x)    // 0b..cba -> 0b..0c0b0a
 {
@@ -160,62 +166,96 @@ __device__ __forceinline__ uint32_t SpreadBits(uint32_t x)    // 0b..cba -> 0b..
 }
 
 template <typename Real>
-__global__ void DirectionBinKernel(const Real* __restrict__ points, int64_t num_points, int64_t point_stride,
-                                   const typename RaycastTraits<Real>::Grid g, uint32_t* __restrict__ bins,
-                                   uint32_t* __restrict__ histogram)
+__device__ __forceinline__ uint32_t DirectionBin(const Real* __restrict__ points, int64_t point_stride, int64_t i,
+                                                 const Real* __restrict__ T)
 {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= num_points) return;
   const float px = static_cast<float>(points[point_stride * i + 0]);
   const float py = static_cast<float>(points[point_stride * i + 1]);
   const float pz = static_cast<float>(points[point_stride * i + 2]);
-  uint32_t bin = kSortBins - 1;
-  if (isfinite(px) && isfinite(py) && isfinite(pz))
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return kSortBins - 1;
+  const float d[3] = {static_cast<float>(T[0]) * px + static_cast<float>(T[4]) * py + static_cast<float>(T[8]) * pz,
+                      static_cast<float>(T[1]) * px + static_cast<float>(T[5]) * py + static_cast<float>(T[9]) * pz,
+                      static_cast<float>(T[2]) * px + static_cast<float>(T[6]) * py + static_cast<float>(T[10]) * pz};
+  const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
+  int axis = 0;
+  float major = ax;
+  if (ay > major)
   {
-    const Real* T = g.xform;
-    const float d[3] = {static_cast<float>(T[0]) * px + static_cast<float>(T[4]) * py + static_cast<float>(T[8]) * pz,
-                        static_cast<float>(T[1]) * px + static_cast<float>(T[5]) * py + static_cast<float>(T[9]) * pz,
-                        static_cast<float>(T[2]) * px + static_cast<float>(T[6]) * py + static_cast<float>(T[10]) * pz};
-    const float ax = fabsf(d[0]), ay = fabsf(d[1]), az = fabsf(d[2]);
-    int axis = 0;
-    float major = ax;
-    if (ay > major)
-    {
-      axis = 1;
-      major = ay;
-    }
-    if (az > major)
-    {
-      axis = 2;
-      major = az;
-    }
-    bin = 0;
-    if (major > 0.0f && isfinite(major))
-    {
-      const float u = d[(axis + 1) % 3] / major, v = d[(axis + 2) % 3] / major;  // in [-1, 1]
-      const int cells = 1 << kFaceBits;
-      const int iu = min(cells - 1, max(0, static_cast<int>((u + 1.0f) * (0.5f * cells))));
-      const int iv = min(cells - 1, max(0, static_cast<int>((v + 1.0f) * (0.5f * cells))));
-      const uint32_t face = static_cast<uint32_t>(axis * 2 + (d[axis] < 0.0f ? 1 : 0));
-      bin = (face << (2 * kFaceBits)) | SpreadBits(static_cast<uint32_t>(iu)) | (SpreadBits(static_cast<uint32_t>(iv)) << 1);
-    }
+    axis = 1;
+    major = ay;
   }
-  bins[i] = bin;
-  atomicAdd(&histogram[bin], 1u);
+  if (az > major)
+  {
+    axis = 2;
+    major = az;
+  }
+  if (!(major > 0.0f && isfinite(major))) return 0;
+  const float u = d[(axis + 1) % 3] / major, v = d[(axis + 2) % 3] / major;  // in [-1, 1]
+  const int cells = 1 << kFaceBits;
+  const int iu = min(cells - 1, max(0, static_cast<int>((u + 1.0f) * (0.5f * cells))));
+  const int iv = min(cells - 1, max(0, static_cast<int>((v + 1.0f) * (0.5f * cells))));
+  const uint32_t face = static_cast<uint32_t>(axis * 2 + (d[axis] < 0.0f ? 1 : 0));
+  return (face << (2 * kFaceBits)) | SpreadBits(static_cast<uint32_t>(iu)) | (SpreadBits(static_cast<uint32_t>(iv)) << 1);
 }
 
-// histogram -> exclusive prefix sums, in place (one workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void BinOffsetsKernel(uint32_t* __restrict__ histogram)
+template <typename Real>
+__global__ __launch_bounds__(256) void DirectionBinKernel(const Real* __restrict__ points, int64_t num_points,
+                                                         int64_t point_stride,
+                                                         const typename RaycastTraits<Real>::Grid g,
+                                                         uint16_t* __restrict__ bins, uint32_t* __restrict__ table,
+                                                         int num_chunks)
 {
-  __shared__ uint32_t partial[1024];
-  constexpr int kPerThread = kSortBins / 1024;  // 96
-  static_assert(kSortBins % 1024 == 0, "bins per thread");
-  const int first = threadIdx.x * kPerThread;
+  // two 16-bit counters per word (a chunk holds kSortChunk = 16384 rays, so a counter cannot overflow)
+  __shared__ uint32_t histogram[kSortBins / 2];
+  for (int b = threadIdx.x; b < kSortBins / 2; b += blockDim.x) histogram[b] = 0u;
+  __syncthreads();
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kSortChunk;
+  const int64_t last = min(first + kSortChunk, num_points);
+  for (int64_t i = first + threadIdx.x; i < last; i += blockDim.x)
+  {
+    const uint32_t bin = DirectionBin<Real>(points, point_stride, i, g.xform);
+    bins[i] = static_cast<uint16_t>(bin);
+    atomicAdd(&histogram[bin >> 1], 1u << ((bin & 1u) * 16u));
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kSortBins; b += blockDim.x)
+    table[static_cast<int64_t>(b) * num_chunks + blockIdx.x] = (histogram[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
+}
+
+// table[bin][chunk] counts -> exclusive prefix over the chunks of each bin, in place, and the bin's total.
+__global__ __launch_bounds__(256) void BinOffsetsKernel(uint32_t* __restrict__ table, int num_chunks,
+                                                       uint32_t* __restrict__ bin_total)
+{
+  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= kSortBins) return;
+  uint32_t* row = table + static_cast<int64_t>(bin) * num_chunks;
+  uint32_t running = 0;
+  for (int c = 0; c < num_chunks; c++)
+  {
+    const uint32_t count = row[c];
+    row[c] = running;
+    running += count;
+  }
+  bin_total[bin] = running;
+}
+
+__global__ __launch_bounds__(256) void ScatterOrderKernel(const uint16_t* __restrict__ bins, int64_t num_points,
+                                                         const uint32_t* __restrict__ table, int num_chunks,
+                                                         const uint32_t* __restrict__ bin_total,
+                                                         uint32_t* __restrict__ order)
+{
+  extern __shared__ uint32_t next[];  // kSortBins words (dynamic: 96 KiB)
+  __shared__ uint32_t partial[256];
+  // first output position of every bin: exclusive scan of the bin totals (every workgroup recomputes it),
+  // plus this chunk's offset inside the bin
+  constexpr int kPerThread = kSortBins / 256;  // 96
+  static_assert(kSortBins % 256 == 0, "bins per thread");
+  const int first_bin = threadIdx.x * kPerThread;
   uint32_t sum = 0;
-  for (int k = 0; k < kPerThread; k++) sum += histogram[first + k];
+  for (int k = 0; k < kPerThread; k++) sum += bin_total[first_bin + k];
   partial[threadIdx.x] = sum;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1)
+  for (int d = 1; d < 256; d <<= 1)
   {
     const uint32_t add = (threadIdx.x >= static_cast<unsigned>(d)) ? partial[threadIdx.x - d] : 0u;
     __syncthreads();
@@ -225,22 +265,17 @@ __global__ __launch_bounds__(1024) void BinOffsetsKernel(uint32_t* __restrict__ 
   uint32_t running = partial[threadIdx.x] - sum;
   for (int k = 0; k < kPerThread; k++)
   {
-    const uint32_t count = histogram[first + k];
-    histogram[first + k] = running;
-    running += count;
+    const int b = first_bin + k;
+    next[b] = running + table[static_cast<int64_t>(b) * num_chunks + blockIdx.x];
+    running += bin_total[b];
   }
+  __syncthreads();
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kSortChunk;
+  const int64_t last = min(first + kSortChunk, num_points);
+  for (int64_t i = first + threadIdx.x; i < last; i += blockDim.x)
+    order[atomicAdd(&next[bins[i]], 1u)] = static_cast<uint32_t>(i);
 }
 
-__global__ void ScatterOrderKernel(const uint32_t* __restrict__ bins, int64_t num_points,
-                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ order)
-{
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= num_points) return;
-  order[atomicAdd(&offsets[bins[i]], 1u)] = static_cast<uint32_t>(i);
-}
-
-// One thread per point.  Real = float reproduces the reference device kernels, Real = double
-// the reference CPU voxelizer (cpu_pointcloud_voxelization.cpp:208-436, "HIP_EXACT_FP64").
 // kTable: seen-free visits go through the workgroup's LDS table (needs num_cells < 2^32 - 1); `order`
 // (optional) = the direction-sorted permutation of the points.
 template <typename Real, bool kTable>
@@ -455,7 +490,10 @@ __global__ void FilterKernel(const int32_t* __restrict__ tracking, int64_t num_c
 size_t RaycastScratchBytes(int64_t num_points)
 {
   if (num_points < kSortMinPoints) return 0;
-  return (static_cast<size_t>(kSortBins) + 2 * static_cast<size_t>(num_points)) * sizeof(uint32_t);
+  const size_t chunks = static_cast<size_t>((num_points + kSortChunk - 1) / kSortChunk);
+  // [bin][chunk] table + permutation (uint32 each) + per-point bins (uint16), 256-byte aligned pieces
+  return (static_cast<size_t>(kSortBins) * (chunks + 1) + static_cast<size_t>(num_points)) * sizeof(uint32_t) +
+         static_cast<size_t>(num_points) * sizeof(uint16_t) + 1024;
 }
 
 namespace
@@ -473,16 +511,22 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   // point and cell indices.
   if (need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL && num_cells < 0xffffffffLL)
   {
-    uint32_t* histogram = static_cast<uint32_t*>(scratch_dev);
-    uint32_t* bins = histogram + kSortBins;
-    uint32_t* order = bins + num_points;
-    hipError_t err = hipMemsetAsync(histogram, 0, static_cast<size_t>(kSortBins) * sizeof(uint32_t), stream);
-    if (err != hipSuccess) return err;
-    const unsigned sort_blocks = static_cast<unsigned>((num_points + 255) / 256);
-    hipLaunchKernelGGL(DirectionBinKernel<Real>, dim3(sort_blocks), dim3(256), 0, stream, points_dev, num_points,
-                       point_stride, g, bins, histogram);
-    hipLaunchKernelGGL(BinOffsetsKernel, dim3(1), dim3(1024), 0, stream, histogram);
-    hipLaunchKernelGGL(ScatterOrderKernel, dim3(sort_blocks), dim3(256), 0, stream, bins, num_points, histogram, order);
+    const int num_chunks = static_cast<int>((num_points + kSortChunk - 1) / kSortChunk);
+    const int64_t entries = static_cast<int64_t>(kSortBins) * num_chunks;
+    uint32_t* table = static_cast<uint32_t*>(scratch_dev);
+    uint32_t* bin_total = table + ((entries + 63) / 64 * 64);
+    uint32_t* order = bin_total + kSortBins;
+    uint16_t* bins = reinterpret_cast<uint16_t*>(order + ((num_points + 63) / 64 * 64));
+    hipLaunchKernelGGL(DirectionBinKernel<Real>, dim3(num_chunks), dim3(256), 0, stream, points_dev, num_points,
+                       point_stride, g, bins, table, num_chunks);
+    hipLaunchKernelGGL(BinOffsetsKernel, dim3((kSortBins + 255) / 256), dim3(256), 0, stream, table, num_chunks,
+                       bin_total);
+    constexpr size_t kScatterLds = static_cast<size_t>(kSortBins) * sizeof(uint32_t);
+    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ScatterOrderKernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kScatterLds));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(256), kScatterLds, stream, bins, num_points, table,
+                       num_chunks, bin_total, order);
     hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
                        stream, points_dev, num_points, point_stride, order, g, tracking_dev);
     return hipGetLastError();
