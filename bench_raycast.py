@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--threads-per-block", type=int, default=-1, help="HIP_THREADS_PER_BLOCK of the helper (-1 = default)")
     args = ap.parse_args()
     import torch
     from voxelized_geometry_tools_amd import capi, synthetic
@@ -41,7 +42,7 @@ def main():
     env[:, :, 0] = 1.0
     dev = torch.device("cuda", 0)
     pts_dev = torch.from_numpy(pts).to(dev)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, args.threads_per_block)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     out = {}
     for name, sensor in (("A_inside", (2.56, 2.56, 2.56)), ("B_outside", (-1.0, 2.56, 2.56))):

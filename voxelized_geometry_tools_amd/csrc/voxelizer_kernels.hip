@@ -95,7 +95,7 @@ __device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracki
 }
 
 // ---- per-workgroup accumulation table (see the header) ----
-constexpr int kTableSlots = 4096;       // 32 KiB of LDS: keys + counts
+constexpr int kTableSlotsPerThread = 16;  // slots = 16 x workgroup size (4096 slots = 32 KiB of LDS at 256 threads)
 constexpr int kTableProbes = 6;
 constexpr int kWalkSegment = 96;        // steps between flushes
 constexpr uint32_t kEmptyKey = 0xffffffffu;
@@ -104,9 +104,11 @@ struct VisitTable
 {
   uint32_t* keys;
   uint32_t* counts;
+  int slots;   // power of two
+  int shift;   // 32 - log2(slots)
   __device__ __forceinline__ void Clear()
   {
-    for (int s = threadIdx.x; s < kTableSlots; s += blockDim.x)
+    for (int s = threadIdx.x; s < slots; s += blockDim.x)
     {
       keys[s] = kEmptyKey;
       counts[s] = 0u;
@@ -115,7 +117,7 @@ struct VisitTable
   // seen-free visit of `cell` (cell < 2^32 - 1)
   __device__ __forceinline__ void Add(uint32_t cell, int32_t* __restrict__ tracking)
   {
-    uint32_t slot = (cell * 2654435761u) >> 20;  // top 12 bits: kTableSlots = 4096
+    uint32_t slot = (cell * 2654435761u) >> shift;
 #pragma unroll 1
     for (int probe = 0; probe < kTableProbes; probe++)
     {
@@ -126,13 +128,13 @@ struct VisitTable
         atomicAdd(&counts[slot], 1u);
         return;
       }
-      slot = (slot + 1u) & (kTableSlots - 1);
+      slot = (slot + 1u) & static_cast<uint32_t>(slots - 1);
     }
     atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
   }
   __device__ __forceinline__ void Flush(int32_t* __restrict__ tracking)
   {
-    for (int s = threadIdx.x; s < kTableSlots; s += blockDim.x)
+    for (int s = threadIdx.x; s < slots; s += blockDim.x)
     {
       const uint32_t key = keys[s];
       if (key != kEmptyKey)
@@ -283,10 +285,10 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
                               int64_t point_stride,  // elements between consecutive points (3 = packed xyz)
                               const uint32_t* __restrict__ order,
                               const typename RaycastTraits<Real>::Grid g,
-                              int32_t* __restrict__ tracking)
+                              int32_t* __restrict__ tracking, int table_slots)
 {
-  __shared__ uint32_t table_words[kTable ? 2 * kTableSlots : 2];
-  VisitTable table{table_words, table_words + (kTable ? kTableSlots : 1)};
+  extern __shared__ uint32_t table_words[];  // kTable: 2 * table_slots words
+  VisitTable table{table_words, table_words + table_slots, table_slots, 32 - (31 - __clz(table_slots))};
   if constexpr (kTable) table.Clear();
 
   const int64_t slot = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -527,13 +529,19 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(256), kScatterLds, stream, bins, num_points, table,
                        num_chunks, bin_total, order);
-    hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
-                       stream, points_dev, num_points, point_stride, order, g, tracking_dev);
+    int table_slots = 1024;
+    while (table_slots < kTableSlotsPerThread * threads_per_block) table_slots <<= 1;
+    const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block),
+                       table_lds, stream, points_dev, num_points, point_stride, order, g, tracking_dev, table_slots);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((RaycastKernel<Real, false>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
                      stream, points_dev, num_points, point_stride, static_cast<const uint32_t*>(nullptr), g,
-                     tracking_dev);
+                     tracking_dev, 0);
   return hipGetLastError();
 }
 }  // namespace
