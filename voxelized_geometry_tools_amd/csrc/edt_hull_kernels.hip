@@ -213,6 +213,13 @@ __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int 
 }
 
 using HullGeom = TileGeom;
+// The envelope ignores classes: for a row q of class c every row r of the other class -- and every row of the
+// own class beyond one -- offers (q - r)^2 + |F[r]| >= (q - b)^2, where b is the nearest row of the other class on
+// that side of q, and (q - b)^2 is a candidate of its own (the evaluation's bounding rows).  So
+//     out(q) = min( lower envelope over ALL rows with cost |F[r]| at q, (q - b_below)^2, (b_above - q)^2 )
+// is exact, and stacks need not restart at class changes, junctions need not know runs, start rows need no run
+// limits.  (Set to false for the per-run formulation of round 1.)
+constexpr bool kClassAgnostic = true;
 constexpr bool kXBeforeY = false;  // see XBeforeY(): measured 15.13 vs 15.21 ms at 1024^3 (neutral), kept off
 constexpr int kChordMaxSpacing = 1;  // 2 (spacings 1 and 2) measured the same
 
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (fr[k] != kInf32) finite |= 1u << k;
     }
     // flips: bit k set when row k starts a new run portion inside the band
-    const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(r1 - r0);
+    const uint32_t flips = kClassAgnostic ? 0u : ((sbits ^ (sbits << 1)) & ~1u & LowMask(r1 - r0));
     const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;  // first portion = [0, first_end)
     const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;     // last portion = [last_begin, ..)
     int32_t min_first = kInf32, min_last = kInf32;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int R = (j + 1) << 5;
         const bool neg_r = s_above & 1u;
-        const int run_a = (neg_r ? hi_pos : hi_neg) + 1;  // inclusive scans: other class at or below band j
+        const int run_a = kClassAgnostic ? 0 : (neg_r ? hi_pos : hi_neg) + 1;  // inclusive scans: other class at or below band j
         const int off = ok ? t.min_last[j * W + line] : 255;
         int row = (off != 255) ? (j << 5) + off : -1;
         int32_t f = 0;
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         const int Q = (j << 5) - 1;
         const bool neg_q = (s_below >> 31) & 1u;
-        const int run_b = (neg_q ? lo_pos : lo_neg) - 1;  // inclusive scans: other class at or above band j
+        const int run_b = kClassAgnostic ? n - 1 : (neg_q ? lo_pos : lo_neg) - 1;  // inclusive scans: other class at or above band j
         const int off = ok ? t.min_first[j * W + line] : 255;
         int row = (off != 255) ? (j << 5) + off : -1;
         int32_t f = 0;
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         // carried sites are real members of the same run portion (or the seeds), so the kills are
         // valid; the choice of carried site is only a heuristic (the stack below is exact).
         constexpr int32_t kNone = 0x40000000;  // > any finite value (< 3 * 16384^2), no overflow when a square is added
-        const uint32_t flips = (sbits ^ (sbits << 1)) & ~1u & LowMask(nrows);
+        const uint32_t flips = kClassAgnostic ? 0u : ((sbits ^ (sbits << 1)) & ~1u & LowMask(nrows));
         int32_t cf = (seed_l >= 0) ? Gseed_l - Sq(seed_l) : kNone;
         int cd = (seed_l >= 0) ? r0 - seed_l : 0;
         uint32_t covered_l = 0, covered_r = 0;
@@ -602,13 +609,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         // a new run portion begins when the class differs from the previous candidate's or a
         // row of the other class lies in between
         const uint32_t flips_between =
-            have_run ? ((sbits ^ (neg ? ~0u : 0u)) & LowMask(k + 1) & ~LowMask(run_bit0)) : 1u;
+            have_run ? (kClassAgnostic ? 0u : ((sbits ^ (neg ? ~0u : 0u)) & LowMask(k + 1) & ~LowMask(run_bit0))) : 1u;
         if (flips_between)
         {
           neg = sneg;
           have_run = true;
           // first row of the portion that holds k
-          const uint32_t other_below = (sneg ? ~sbits : sbits) & LowMask(k);
+          const uint32_t other_below = kClassAgnostic ? 0u : ((sneg ? ~sbits : sbits) & LowMask(k));
           run_bit0 = other_below ? 32 - __clz(static_cast<int>(other_below)) : 0;
           top = sec = -1;
           bottom_seed = -1;
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       // the right seed closes the portion that reaches the end of the band
       if (seed_r >= 0 && have_run)
       {
-        const uint32_t other_after = (neg ? ~sbits : sbits) & LowMask(nrows) & ~LowMask(run_bit0);
+        const uint32_t other_after = kClassAgnostic ? 0u : ((neg ? ~sbits : sbits) & LowMask(nrows) & ~LowMask(run_bit0));
         if (other_after) seed_r = -1;  // the last candidate's portion ends inside the band
       }
       if (seed_r >= 0)
@@ -697,10 +704,10 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     {
       const int R = r0;  // first row above the junction
       const bool neg = (sbits & 1u) != 0u;
-      if (t.Neg(R - 1) == neg)  // the run continues across the junction
+      if (kClassAgnostic || t.Neg(R - 1) == neg)  // the run continues across the junction
       {
-        const int lo = t.PrevOpp(R, neg) + 1;
-        const int hi = t.NextOpp(R - 1, neg);
+        const int lo = kClassAgnostic ? 0 : t.PrevOpp(R, neg) + 1;
+        const int hi = kClassAgnostic ? n : t.NextOpp(R - 1, neg);
         // walkers over the members below / above the junction: the current mask word is held in
         // a register (its bits already passed are cleared), the next non-empty word comes from
         // the per-line summary.  A word copy may miss kills made by other junctions meanwhile;
@@ -818,8 +825,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             // new run: the previous member was the last of its run
             if (prev >= 0) owns(prev, prev_start, run_b + 1);
             const bool neg = (sbits >> (h - r0)) & 1u;
-            run_a = t.PrevOpp(h, neg) + 1;
-            run_b = t.NextOpp(h, neg) - 1;
+            run_a = kClassAgnostic ? 0 : t.PrevOpp(h, neg) + 1;
+            run_b = kClassAgnostic ? n - 1 : t.NextOpp(h, neg) - 1;
             start_h = run_a;
             if (run_a < r0)
             {
