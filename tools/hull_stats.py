@@ -52,7 +52,7 @@ def main():
         print("  %-14s %14d" % (NAMES[12], vals[12]))
         sub = [out[base + i] for i in (11, 13, 14, 15)]
         print("  local split: rows->regs %d, carries %d (thread 0); seeds %d, prefilter %d, prefilter done at %d, "
-              "stack done at %d cycles after load (thread 256)" % tuple(v / wg for v in sub + [out[base + 12], out[base + 9]]))
+              "stack done at %d cycles after load (thread 64)" % tuple(v / wg for v in sub + [out[base + 12], out[base + 9]]))
 
 
 if __name__ == "__main__":

@@ -221,7 +221,7 @@ using HullGeom = TileGeom;
 // limits.  (Set to false for the per-run formulation of round 1.)
 constexpr bool kClassAgnostic = true;
 constexpr bool kXBeforeY = false;  // see XBeforeY(): measured 15.13 vs 15.21 ms at 1024^3 (neutral), kept off
-constexpr int kChordMaxSpacing = 1;  // 2 (spacings 1 and 2) measured the same
+constexpr int kChordMaxSpacing = 4;  // spacings 1, 2, 4 (13.48 -> 13.28 ms at 1024^3 once the envelope ignores classes)
 
 // Bytes of dynamic LDS for a tile of n rows x W lines.
 template <int W>
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #ifdef VGT_HULL_STATS
       const long long clk_pref = clock64();
 #if VGT_HULL_STATS == 1
-      if (threadIdx.x == 256) { VGT_CLK_ADD(14, clk_seeds - clk1b); VGT_CLK_ADD(15, clk_pref - clk_seeds); VGT_CLK_ADD(12, clk_pref - clk1); }
+      if (threadIdx.x == 64) { VGT_CLK_ADD(14, clk_seeds - clk1b); VGT_CLK_ADD(15, clk_pref - clk_seeds); VGT_CLK_ADD(12, clk_pref - clk1); }
 #endif
 #endif
       // stack over the remaining candidates: one predicate test or one push per iteration
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     }
     t.A[band * W + t.w] = abits;
 #if VGT_HULL_STATS == 1
-    if (threadIdx.x == 256) VGT_CLK_ADD(9, clock64() - clk1);
+    if (threadIdx.x == 64) VGT_CLK_ADD(9, clock64() - clk1);
 #endif
   }
 #if VGT_HULL_STATS > 1
