@@ -219,6 +219,11 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%s: refusing to report a run of a different size"
                          % (args.gpus, os.environ.get("WORLD_SIZE")))
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 (librccl prints a
+    # version banner through C stdio, flushed at exit) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -340,7 +345,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
