@@ -9,21 +9,23 @@
 // Per line the pass computes, for every row q, min over sites o of (q-o)^2 + f(o), where the
 // sites seen by a voxel of one class are the voxels of its own class with their value so far
 // ("members", value f) and every voxel of the other class with value 0.  A zero-valued site
-// shields everything behind it, so a line splits into maximal same-class RUNS [a, b] and
-//     out(q) = min( lower envelope of the run's members at q, (q-(a-1))^2, ((b+1)-q)^2 ),
-// i.e. one Felzenszwalb-Huttenlocher envelope per run over members only, plus the distance to
-// the two voxels of the other class that bound the run (when they exist).
+// shields everything behind it: with b_below / b_above the nearest rows of the other class on
+// either side of q, every row r of the other class -- and every row of the own class beyond
+// one -- can only offer (q-r)^2 + |F[r]| >= (q-b)^2.  So the classes can be ignored while the
+// envelope is built:
+//     out(q) = min( lower envelope over ALL rows with cost |F[r]| at q, (q-b_below)^2, (b_above-q)^2 ),
+// i.e. ONE Felzenszwalb-Huttenlocher envelope per line plus the distance to the two bounding
+// rows of the other class (when they exist), which the evaluation adds as candidates.
 //
 // Parallelisation inside a line: the line is cut into bands of 32 rows, one thread per
 // (line, band); lanes of a wave are different lines (neighbouring Z) and different bands.  An
 // envelope is a bit mask (bit = member survives), one 32-bit word per band, so "pop" clears a
 // bit and stack neighbours are clz/ffs; a per-line summary word skips empty mask words.  Phases
 // (workgroup barriers between them):
-//   1a the band's 32 rows -> registers; sign word; the strongest member of the band's first and
-//      last run portion is published
-//   1b per-word carries of the nearest row of either class below / above (wave scans) and, by a
-//      doubling scan over the published members, one SEED per band and direction: a strong
-//      member of the same run in the bands below / above
+//   1a the band's 32 rows -> registers; sign word; the band's strongest member is published
+//   1b per-word carries of the nearest row of either class below / above (wave scans, for the
+//      evaluation's bounding rows) and, by a doubling scan over the published members, one SEED
+//      per band and direction: a strong member of the bands below / above
 //   1c branch-free prefilter over the registers (a member matched at its own row by a site on
 //      each side never owns a row; chord test against the adjacent rows), then the stack
 //      algorithm over the surviving candidates, with the seeds as virtual bottom / closing
@@ -97,8 +99,7 @@ struct Tile
   int16_t* seed_lo;    // [nwords][W] seed row entering the band from below (-1 none); aliases cumA
   int16_t* seed_hi;    //             ... from above; aliases cumT (both dead before 2c writes cumA/cumT)
   int16_t* first_start;  // [nwords][W] start row of the band's first member (-1 none); aliases cumA (2b only)
-  uint8_t* min_first;  // [nwords][W] offset of the smallest member of the band's first run portion
-  uint8_t* min_last;   //             ... of its last run portion (255 = none)
+  uint8_t* min_member;  // [nwords][W] offset of the band's smallest member (255 = none)
   uint64_t* sumA;      // [W] words of A that may be non-empty (superset)
   uint64_t* sumA2;     // [W] words of A2 that are non-empty
   int n;
@@ -110,29 +111,6 @@ struct Tile
   {
     const int32_t v = Raw(row);
     return v < 0 ? -v : v;
-  }
-  __device__ __forceinline__ uint32_t Valid(int j) const { return LowMask(n - (j << 5)); }
-  __device__ __forceinline__ bool Neg(int row) const
-  {
-    return (S[(row >> 5) * W + w] >> (row & 31)) & 1u;
-  }
-  // nearest row of the OTHER class strictly below `row` (-1 if none)
-  __device__ __forceinline__ int PrevOpp(int row, bool neg) const
-  {
-    const int j = row >> 5;
-    const uint32_t s = S[j * W + w];
-    const uint32_t m = (neg ? ~s : s) & LowMask(row & 31);
-    if (m) return (j << 5) + 31 - __clz(static_cast<int>(m));
-    return neg ? last_pos[j * W + w] : last_neg[j * W + w];
-  }
-  // nearest row of the OTHER class strictly above `row` (n if none)
-  __device__ __forceinline__ int NextOpp(int row, bool neg) const
-  {
-    const int j = row >> 5;
-    const uint32_t s = S[j * W + w];
-    const uint32_t m = (neg ? ~s : s) & Valid(j) & ~LowMask((row & 31) + 1);
-    if (m) return (j << 5) + __ffs(static_cast<int>(m)) - 1;
-    return neg ? next_pos[j * W + w] : next_neg[j * W + w];
   }
   // highest set bit of mask M over rows [lo, r), or -1
   __device__ int PrevBit(const uint32_t* M, const uint64_t* sum, int r, int lo) const
@@ -213,13 +191,6 @@ __device__ __forceinline__ int FirstOwnedRow(int32_t Gp, int p, int32_t Gh, int 
 }
 
 using HullGeom = TileGeom;
-// The envelope ignores classes: for a row q of class c every row r of the other class -- and every row of the
-// own class beyond one -- offers (q - r)^2 + |F[r]| >= (q - b)^2, where b is the nearest row of the other class on
-// that side of q, and (q - b)^2 is a candidate of its own (the evaluation's bounding rows).  So
-//     out(q) = min( lower envelope over ALL rows with cost |F[r]| at q, (q - b_below)^2, (b_above - q)^2 )
-// is exact, and stacks need not restart at class changes, junctions need not know runs, start rows need no run
-// limits.  (Set to false for the per-run formulation of round 1.)
-constexpr bool kClassAgnostic = true;
 constexpr bool kXBeforeY = false;  // see XBeforeY(): measured 15.13 vs 15.21 ms at 1024^3 (neutral), kept off
 constexpr int kChordMaxSpacing = 4;  // spacings 1, 2, 4 (13.48 -> 13.28 ms at 1024^3 once the envelope ignores classes)
 
@@ -230,7 +201,7 @@ size_t TileBytes(int n)
   const size_t nwords = static_cast<size_t>((n + kBandRows - 1) / kBandRows);
   return static_cast<size_t>(n) * W * sizeof(int32_t) + 4 * nwords * W * sizeof(uint32_t) +
          4 * nwords * W * sizeof(int16_t) + 2 * nwords * W * sizeof(uint16_t) +
-         2 * nwords * W * sizeof(uint8_t) + 2 * W * sizeof(uint64_t);
+         nwords * W * sizeof(uint8_t) + 2 * W * sizeof(uint64_t);
 }
 
 // SW = lanes used per line in the transposed scans (32 when a line has <= 32 words, else 64).
@@ -261,8 +232,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   t.seed_lo = reinterpret_cast<int16_t*>(t.cumA);
   t.seed_hi = reinterpret_cast<int16_t*>(t.cumT);
   t.first_start = reinterpret_cast<int16_t*>(t.cumA);
-  t.min_first = reinterpret_cast<uint8_t*>(t.cumT + mw);
-  t.min_last = t.min_first + mw;
+  t.min_member = reinterpret_cast<uint8_t*>(t.cumT + mw);
   t.n = n;
   t.nwords = nwords;
   t.w = threadIdx.x % W;
@@ -301,8 +271,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int r1 = min(r0 + kBandRows, n);
   uint32_t sbits = 0;
 
-  // ---- 1a. this band's rows into registers; sign word; strongest member (smallest value) of
-  // the band's first and last run portion, published for the neighbouring bands ----
+  // ---- 1a. this band's rows into registers; sign word; the band's strongest member (smallest
+  // value), published for the neighbouring bands ----
   int32_t fr[kBandRows];  // magnitudes, kInf32 = not a site (also rows past the end)
   uint32_t finite = 0;
   if (band < nwords)
@@ -329,29 +299,20 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       fr[k] = v < 0 ? -v : v;
       if (fr[k] != kInf32) finite |= 1u << k;
     }
-    // flips: bit k set when row k starts a new run portion inside the band
-    const uint32_t flips = kClassAgnostic ? 0u : ((sbits ^ (sbits << 1)) & ~1u & LowMask(r1 - r0));
-    const int first_end = flips ? __ffs(static_cast<int>(flips)) - 1 : kBandRows;  // first portion = [0, first_end)
-    const int last_begin = flips ? 32 - __clz(static_cast<int>(flips)) - 1 : 0;     // last portion = [last_begin, ..)
-    int32_t min_first = kInf32, min_last = kInf32;
-    int best_first = 255, best_last = 255;
+    // strongest member of the band (smallest value), for the seeds
+    int32_t min_value = kInf32;
+    int best = 255;
 #pragma unroll
     for (int k = 0; k < kBandRows; k++)
     {
-      if (k < first_end && fr[k] < min_first)
+      if (fr[k] < min_value)
       {
-        min_first = fr[k];
-        best_first = k;
-      }
-      if (k >= last_begin && fr[k] < min_last)
-      {
-        min_last = fr[k];
-        best_last = k;
+        min_value = fr[k];
+        best = k;
       }
     }
     t.S[band * W + t.w] = sbits;
-    t.min_first[band * W + t.w] = static_cast<uint8_t>(best_first);
-    t.min_last[band * W + t.w] = static_cast<uint8_t>(best_last);
+    t.min_member[band * W + t.w] = static_cast<uint8_t>(best);
     t.T[band * W + t.w] = 0u;
   }
   __syncthreads();
@@ -395,33 +356,29 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       t.next_neg[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_ln);
       t.next_pos[j * W + line] = static_cast<int16_t>(j == SW - 1 ? n : ex_lp);
     }
-    // Seeds.  Band j+1 gets, for the run portion that enters it from below, a strong member of
-    // the lower bands: doubling scan over the bands' published members, each step keeping the
-    // candidate with the smaller value at the first row of band j+1.  Any member of that run is a
-    // legal seed; the scan picks a good one, not necessarily the best.  Same from above.
+    // Seeds.  Band j+1 gets a strong member of the lower bands: doubling scan over the bands' published members,
+    // each step keeping the candidate with the smaller value at the first row of band j+1.  Any row of the line is
+    // a legal seed; the scan picks a good one, not necessarily the best.  Same from above.
     {
-      const uint32_t s_above = __shfl_down(s, 1, SW);  // sign word of band j+1
-      const uint32_t s_below = __shfl_up(s, 1, SW);    // sign word of band j-1
+      const int off = ok ? t.min_member[j * W + line] : 255;
+      const int member = (off != 255) ? (j << 5) + off : -1;
+      int32_t member_f = 0;
+      if (member >= 0)
+      {
+        const int32_t v = t.F[member * W + line];
+        member_f = v < 0 ? -v : v;
+      }
       // upwards: boundary row R = first row of band j+1
       {
         const int R = (j + 1) << 5;
-        const bool neg_r = s_above & 1u;
-        const int run_a = kClassAgnostic ? 0 : (neg_r ? hi_pos : hi_neg) + 1;  // inclusive scans: other class at or below band j
-        const int off = ok ? t.min_last[j * W + line] : 255;
-        int row = (off != 255) ? (j << 5) + off : -1;
-        int32_t f = 0;
-        if (row >= 0)
-        {
-          const int32_t v = t.F[row * W + line];
-          f = v < 0 ? -v : v;
-        }
-        if (row < run_a) row = -1;
+        int row = member;
+        int32_t f = member_f;
         int32_t val = (row >= 0) ? f + Sq(R - row) : kInf32;
         for (int d = 1; d < SW; d <<= 1)
         {
           const int prow = __shfl_up(row, d, SW);
           const int32_t pf = __shfl_up(f, d, SW);
-          if (j >= d && prow >= run_a)
+          if (j >= d && prow >= 0)
           {
             const int32_t pval = pf + Sq(R - prow);
             if (pval < val)
@@ -438,23 +395,14 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       // downwards: boundary row Q = last row of band j-1
       {
         const int Q = (j << 5) - 1;
-        const bool neg_q = (s_below >> 31) & 1u;
-        const int run_b = kClassAgnostic ? n - 1 : (neg_q ? lo_pos : lo_neg) - 1;  // inclusive scans: other class at or above band j
-        const int off = ok ? t.min_first[j * W + line] : 255;
-        int row = (off != 255) ? (j << 5) + off : -1;
-        int32_t f = 0;
-        if (row >= 0)
-        {
-          const int32_t v = t.F[row * W + line];
-          f = v < 0 ? -v : v;
-        }
-        if (row > run_b) row = -1;
+        int row = member;
+        int32_t f = member_f;
         int32_t val = (row >= 0) ? f + Sq(row - Q) : kInf32;
         for (int d = 1; d < SW; d <<= 1)
         {
           const int prow = __shfl_down(row, d, SW);
           const int32_t pf = __shfl_down(f, d, SW);
-          if (j + d < SW && prow >= 0 && prow <= run_b)
+          if (j + d < SW && prow >= 0)
           {
             const int32_t pval = pf + Sq(prow - Q);
             if (pval < val)
@@ -487,7 +435,6 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     uint32_t abits = 0;
     if (z < g.nz && !(VGT_SKIP(8)) && finite)
     {
-      const int nrows = r1 - r0;
       // seeds chosen in 1b
       int seed_l = t.seed_lo[band * W + t.w], seed_r = t.seed_hi[band * W + t.w];
       const int32_t Gseed_l = (seed_l >= 0) ? t.Mag(seed_l) + Sq(seed_l) : 0;
@@ -506,17 +453,15 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         // One carried site per direction: sweeping up, the carried site is the one that was
         // strictly better at its own row than the site carried before it; a member the carried
         // site matches at the member's own row is "covered from the left".  Same downwards.  The
-        // carried sites are real members of the same run portion (or the seeds), so the kills are
-        // valid; the choice of carried site is only a heuristic (the stack below is exact).
+        // carried sites are real rows of the line (or the seeds), so the kills are valid; the
+        // choice of carried site is only a heuristic (the stack below is exact).
         constexpr int32_t kNone = 0x40000000;  // > any finite value (< 3 * 16384^2), no overflow when a square is added
-        const uint32_t flips = kClassAgnostic ? 0u : ((sbits ^ (sbits << 1)) & ~1u & LowMask(nrows));
         int32_t cf = (seed_l >= 0) ? Gseed_l - Sq(seed_l) : kNone;
         int cd = (seed_l >= 0) ? r0 - seed_l : 0;
         uint32_t covered_l = 0, covered_r = 0;
 #pragma unroll
         for (int k = 0; k < kBandRows; k++)
         {
-          if ((flips >> k) & 1u) cf = kNone;
           const int32_t lv = cf + Sq(cd);
           const bool covered = lv <= fr[k];
           covered_l |= (covered ? 1u : 0u) << k;
@@ -528,7 +473,6 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #pragma unroll
         for (int k = kBandRows - 1; k >= 0; k--)
         {
-          if (k + 1 < kBandRows && ((flips >> (k + 1)) & 1u)) cf = kNone;
           const int32_t rv = cf + Sq(cd);
           const bool covered = rv <= fr[k];
           covered_r |= (covered ? 1u : 0u) << k;
@@ -537,7 +481,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         }
         cand &= ~(covered_l & covered_r);
         // Chord tests at fixed spacings: member k lies on or above the chord of the members d rows
-        // below and above it (same run portion) <=> G(k-d) + G(k+d) <= 2 G(k)
+        // below and above it <=> G(k-d) + G(k+d) <= 2 G(k)
         // <=> f(k-d) + f(k+d) + 2 d^2 <= 2 f(k): no multiplications for a constant d.
         if (!(VGT_SKIP(256)))
         {
@@ -552,11 +496,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
               const uint32_t lo = static_cast<uint32_t>(fr[k - d]), hi = static_cast<uint32_t>(fr[k + d]);
               dom |= (lo + hi + 2u * d * d <= 2u * static_cast<uint32_t>(fr[k]) ? 1u : 0u) << k;
             }
-            // both neighbours are members, and no class change in (k-d, k+d]
-            uint32_t change = 0;
-#pragma unroll
-            for (int j = -d + 1; j <= d; j++) change |= (j < 0) ? (flips << -j) : (flips >> j);
-            above |= dom & (finite << d) & (finite >> d) & ~change;
+            // both neighbours are members
+            above |= dom & (finite << d) & (finite >> d);
           }
           cand &= ~above;
         }
@@ -569,10 +510,10 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 #endif
       // stack over the remaining candidates: one predicate test or one push per iteration
-      // (lanes never wait for each other's pops)
-      bool neg = false, have_run = false;
-      int top = -1, sec = -1, run_bit0 = 0, bottom_seed = -1;
-      int32_t Gtop = 0, Gsec = 0;
+      // (lanes never wait for each other's pops); the seed from below is the virtual bottom element
+      int top = seed_l, sec = -1;
+      const int bottom_seed = seed_l;
+      int32_t Gtop = Gseed_l, Gsec = 0;
       auto pop = [&]() {
         VGT_STAT_ADD(8, 1);
         abits &= ~(1u << (top - r0));
@@ -581,7 +522,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         sec = -1;
         if (top != bottom_seed)
         {
-          const uint32_t m = abits & LowMask(top - r0) & ~LowMask(run_bit0);
+          const uint32_t m = abits & LowMask(top - r0);
           if (m)
           {
             sec = r0 + 31 - __clz(static_cast<int>(m));
@@ -605,27 +546,6 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         stat_iters++;
 #endif
         const int r = r0 + k;
-        const bool sneg = (sbits >> k) & 1u;
-        // a new run portion begins when the class differs from the previous candidate's or a
-        // row of the other class lies in between
-        const uint32_t flips_between =
-            have_run ? (kClassAgnostic ? 0u : ((sbits ^ (neg ? ~0u : 0u)) & LowMask(k + 1) & ~LowMask(run_bit0))) : 1u;
-        if (flips_between)
-        {
-          neg = sneg;
-          have_run = true;
-          // first row of the portion that holds k
-          const uint32_t other_below = kClassAgnostic ? 0u : ((sneg ? ~sbits : sbits) & LowMask(k));
-          run_bit0 = other_below ? 32 - __clz(static_cast<int>(other_below)) : 0;
-          top = sec = -1;
-          bottom_seed = -1;
-          if (run_bit0 == 0 && seed_l >= 0)
-          {
-            top = seed_l;
-            Gtop = Gseed_l;
-            bottom_seed = seed_l;
-          }
-        }
         const int32_t Gc = fcur + Sq(r);
         if (sec >= 0 && !(VGT_SKIP(4)) && Dominated(Gsec, sec, Gtop, top, Gc, r))
         {
@@ -641,12 +561,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         k = todo ? __ffs(static_cast<int>(todo)) - 1 : kBandRows;
         if (k < kBandRows) fcur = t.Mag(r0 + k);
       }
-      // the right seed closes the portion that reaches the end of the band
-      if (seed_r >= 0 && have_run)
-      {
-        const uint32_t other_after = kClassAgnostic ? 0u : ((neg ? ~sbits : sbits) & LowMask(nrows) & ~LowMask(run_bit0));
-        if (other_after) seed_r = -1;  // the last candidate's portion ends inside the band
-      }
+      // the seed from above closes the band's hull
       if (seed_r >= 0)
         while (sec >= 0 && Dominated(Gsec, sec, Gtop, top, Gseed_r, seed_r)) pop();
     }
@@ -690,7 +605,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const long long clk2 = clock64();
 #endif
 
-  // ---- 2. join the band hulls.  Every band boundary inside a run is a junction; its thread
+  // ---- 2. join the band hulls.  Every band boundary is a junction; its thread
   // removes, from the two hull ends that meet there, every member that the members across the
   // junction dominate (walking outwards as far as needed, across bands).  All junctions work at
   // once; removals only clear bits (LDS atomics) and a removal justified by ANY real site is
@@ -702,12 +617,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     int changed = 0;
     if (active && band > 0 && !(VGT_SKIP(1)))
     {
-      const int R = r0;  // first row above the junction
-      const bool neg = (sbits & 1u) != 0u;
-      if (kClassAgnostic || t.Neg(R - 1) == neg)  // the run continues across the junction
       {
-        const int lo = kClassAgnostic ? 0 : t.PrevOpp(R, neg) + 1;
-        const int hi = kClassAgnostic ? n : t.NextOpp(R - 1, neg);
         // walkers over the members below / above the junction: the current mask word is held in
         // a register (its bits already passed are cleared), the next non-empty word comes from
         // the per-line summary.  A word copy may miss kills made by other junctions meanwhile;
@@ -721,13 +631,11 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             const uint64_t below = t.sumA[t.w] & ((1ull << down_word) - 1ull);
             if (below == 0ull) return -1;
             down_word = 63 - __clzll(static_cast<long long>(below));
-            if (((down_word << 5) + 31) < lo) return -1;
             down_rest = t.A[down_word * W + t.w];
           }
           const int bit = 31 - __clz(static_cast<int>(down_rest));
           down_rest &= ~(1u << bit);
-          const int row = (down_word << 5) + bit;
-          return row >= lo ? row : -1;
+          return (down_word << 5) + bit;
         };
         auto next_member = [&]() -> int {
           while (up_rest == 0u)
@@ -735,13 +643,11 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             const uint64_t above = (up_word < 63) ? (t.sumA[t.w] & ~((2ull << up_word) - 1ull)) : 0ull;
             if (above == 0ull) return -1;
             up_word = __ffsll(static_cast<long long>(above)) - 1;
-            if ((up_word << 5) >= hi) return -1;
             up_rest = t.A[up_word * W + t.w];
           }
           const int bit = __ffs(static_cast<int>(up_rest)) - 1;
           up_rest &= up_rest - 1u;
-          const int row = (up_word << 5) + bit;
-          return row < hi ? row : -1;
+          return (up_word << 5) + bit;
         };
         int i = prev_member();
         int j = next_member();
@@ -789,13 +695,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #endif
 
   // ---- 2b. first owned row of every hull member; drop members that own no row ----
-  // A member owns [its start, the start of the next member of its run) clipped to the run.  Every
-  // thread computes the start of each of its members once (the predecessor of the band's first
-  // member is found in the bands below), publishes the start of the band's first member, and
-  // after a barrier closes its last member with the published start of the next member above.
+  // A member owns [its start, the start of the next member of the line).  Every thread computes the start of each
+  // of its members once (the predecessor of the band's first member is found in the bands below), publishes the
+  // start of the band's first member, and after a barrier closes its last member with the published start of the
+  // next member above.
   {
     uint32_t a2 = 0;
-    int pend_row = -1, pend_start = 0, pend_run_b = -1;  // last member, if its run continues above
+    int pend_row = -1, pend_start = 0;  // the band's last member: its end is the start of the next member above
     auto owns = [&](int member, int start, int end) {
       if (start < end)
       {
@@ -810,52 +716,33 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (z < g.nz)
       {
         uint32_t bits = t.A[band * W + t.w];
-        int run_a = 0, run_b = -1;  // current run [run_a, run_b]
         int prev = -1, prev_start = 0;
         int32_t Gprev = 0;
-        bool first = true;
         while (bits)
         {
           const int h = r0 + __ffs(static_cast<int>(bits)) - 1;
           bits &= bits - 1u;
           const int32_t Gh = t.Mag(h) + Sq(h);
           int start_h;
-          if (h > run_b)
+          if (prev < 0)
           {
-            // new run: the previous member was the last of its run
-            if (prev >= 0) owns(prev, prev_start, run_b + 1);
-            const bool neg = (sbits >> (h - r0)) & 1u;
-            run_a = kClassAgnostic ? 0 : t.PrevOpp(h, neg) + 1;
-            run_b = kClassAgnostic ? n - 1 : t.NextOpp(h, neg) - 1;
-            start_h = run_a;
-            if (run_a < r0)
-            {
-              const int p = t.PrevBit(t.A, t.sumA, r0, run_a);  // nearest member of the run below the band
-              if (p >= 0) start_h = max(run_a, FirstOwnedRow(t.Mag(p) + Sq(p), p, Gh, h));
-            }
+            // the band's first member: its predecessor is the nearest member below the band, if any
+            start_h = 0;
+            const int p = t.PrevBit(t.A, t.sumA, r0, 0);
+            if (p >= 0) start_h = max(0, FirstOwnedRow(t.Mag(p) + Sq(p), p, Gh, h));
+            first_start = min(start_h, n);
           }
           else
           {
-            start_h = max(run_a, FirstOwnedRow(Gprev, prev, Gh, h));
-            owns(prev, prev_start, min(run_b + 1, start_h));
+            start_h = max(0, FirstOwnedRow(Gprev, prev, Gh, h));
+            owns(prev, prev_start, min(n, start_h));
           }
-          if (first) first_start = min(start_h, n);
-          first = false;
           prev = h;
           prev_start = start_h;
           Gprev = Gh;
         }
-        if (prev >= 0)
-        {
-          if (run_b >= r1)
-          {
-            pend_row = prev;
-            pend_start = prev_start;
-            pend_run_b = run_b;
-          }
-          else
-            owns(prev, prev_start, run_b + 1);
-        }
+        pend_row = prev;
+        pend_start = prev_start;
       }
       t.first_start[band * W + t.w] = static_cast<int16_t>(first_start);
     }
@@ -864,17 +751,15 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     {
       if (pend_row >= 0)
       {
-        int end = pend_run_b + 1;
+        int end = n;
         // first member above this band (sumA may list words that have become empty)
         uint64_t cand = (band < 63) ? (t.sumA[t.w] & ~((2ull << band) - 1ull)) : 0ull;
         while (cand)
         {
           const int jj = __ffsll(static_cast<long long>(cand)) - 1;
-          const uint32_t m = t.A[jj * W + t.w];
-          if (m)
+          if (t.A[jj * W + t.w])
           {
-            const int row = (jj << 5) + __ffs(static_cast<int>(m)) - 1;
-            if (row <= pend_run_b) end = min(end, static_cast<int>(t.first_start[jj * W + t.w]));
+            end = min(end, static_cast<int>(t.first_start[jj * W + t.w]));
             break;
           }
           cand &= cand - 1ull;
