@@ -12,7 +12,8 @@
 // slab) when the devices are distinct; when one device appears more than once in `devices`
 // (several slabs on one GPU: the single-GPU test of this path, or a grid that does not fit one
 // GPU's workspace in one piece) rccl cannot form a communicator and the summaries are copied
-// slab to slab with hipMemcpyPeerAsync instead.  The field's extrema are reduced on the host: this
+// slab to slab with hipMemcpyPeerAsync instead.  Communicators are formed once per device list and kept
+// for the life of the process (CommSet below).  The field's extrema are reduced on the host: this
 // process already holds every device's (min, max) pair.
 #include "../../include/vgt_hip.h"
 
@@ -24,6 +25,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -71,6 +74,36 @@ const Rccl& GetRccl()
   return api;
 }
 
+// Communicators are expensive to form (hundreds of milliseconds for a clique), so one set per ordered
+// device list is kept for the life of the process (never destroyed: rccl may already be unloading when
+// static destructors run).  A communicator serves one collective at a time; `in_use` is held from the
+// group that enqueues the all-gather until the streams have drained.
+struct CommSet
+{
+  std::vector<ncclComm_t> comms;
+  std::mutex in_use;
+};
+
+CommSet* GetCommSet(const Rccl& rccl, const std::vector<int>& devices, std::string* error)
+{
+  static std::mutex registry_lock;
+  static auto* registry = new std::map<std::vector<int>, CommSet*>();
+  std::lock_guard<std::mutex> guard(registry_lock);
+  auto found = registry->find(devices);
+  if (found != registry->end()) return found->second;
+  auto* set = new CommSet();
+  set->comms.assign(devices.size(), nullptr);
+  const ncclResult_t res = rccl.CommInitAll(set->comms.data(), static_cast<int>(devices.size()), devices.data());
+  if (res != ncclSuccess)
+  {
+    *error = std::string("[ncclCommInitAll] RCCL error [") + rccl.GetErrorString(res) + "]";
+    delete set;
+    return nullptr;
+  }
+  (*registry)[devices] = set;
+  return set;
+}
+
 struct Slab
 {
   int device = -1;
@@ -92,7 +125,7 @@ struct Slab
 struct MultiState
 {
   std::vector<Slab> slabs;
-  std::vector<ncclComm_t> comms;
+  std::unique_lock<std::mutex> comm_lock;  // the communicator set, held until the streams have drained
   bool registered_in = false, registered_out = false;
   const void* host_in = nullptr;
   void* host_out = nullptr;
@@ -105,8 +138,7 @@ struct MultiState
       (void)hipSetDevice(s.device);
       if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
-    for (ncclComm_t c : comms)
-      if (c) (void)GetRccl().CommDestroy(c);
+    if (comm_lock.owns_lock()) comm_lock.unlock();
     for (Slab& s : slabs)
     {
       if (s.device < 0) continue;
@@ -231,17 +263,19 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   {
     const Rccl& rccl = GetRccl();
     if (!rccl.error.empty()) return FailMulti(VGT_HIP_ERR_UNAVAILABLE, rccl.error);
-    st.comms.assign(static_cast<size_t>(world), nullptr);
     std::vector<int> devs(static_cast<size_t>(world));
     for (int r = 0; r < world; r++) devs[r] = st.slabs[r].device;
-    VGTX_NCCL(rccl.CommInitAll(st.comms.data(), world, devs.data()), "ncclCommInitAll");
+    std::string comm_error;
+    CommSet* const set = GetCommSet(rccl, devs, &comm_error);
+    if (!set) return FailMulti(VGT_HIP_ERR_RUNTIME, comm_error);
+    st.comm_lock = std::unique_lock<std::mutex>(set->in_use);
     VGTX_NCCL(rccl.GroupStart(), "ncclGroupStart");
     for (int r = 0; r < world; r++)
     {
       Slab& s = st.slabs[r];
       // 8-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
       const ncclResult_t res = rccl.AllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
-                                              st.comms[r], s.stream);
+                                              set->comms[r], s.stream);
       if (res != ncclSuccess)
       {
         (void)rccl.GroupEnd();
