@@ -245,6 +245,30 @@ def test_multi_device_argument_errors():
         capi.sdf_multi([0, 4096], occ, 0.1)
 
 
+@pytest.mark.parametrize("shape", [(40, 33, 2048), (40, 33, 2049), (3, 1024, 2048), (1024, 3, 2048), (1024, 64, 2048),
+                                   (1024, 65, 2048)])
+def test_packed_owner_limits(ctx, oracle, shape):
+    """The line passes keep (owner row, magnitude) in one 32-bit LDS word while every input magnitude is below
+    2^22 and the line has at most 1024 rows, and fall back to the member-mask iterator beyond that: shapes on
+    both sides of the limit (2047^2 < 2^22 <= 2048^2; 2047^2 + 63^2 < 2^22 <= 2047^2 + 64^2), with fields
+    whose distances reach the largest magnitudes (a single site in a corner) and dense ones."""
+    rng = np.random.default_rng(sum(shape))
+    fields = []
+    occ = np.zeros(shape, dtype=np.float32)
+    occ[0, 0, 0] = 1.0
+    fields.append(occ)
+    occ = np.zeros(shape, dtype=np.float32)
+    occ[-1, -1, -1] = 1.0
+    occ[0, shape[1] // 2, 0] = 1.0
+    fields.append(occ)
+    fields.append((rng.random(shape) < 0.002).astype(np.float32))
+    for occ in fields:
+        want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.05)
+        got, lo, hi = ctx.sdf_from_occupancy(occ, 0.05)
+        assert bits_equal(got, want), shape
+        assert (lo, hi) == (wlo, whi)
+
+
 @pytest.mark.parametrize("shape", [(1100, 6, 40), (5, 1500, 33), (2048, 4, 16), (3, 2049, 20),
                                    (2100, 3, 8), (4, 5, 1100), (2, 3, 2500)])
 def test_long_axes(ctx, oracle, shape):

@@ -82,10 +82,19 @@ __device__ int g_hull_stats_base;
 #endif
 namespace
 {
-template <int W>
+// Packed owners (kPacked): when every input magnitude is below 2^kMagBits and a line has at most 1024 rows, the
+// 32-bit LDS word of a row holds the row's magnitude and -- once the hull is final -- the position of the member
+// whose ownership starts at that row.  The evaluation then needs no iterator over the member masks: at a start row
+// the owner is read from the row's own word.
+constexpr int kMagBits = 22;
+constexpr int32_t kMagMask = (1 << kMagBits) - 1;
+
+template <int W, bool kPacked>
 struct Tile
 {
-  int32_t* F;          // [n][W]  signed squared value (sign = class, |.| = distance^2 or kInf32)
+  int32_t* F;          // [n][W]  signed squared value (sign = class, |.| = distance^2 or kInf32); packed
+                       //         owners: magnitude in the low kMagBits, from phase 2b the owner that starts at
+                       //         this row above them
   uint32_t* S;         // [nwords][W] sign bits (1 = negative class)
   uint32_t* A;         // [nwords][W] hull bits while merging
   uint32_t* A2;        // [nwords][W] members that own at least one row
@@ -110,6 +119,7 @@ struct Tile
   __device__ __forceinline__ int32_t Mag(int row) const
   {
     const int32_t v = Raw(row);
+    if constexpr (kPacked) return v & kMagMask;
     return v < 0 ? -v : v;
   }
   // highest set bit of mask M over rows [lo, r), or -1
@@ -205,7 +215,7 @@ size_t TileBytes(int n)
 }
 
 // SW = lanes used per line in the transposed scans (32 when a line has <= 32 words, else 64).
-template <typename InT, typename OutT, bool kFinal, int W, int SW>
+template <typename InT, typename OutT, bool kFinal, int W, int SW, bool kPacked>
 __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ in,
                                                       OutT* __restrict__ out,
                                                       uint32_t* __restrict__ minmax_enc,
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int n = g.n;
   const int nwords = (n + kBandRows - 1) / kBandRows;
   const int mw = nwords * W;
-  Tile<W> t;
+  Tile<W, kPacked> t;
   t.F = reinterpret_cast<int32_t*>(smem);
   t.sumA = reinterpret_cast<uint64_t*>(t.F + static_cast<size_t>(n) * W);
   t.sumA2 = t.sumA + W;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     // (lines beyond nz hold +kInf32 in the tile, so only rows past the end need a guard; a full
     // band reads its 32 rows at constant offsets from one address)
     int32_t raw[kBandRows];
-    const int32_t* column = t.F + r0 * W + t.w;
+    int32_t* column = t.F + r0 * W + t.w;
     if (r0 + kBandRows <= n)
     {
 #pragma unroll
@@ -298,6 +308,21 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (v < 0) sbits |= 1u << k;
       fr[k] = v < 0 ? -v : v;
       if (fr[k] != kInf32) finite |= 1u << k;
+    }
+    if constexpr (kPacked)
+    {
+      // magnitudes only in the tile from here on (the signs are in S); rows without a site get clean upper bits too
+      if (r0 + kBandRows <= n)
+      {
+#pragma unroll
+        for (int k = 0; k < kBandRows; k++) column[k * W] = fr[k] & kMagMask;
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < kBandRows; k++)
+          if (r0 + k < n) column[k * W] = fr[k] & kMagMask;
+      }
     }
     // strongest member of the band (smallest value), for the seeds
     int32_t min_value = kInf32;
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (member >= 0)
       {
         const int32_t v = t.F[member * W + line];
-        member_f = v < 0 ? -v : v;
+        member_f = kPacked ? (v & kMagMask) : (v < 0 ? -v : v);
       }
       // upwards: boundary row R = first row of band j+1
       {
@@ -707,6 +732,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       {
         a2 |= 1u << (member - r0);
         atomicOr(&t.T[(start >> 5) * W + t.w], 1u << (start & 31));
+        if constexpr (kPacked)
+          atomicOr(reinterpret_cast<uint32_t*>(&t.F[start * W + t.w]), static_cast<uint32_t>(member) << kMagBits);
         VGT_STAT_ADD(10, 1);
       }
     };
@@ -771,7 +798,24 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   }
   __syncthreads();
 
-  // ---- 2c. per word: survivors and start bits in lower words, summary of A2 ----
+  // ---- 2c. per word: survivors and start bits in lower words, summary of A2 (packed owners: only the summary
+  // of the start words, kept in sumA2) ----
+  if constexpr (kPacked)
+  {
+    for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
+    {
+      const int line = tt / SW;
+      const int j = tt % SW;
+      const uint32_t s = (j < nwords) ? t.T[j * W + line] : 0u;
+      const uint64_t any = __ballot(s != 0u);
+      if (j == 0)
+      {
+        const int sh = (threadIdx.x & 63) / SW * SW;
+        t.sumA2[line] = (SW == 64) ? any : ((any >> sh) & 0xffffffffull);
+      }
+    }
+  }
+  else
   for (int tt = threadIdx.x; tt < W * SW; tt += blockDim.x)
   {
     const int line = tt / SW;
@@ -816,8 +860,31 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     int cur = -1;
     int32_t fcur = 0;
     // iterator over the line's owners (bits of A2): word index and the bits of that word above cur
-    int owner_word = -1;
-    uint32_t owner_rest = 0;
+    [[maybe_unused]] int owner_word = -1;
+    [[maybe_unused]] uint32_t owner_rest = 0;
+    // packed owners: OR-ed into the owner's value, kNoValue while the line has no member at all
+    [[maybe_unused]] int32_t no_owner = 0;
+    if constexpr (kPacked)
+    {
+      // the owner of r0 is written at the nearest start row at or below r0 (row 0 starts the first member's range)
+      cur = r0;
+      if (!(tw & 1u))
+      {
+        const uint64_t below = t.sumA2[t.w] & ((1ull << band) - 1ull);
+        if (below)
+        {
+          const int j = 63 - __clzll(static_cast<long long>(below));
+          const uint32_t tj = t.T[j * W + t.w];
+          const int row = (j << 5) + 31 - __clz(static_cast<int>(tj));
+          cur = static_cast<int>(static_cast<uint32_t>(t.Raw(row)) >> kMagBits);
+        }
+        else
+        {
+          no_owner = 0x60000000;  // = kNoValue below
+        }
+      }
+    }
+    else
     {
       int k = t.cumT[band * W + t.w] + static_cast<int>(tw & 1u);
       if (k > 0)
@@ -858,11 +925,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     constexpr int32_t kNoValue = 0x60000000;    // above every real squared distance, + 2047^2 stays below 2^31
     constexpr int32_t kFarRows = 36000;         // 36000^2 > 3 * 16384^2, (36000 + 2048)^2 < 2^31
     constexpr int32_t kRealLimit = 0x40000000;
-    if (cur < 0)
+    if (!kPacked && cur < 0)
     {
       cur = r0;
       fcur = kNoValue;
     }
+    static_assert(kNoValue == 0x60000000, "no_owner above");
+    [[maybe_unused]] const int32_t* column = t.F + r0 * W + t.w;
     bool neg = false;
     int prev_opp = -kFarRows, next_opp = n + kFarRows;
     const uint32_t row_mask = LowMask(r1 - r0);
@@ -876,7 +945,15 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
       if (k < r1 - r0)
       {
         const int r = r0 + k;
-        if (k > 0 && ((tw >> k) & 1u))
+        if constexpr (kPacked)
+        {
+          // a start row names its owner in its own word; the owner's value is gathered every row (cheaper than a
+          // branch that some lane of the wave takes at nearly every row)
+          const uint32_t word = static_cast<uint32_t>(column[k * W]);
+          cur = ((tw >> k) & 1u) ? static_cast<int>(word >> kMagBits) : cur;
+          fcur = t.Mag(cur) | no_owner;
+        }
+        else if (k > 0 && ((tw >> k) & 1u) && !(VGT_SKIP(4096)))
         {
           // every start bit has its owner: the next bit of A2 (sumA2 lists the non-empty words exactly)
           if (owner_rest == 0u)
@@ -973,7 +1050,7 @@ int LinesPerTile(int64_t n)
   return 0;
 }
 
-template <typename InT, typename OutT, bool kFinal, int W, int SW>
+template <typename InT, typename OutT, bool kFinal, int W, int SW, bool kPacked = false>
 hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const HullGeom& g,
                       int64_t outer_count, hipStream_t stream)
 {
@@ -981,7 +1058,7 @@ hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const Hull
   const size_t lds = TileBytes<W>(g.n);
   int threads = nwords * W;
   threads = (threads + 63) / 64 * 64;
-  auto kernel = HullPassKernel<InT, OutT, kFinal, W, SW>;
+  auto kernel = HullPassKernel<InT, OutT, kFinal, W, SW, kPacked>;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
@@ -1003,7 +1080,7 @@ hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const Hull
 
 template <typename InT, typename OutT, bool kFinal>
 hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom g,
-                        int64_t outer_count, hipStream_t stream, bool* handled)
+                        int64_t outer_count, int64_t max_input, hipStream_t stream, bool* handled)
 {
   int W = LinesPerTile(g.n);
 #ifdef VGT_HULL_DEBUG  // tile-width experiments (diagnostic build only)
@@ -1030,6 +1107,16 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
     return hipSuccess;
   }
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
+  // packed owners: 10 bits of row above kMagBits of magnitude in one LDS word
+  bool packed = (g.n <= 1024) && (max_input <= kMagMask);
+#ifdef VGT_HULL_DEBUG
+  static const int no_packed = getenv("VGT_HULL_NO_PACKED") ? atoi(getenv("VGT_HULL_NO_PACKED")) : 0;
+  if (no_packed) packed = false;
+#endif
+  if (W == 32 && packed)
+    return LaunchHull<InT, OutT, kFinal, 32, 32, true>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 8 && packed)
+    return LaunchHull<InT, OutT, kFinal, 8, 32, true>(in, out, minmax_enc, g, outer_count, stream);
   if (W == 32)
     return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
 #ifdef VGT_HULL_DEBUG
@@ -1103,7 +1190,10 @@ hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams&
 {
   int64_t outer_count = 0;
   const HullGeom g = PassGeometry(p, XBeforeY(p) ? 0 : 1, &outer_count);
-  return DispatchHull<int16_t, int32_t, false>(in16, out32, nullptr, g, outer_count, stream, handled);
+  // input: squared Z distances
+  const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
+  const int64_t max_input = (nzg - 1) * (nzg - 1);
+  return DispatchHull<int16_t, int32_t, false>(in16, out32, nullptr, g, outer_count, max_input, stream, handled);
 }
 
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -1111,7 +1201,11 @@ hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* mi
 {
   int64_t outer_count = 0;
   const HullGeom g = PassGeometry(p, XBeforeY(p) ? 1 : 0, &outer_count);
-  return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, outer_count, stream, handled);
+  // input: squared distances within the plane of Z and the axis of the first line pass
+  const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
+  const int64_t first = XBeforeY(p) ? p.nx : p.ny;
+  const int64_t max_input = (nzg - 1) * (nzg - 1) + (first - 1) * (first - 1);
+  return DispatchHull<int32_t, float, true>(in32, sdf, minmax_enc, g, outer_count, max_input, stream, handled);
 }
 }  // namespace vgt
 
