@@ -246,11 +246,13 @@ def test_multi_device_argument_errors():
 
 
 @pytest.mark.parametrize("shape", [(40, 33, 2048), (40, 33, 2049), (3, 1024, 2048), (1024, 3, 2048), (1024, 64, 2048),
-                                   (1024, 65, 2048)])
+                                   (1024, 65, 2048), (3, 2048, 1449), (3, 2048, 1450), (2048, 3, 1449),
+                                   (2048, 30, 1449)])
 def test_packed_owner_limits(ctx, oracle, shape):
     """The line passes keep (owner row, magnitude) in one 32-bit LDS word while every input magnitude is below
-    2^22 and the line has at most 1024 rows, and fall back to the member-mask iterator beyond that: shapes on
-    both sides of the limit (2047^2 < 2^22 <= 2048^2; 2047^2 + 63^2 < 2^22 <= 2047^2 + 64^2), with fields
+    2^22 and the line has at most 1024 rows (2^21 and 2048 rows), and fall back to the member-mask iterator
+    beyond that: shapes on both sides of the limits (2047^2 < 2^22 <= 2048^2; 2047^2 + 63^2 < 2^22 <=
+    2047^2 + 64^2; 1448^2 < 2^21 <= 1449^2; 1448^2 + 2^2 < 2^21 <= 1448^2 + 29^2), with fields
     whose distances reach the largest magnitudes (a single site in a corner) and dense ones."""
     rng = np.random.default_rng(sum(shape))
     fields = []

@@ -82,16 +82,16 @@ __device__ int g_hull_stats_base;
 #endif
 namespace
 {
-// Packed owners (kPacked): when every input magnitude is below 2^kMagBits and a line has at most 1024 rows, the
+// Packed owners (kMagBits != 0): when every input magnitude is below 2^kMagBits and a row index fits the other
+// 32 - kMagBits bits (22 + 10 for lines of up to 1024 rows, 21 + 11 up to 2048), the
 // 32-bit LDS word of a row holds the row's magnitude and -- once the hull is final -- the position of the member
 // whose ownership starts at that row.  The evaluation then needs no iterator over the member masks: at a start row
 // the owner is read from the row's own word.
-constexpr int kMagBits = 22;
-constexpr int32_t kMagMask = (1 << kMagBits) - 1;
-
-template <int W, bool kPacked>
+template <int W, int kMagBits>
 struct Tile
 {
+  static constexpr bool kPacked = kMagBits != 0;
+  static constexpr int32_t kMagMask = (1 << kMagBits) - 1;
   int32_t* F;          // [n][W]  signed squared value (sign = class, |.| = distance^2 or kInf32); packed
                        //         owners: magnitude in the low kMagBits, from phase 2b the owner that starts at
                        //         this row above them
@@ -215,7 +215,7 @@ size_t TileBytes(int n)
 }
 
 // SW = lanes used per line in the transposed scans (32 when a line has <= 32 words, else 64).
-template <typename InT, typename OutT, bool kFinal, int W, int SW, bool kPacked>
+template <typename InT, typename OutT, bool kFinal, int W, int SW, int kMagBits>
 __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ in,
                                                       OutT* __restrict__ out,
                                                       uint32_t* __restrict__ minmax_enc,
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
   const int n = g.n;
   const int nwords = (n + kBandRows - 1) / kBandRows;
   const int mw = nwords * W;
-  Tile<W, kPacked> t;
+  constexpr bool kPacked = kMagBits != 0;
+  constexpr int32_t kMagMask = (1 << kMagBits) - 1;
+  Tile<W, kMagBits> t;
   t.F = reinterpret_cast<int32_t*>(smem);
   t.sumA = reinterpret_cast<uint64_t*>(t.F + static_cast<size_t>(n) * W);
   t.sumA2 = t.sumA + W;
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 
   // ---- 3. evaluate this band's rows, store ----
   uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
-  int32_t lo_key = kInf32, hi_key = -kInf32;
+  float lo_value = INFINITY, hi_value = -INFINITY;
   if (active && !(VGT_SKIP(2)))
   {
     const uint32_t tw = t.T[band * W + t.w];
@@ -939,10 +941,7 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
     const uint32_t run_starts = ((sbits ^ (sbits << 1)) | 1u) & row_mask;
     const int wi = band * W + t.w;
     OutT* dst = out + (base + static_cast<int64_t>(r0) * g.row_stride + t.w);
-#pragma unroll
-    for (int k = 0; k < kBandRows; k++)
-    {
-      if (k < r1 - r0)
+    auto evaluate_row = [&](const int k) __attribute__((always_inline)) {
       {
         const int r = r0 + k;
         if constexpr (kPacked)
@@ -992,11 +991,13 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
             *dst = (neg ? -1.0f : 1.0f) * __fsqrt_rn(static_cast<float>(best)) * static_cast<float>(g.resolution);
           else
 #endif
-          if (!VGT_SKIP(1024) || best == 123456789) *dst = DistanceToSdf(best, neg, g.resolution);
-          // the SDF value is monotone in the signed squared distance: track that, convert once
-          const int32_t key = neg ? -best : best;
-          lo_key = min(lo_key, key);
-          hi_key = max(hi_key, key);
+          {
+            const float value = DistanceToSdf(best, neg, g.resolution);
+            *dst = value;
+            // extrema of the field (plain instructions: no NaN can occur, so no canonicalisation is needed)
+            asm("v_min_f32 %0, %0, %1" : "+v"(lo_value) : "v"(value));
+            asm("v_max_f32 %0, %0, %1" : "+v"(hi_value) : "v"(value));
+          }
         }
         else
         {
@@ -1004,14 +1005,26 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         }
         dst += g.row_stride;
       }
+    };
+    if ((n & (kBandRows - 1)) == 0)
+    {
+      // every band is full: no per-row guard
+#pragma unroll
+      for (int k = 0; k < kBandRows; k++) evaluate_row(k);
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < kBandRows; k++)
+        if (k < r1 - r0) evaluate_row(k);
     }
   }
   if constexpr (kFinal)
   {
-    if (lo_key <= hi_key)
+    if (lo_value <= hi_value)
     {
-      lo_enc = EncodeOrdered(DistanceToSdf(lo_key < 0 ? -lo_key : lo_key, lo_key < 0, g.resolution));
-      hi_enc = EncodeOrdered(DistanceToSdf(hi_key < 0 ? -hi_key : hi_key, hi_key < 0, g.resolution));
+      lo_enc = EncodeOrdered(lo_value);
+      hi_enc = EncodeOrdered(hi_value);
     }
     BlockMinMax(lo_enc, hi_enc, minmax_enc);
   }
@@ -1050,7 +1063,7 @@ int LinesPerTile(int64_t n)
   return 0;
 }
 
-template <typename InT, typename OutT, bool kFinal, int W, int SW, bool kPacked = false>
+template <typename InT, typename OutT, bool kFinal, int W, int SW, int kMagBits = 0>
 hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const HullGeom& g,
                       int64_t outer_count, hipStream_t stream)
 {
@@ -1058,7 +1071,7 @@ hipError_t LaunchHull(const InT* in, OutT* out, uint32_t* minmax_enc, const Hull
   const size_t lds = TileBytes<W>(g.n);
   int threads = nwords * W;
   threads = (threads + 63) / 64 * 64;
-  auto kernel = HullPassKernel<InT, OutT, kFinal, W, SW, kPacked>;
+  auto kernel = HullPassKernel<InT, OutT, kFinal, W, SW, kMagBits>;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
@@ -1107,16 +1120,19 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
     return hipSuccess;
   }
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
-  // packed owners: 10 bits of row above kMagBits of magnitude in one LDS word
-  bool packed = (g.n <= 1024) && (max_input <= kMagMask);
+  // packed owners: the row index above the magnitude in one LDS word
+  bool packed22 = (g.n <= 1024) && (max_input < (1 << 22));
+  bool packed21 = (g.n <= 2048) && (max_input < (1 << 21));
 #ifdef VGT_HULL_DEBUG
   static const int no_packed = getenv("VGT_HULL_NO_PACKED") ? atoi(getenv("VGT_HULL_NO_PACKED")) : 0;
-  if (no_packed) packed = false;
+  if (no_packed) packed22 = packed21 = false;
 #endif
-  if (W == 32 && packed)
-    return LaunchHull<InT, OutT, kFinal, 32, 32, true>(in, out, minmax_enc, g, outer_count, stream);
-  if (W == 8 && packed)
-    return LaunchHull<InT, OutT, kFinal, 8, 32, true>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 32 && packed22)
+    return LaunchHull<InT, OutT, kFinal, 32, 32, 22>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 8 && nwords <= 32 && packed22)
+    return LaunchHull<InT, OutT, kFinal, 8, 32, 22>(in, out, minmax_enc, g, outer_count, stream);
+  if (W == 8 && nwords > 32 && packed21)
+    return LaunchHull<InT, OutT, kFinal, 8, 64, 21>(in, out, minmax_enc, g, outer_count, stream);
   if (W == 32)
     return LaunchHull<InT, OutT, kFinal, 32, 32>(in, out, minmax_enc, g, outer_count, stream);
 #ifdef VGT_HULL_DEBUG
