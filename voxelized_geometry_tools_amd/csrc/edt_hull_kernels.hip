@@ -303,14 +303,18 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #pragma unroll
       for (int k = 0; k < kBandRows; k++) raw[k] = (r0 + k < n) ? column[k * W] : kInf32;
     }
+    // sign word and "no site" word gathered from sign masks (no compares): kInf32 + 1 is the only sum that wraps
+    uint32_t none = 0;
 #pragma unroll
     for (int k = 0; k < kBandRows; k++)
     {
       const int32_t v = raw[k];
-      if (v < 0) sbits |= 1u << k;
-      fr[k] = v < 0 ? -v : v;
-      if (fr[k] != kInf32) finite |= 1u << k;
+      const int32_t sign = v >> 31;
+      sbits |= static_cast<uint32_t>(sign) & (1u << k);
+      fr[k] = (v ^ sign) - sign;
+      none |= static_cast<uint32_t>(static_cast<int32_t>(static_cast<uint32_t>(fr[k]) + 1u) >> 31) & (1u << k);
     }
+    finite = ~none;
     if constexpr (kPacked)
     {
       // magnitudes only in the tile from here on (the signs are in S); rows without a site get clean upper bits too
@@ -516,13 +520,18 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
 #pragma unroll
           for (int d = 1; d <= kChordMaxSpacing; d <<= 1)
           {
+            // The test as a sign bit, f(k-d) + f(k+d) + 2 d^2 - 1 - 2 f(k) < 0, shifted into the mask from the top
+            // row down (one v_alignbit per test instead of compare + select + or).  Rows without a site wrap around;
+            // they are masked below.
             uint32_t dom = 0;
 #pragma unroll
-            for (int k = d; k + d < kBandRows; k++)
+            for (int k = kBandRows - 1 - d; k >= d; k--)
             {
               const uint32_t lo = static_cast<uint32_t>(fr[k - d]), hi = static_cast<uint32_t>(fr[k + d]);
-              dom |= (lo + hi + 2u * d * d <= 2u * static_cast<uint32_t>(fr[k]) ? 1u : 0u) << k;
+              const uint32_t diff = lo + hi + (2u * d * d - 1u) - 2u * static_cast<uint32_t>(fr[k]);
+              dom = __builtin_amdgcn_alignbit(dom, diff, 31);
             }
+            dom <<= d;
             // both neighbours are members
             above |= dom & (finite << d) & (finite >> d);
           }
@@ -1121,8 +1130,9 @@ hipError_t DispatchHull(const InT* in, OutT* out, uint32_t* minmax_enc, HullGeom
   }
   const int nwords = (g.n + kBandRows - 1) / kBandRows;
   // packed owners: the row index above the magnitude in one LDS word
-  bool packed22 = (g.n <= 1024) && (max_input < (1 << 22));
-  bool packed21 = (g.n <= 2048) && (max_input < (1 << 21));
+  // (strictly below the all-ones magnitude, which stands for "no site" in the tile)
+  bool packed22 = (g.n <= 1024) && (max_input < (1 << 22) - 1);
+  bool packed21 = (g.n <= 2048) && (max_input < (1 << 21) - 1);
 #ifdef VGT_HULL_DEBUG
   static const int no_packed = getenv("VGT_HULL_NO_PACKED") ? atoi(getenv("VGT_HULL_NO_PACKED")) : 0;
   if (no_packed) packed22 = packed21 = false;
