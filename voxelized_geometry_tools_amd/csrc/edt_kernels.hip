@@ -224,10 +224,8 @@ __global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(
 }
 
 // Main path for nz % 4 == 0, nz <= 256 * NCH: every lane owns FOUR consecutive voxels (one 16-byte
-// load, one 8-byte store), so a wave covers 256 voxels per chunk and the 64-bit mask work
-// (nearest group of the other class below / above, one ds_bpermute each to fetch that group's
-// bits) is paid once per four voxels; inside the group the neighbours are found on 4-bit masks.
-// All loads of a line are in flight before the first ballot.
+// load, one 8-byte store), so a wave covers 256 voxels per chunk.  All loads of a line are in flight before
+// the first ballot.
 template <typename InT>
 struct QuadOf;
 template <>
@@ -241,8 +239,15 @@ struct QuadOf<uint8_t>
   using type = uchar4;
 };
 
+// The scan works on class TRANSITIONS: the nearest voxel of the other class below voxel z is the voxel at the
+// last index i < z with class(i) != class(i + 1), the nearest above is i + 1 for the first such i >= z -- one
+// transition set serves both classes, so the kernel has no per-class masks, selects or carries.  The class of a
+// voxel and the transitions are per-lane predicates (lane masks in scalar registers, combined by the scalar
+// unit); every lane publishes the first and the last transition of its own four voxels, the nearest transition
+// outside the quad is fetched from the nearest lane that has one (one ballot, two ds_bpermute per quad), and the
+// four voxels take running selects over their quad's three inner transitions.
 template <typename InT, int NCH>
-__global__ __launch_bounds__(kScanBlock) void ScanZQuadKernel(
+__global__ __launch_bounds__(kScanBlock) void ScanZTransitionKernel(
     const InT* __restrict__ in, int16_t* __restrict__ out, int64_t num_lines, int nz,
     int unknown_is_filled, SlabLineSummary* __restrict__ summary, int z_offset)
 {
@@ -264,108 +269,133 @@ __global__ __launch_bounds__(kScanBlock) void ScanZQuadKernel(
       const int grp = c * kWave + lane;
       if (grp * 4 < nz) v[c] = src[grp];
     }
-    uint32_t fb[NCH], eb[NCH];   // filled / free voxels of my group (4 bits)
-    uint64_t HF[NCH], HE[NCH];   // groups of the chunk that hold a filled / a free voxel
+    bool f[NCH][4];     // class of my four voxels (false beyond the line)
+    int first0[NCH];    // class of the first voxel of my quad as an integer, for the lane below me
 #pragma unroll
     for (int c = 0; c < NCH; c++)
     {
       const bool valid = (c * kWave + lane) * 4 < nz;
-      uint32_t f = 0;
-      if (valid)
-        f = (IsFilled(v[c].x, unknown_is_filled) ? 1u : 0u) | (IsFilled(v[c].y, unknown_is_filled) ? 2u : 0u) |
-            (IsFilled(v[c].z, unknown_is_filled) ? 4u : 0u) | (IsFilled(v[c].w, unknown_is_filled) ? 8u : 0u);
-      fb[c] = f;
-      eb[c] = valid ? (~f & 0xfu) : 0u;
-      HF[c] = __ballot(fb[c] != 0u);
-      HE[c] = __ballot(eb[c] != 0u);
+      f[c][0] = valid && IsFilled(v[c].x, unknown_is_filled);
+      f[c][1] = valid && IsFilled(v[c].y, unknown_is_filled);
+      f[c][2] = valid && IsFilled(v[c].z, unknown_is_filled);
+      f[c][3] = valid && IsFilled(v[c].w, unknown_is_filled);
+      first0[c] = f[c][0] ? 1 : 0;
     }
-    // scalar carries across chunks: nearest filled / free voxel after the chunk, before the chunk
-    int32_t next_filled[NCH], next_free[NCH], prev_filled[NCH], prev_free[NCH];
-    int32_t nf = kNoneAbove, ne = kNoneAbove;
-#pragma unroll
-    for (int c = NCH - 1; c >= 0; c--)
-    {
-      next_filled[c] = nf;
-      next_free[c] = ne;
-      if (HF[c])
-      {
-        const int g = __ffsll(static_cast<long long>(HF[c])) - 1;
-        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fb[c]), g));
-        nf = (c * kWave + g) * 4 + __ffs(static_cast<int>(bits)) - 1;
-      }
-      if (HE[c])
-      {
-        const int g = __ffsll(static_cast<long long>(HE[c])) - 1;
-        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eb[c]), g));
-        ne = (c * kWave + g) * 4 + __ffs(static_cast<int>(bits)) - 1;
-      }
-    }
-    int32_t pf = kNoneBelow, pe = kNoneBelow;
+    bool t[NCH][4];     // t[c][k]: voxels base + k and base + k + 1 exist and differ in class
+    uint64_t HT[NCH];   // lanes whose quad holds a transition
+    int own_first[NCH], own_last[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++)
     {
-      prev_filled[c] = pf;
-      prev_free[c] = pe;
-      if (HF[c])
+      const int base = (c * kWave + lane) * 4;
+      // class of the voxel after my quad: the first voxel of the next lane (of the next chunk for lane 63)
+      int next0 = __shfl_down(first0[c], 1);
+      if (c + 1 < NCH)
       {
-        const int g = 63 - __clzll(static_cast<long long>(HF[c]));
-        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(fb[c]), g));
-        pf = (c * kWave + g) * 4 + 31 - __clz(static_cast<int>(bits));
+        const int wrap = __builtin_amdgcn_readfirstlane(first0[c + 1]);
+        next0 = (lane == kWave - 1) ? wrap : next0;
       }
-      if (HE[c])
-      {
-        const int g = 63 - __clzll(static_cast<long long>(HE[c]));
-        const uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(eb[c]), g));
-        pe = (c * kWave + g) * 4 + 31 - __clz(static_cast<int>(bits));
-      }
+      t[c][0] = (base + 1 < nz) && (f[c][0] != f[c][1]);
+      t[c][1] = (base + 2 < nz) && (f[c][1] != f[c][2]);
+      t[c][2] = (base + 3 < nz) && (f[c][2] != f[c][3]);
+      t[c][3] = (base + 4 < nz) && (f[c][3] != (next0 != 0));
+      HT[c] = __ballot(t[c][0] || t[c][1] || t[c][2] || t[c][3]);
+      own_first[c] = t[c][0] ? base : (t[c][1] ? base + 1 : (t[c][2] ? base + 2 : base + 3));
+      own_last[c] = t[c][3] ? base + 3 : (t[c][2] ? base + 2 : (t[c][1] ? base + 1 : base));
+    }
+    // scalar carries across chunks: first transition after the chunk, last transition before it
+    int32_t next_t[NCH], prev_t[NCH];
+    int32_t nt = kNoneAbove;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; c--)
+    {
+      next_t[c] = nt;
+      if (HT[c]) nt = __builtin_amdgcn_readlane(own_first[c], __ffsll(static_cast<long long>(HT[c])) - 1);
+    }
+    int32_t pt = kNoneBelow;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+    {
+      prev_t[c] = pt;
+      if (HT[c]) pt = __builtin_amdgcn_readlane(own_last[c], 63 - __clzll(static_cast<long long>(HT[c])));
     }
 #pragma unroll
     for (int c = 0; c < NCH; c++)
     {
       const int grp = c * kWave + lane;
       const int base = grp * 4;
-      // nearest filled / free voxel outside my group, below and above
-      const uint64_t fbelow = HF[c] & lt_mask, ebelow = HE[c] & lt_mask;
-      const uint64_t fabove = HF[c] & gt_mask, eabove = HE[c] & gt_mask;
-      const int g_fb = fbelow ? 63 - __clzll(static_cast<long long>(fbelow)) : lane;
-      const int g_eb = ebelow ? 63 - __clzll(static_cast<long long>(ebelow)) : lane;
-      const int g_fa = fabove ? __ffsll(static_cast<long long>(fabove)) - 1 : lane;
-      const int g_ea = eabove ? __ffsll(static_cast<long long>(eabove)) - 1 : lane;
-      const uint32_t b_fb = static_cast<uint32_t>(__shfl(static_cast<int>(fb[c]), g_fb));
-      const uint32_t b_eb = static_cast<uint32_t>(__shfl(static_cast<int>(eb[c]), g_eb));
-      const uint32_t b_fa = static_cast<uint32_t>(__shfl(static_cast<int>(fb[c]), g_fa));
-      const uint32_t b_ea = static_cast<uint32_t>(__shfl(static_cast<int>(eb[c]), g_ea));
-      const int32_t PFb = fbelow ? (c * kWave + g_fb) * 4 + 31 - __clz(static_cast<int>(b_fb)) : prev_filled[c];
-      const int32_t PEb = ebelow ? (c * kWave + g_eb) * 4 + 31 - __clz(static_cast<int>(b_eb)) : prev_free[c];
-      const int32_t PFa = fabove ? (c * kWave + g_fa) * 4 + __ffs(static_cast<int>(b_fa)) - 1 : next_filled[c];
-      const int32_t PEa = eabove ? (c * kWave + g_ea) * 4 + __ffs(static_cast<int>(b_ea)) - 1 : next_free[c];
+      // nearest transition outside my quad, below and above
+      const uint64_t tbelow = HT[c] & lt_mask, tabove = HT[c] & gt_mask;
+      const int g_b = tbelow ? 63 - __clzll(static_cast<long long>(tbelow)) : lane;
+      const int g_a = tabove ? __ffsll(static_cast<long long>(tabove)) - 1 : lane;
+      const int32_t from_b = __shfl(own_last[c], g_b);
+      const int32_t from_a = __shfl(own_first[c], g_a);
+      const int32_t Pb = tbelow ? from_b : prev_t[c];
+      const int32_t Pa = tabove ? from_a : next_t[c];
       if (base < nz)
       {
+        // last transition below voxel k / first transition at or above it
+        const int32_t b0 = Pb;
+        const int32_t b1 = t[c][0] ? base : b0;
+        const int32_t b2 = t[c][1] ? base + 1 : b1;
+        const int32_t b3 = t[c][2] ? base + 2 : b2;
+        const int32_t a3 = t[c][3] ? base + 3 : Pa;
+        const int32_t a2 = t[c][2] ? base + 2 : a3;
+        const int32_t a1 = t[c][1] ? base + 1 : a2;
+        const int32_t a0 = t[c][0] ? base : a1;
+        const int32_t below[4] = {b0, b1, b2, b3};
+        const int32_t above[4] = {a0, a1, a2, a3};
         int16_t r[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
-          const bool is_filled = (fb[c] >> k) & 1u;
-          const uint32_t other = is_filled ? eb[c] : fb[c];
-          const uint32_t lowm = other & ((1u << k) - 1u);
-          const uint32_t highm = other >> (k + 1);
-          const int32_t below = lowm ? base + 31 - __clz(static_cast<int>(lowm)) : (is_filled ? PEb : PFb);
-          const int32_t above = highm ? base + k + __ffs(static_cast<int>(highm)) : (is_filled ? PEa : PFa);
           const int32_t z = base + k;
-          const int32_t d = min(min(z - below, above - z), static_cast<int32_t>(kInf16));
-          r[k] = static_cast<int16_t>(is_filled ? -d : d);
+          // the other class sits AT the transition below and one voxel past the transition above
+          const int32_t d = min(min(z - below[k], above[k] + 1 - z), static_cast<int32_t>(kInf16));
+          r[k] = static_cast<int16_t>(f[c][k] ? -d : d);
         }
         dst[grp] = make_short4(r[0], r[1], r[2], r[3]);
       }
     }
-    if (summary && lane == 0)
+    if (summary)
     {
-      SlabLineSummary out_summary;
-      out_summary.first_filled = static_cast<int16_t>(nf == kNoneAbove ? -1 : nf + z_offset);
-      out_summary.last_filled = static_cast<int16_t>(pf == kNoneBelow ? -1 : pf + z_offset);
-      out_summary.first_free = static_cast<int16_t>(ne == kNoneAbove ? -1 : ne + z_offset);
-      out_summary.last_free = static_cast<int16_t>(pe == kNoneBelow ? -1 : pe + z_offset);
-      summary[line] = out_summary;
+      // slab summaries (multi-GPU): first / last voxel of either class, from the class masks
+      int32_t ff = -1, lf = -1, fe = -1, le = -1;
+#pragma unroll
+      for (int c = NCH - 1; c >= 0; c--)
+      {
+#pragma unroll
+        for (int k = 3; k >= 0; k--)
+        {
+          const bool valid = (c * kWave + lane) * 4 + k < nz;
+          const uint64_t F = __ballot(f[c][k]);
+          const uint64_t E = __ballot(valid && !f[c][k]);
+          // descending (c, k, lane-within-mask is handled by taking the lowest lane): keep the smallest position
+          if (F)
+          {
+            const int pos = (c * kWave + __ffsll(static_cast<long long>(F)) - 1) * 4 + k;
+            ff = (ff < 0 || pos < ff) ? pos : ff;
+            const int last = (c * kWave + 63 - __clzll(static_cast<long long>(F))) * 4 + k;
+            lf = (last > lf) ? last : lf;
+          }
+          if (E)
+          {
+            const int pos = (c * kWave + __ffsll(static_cast<long long>(E)) - 1) * 4 + k;
+            fe = (fe < 0 || pos < fe) ? pos : fe;
+            const int last = (c * kWave + 63 - __clzll(static_cast<long long>(E))) * 4 + k;
+            le = (last > le) ? last : le;
+          }
+        }
+      }
+      if (lane == 0)
+      {
+        SlabLineSummary out_summary;
+        out_summary.first_filled = static_cast<int16_t>(ff < 0 ? -1 : ff + z_offset);
+        out_summary.last_filled = static_cast<int16_t>(lf < 0 ? -1 : lf + z_offset);
+        out_summary.first_free = static_cast<int16_t>(fe < 0 ? -1 : fe + z_offset);
+        out_summary.last_free = static_cast<int16_t>(le < 0 ? -1 : le + z_offset);
+        summary[line] = out_summary;
+      }
     }
   }
 }
@@ -589,7 +619,7 @@ hipError_t LaunchScanZ(const InT* in, int16_t* out16, const SdfParams& p, int un
                        (reinterpret_cast<uintptr_t>(in) % (4 * sizeof(InT)) == 0) &&
                        (reinterpret_cast<uintptr_t>(out16) % 8 == 0);
 #define VGT_QUAD_CASE(N)                                                                    \
-  hipLaunchKernelGGL((ScanZQuadKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
+  hipLaunchKernelGGL((ScanZTransitionKernel<InT, N>), dim3(grid), dim3(kScanBlock), 0, stream, in, \
                      out16, lines, nz, unknown_is_filled, summary, z_offset)
   if (quad_ok && nz <= 256)
     VGT_QUAD_CASE(1);
