@@ -105,11 +105,18 @@ def test_variants_agree_on_synthetic_distributions(ctx, oracle):
 def test_mask_entry_point(ctx, oracle):
     """vgt_hip_sdf_from_mask_u8: the path for map types whose predicate is evaluated on the host."""
     rng = np.random.default_rng(11)
-    mask = (rng.random((21, 34, 55)) < 0.1).astype(np.uint8)
-    got, lo, hi = ctx.sdf_from_mask(mask, 0.05)
-    want = oracle.sdf_from_mask(mask, 0.05)
-    assert bits_equal(got, want)
-    assert lo == want.min() and hi == want.max()
+    # Z extents that take the generic scan (55), the four-voxels-per-lane scan with 1, 2, 4 and 8 chunks per line
+    # (56, 260, 1024, 2048) and its partial last chunk (260)
+    for shape, p in (((21, 34, 55), 0.1), ((21, 34, 56), 0.1), ((5, 9, 260), 0.02), ((9, 7, 1024), 0.004),
+                     ((3, 3, 2048), 0.002), ((2, 2, 2048), 0.0)):
+        mask = (rng.random(shape) < p).astype(np.uint8)
+        if p == 0.0:
+            mask[0, 0, 0] = 1
+            mask[1, 1, 2047] = 1
+        got, lo, hi = ctx.sdf_from_mask(mask, 0.05)
+        want = oracle.sdf_from_mask(mask, 0.05)
+        assert bits_equal(got, want), shape
+        assert lo == want.min() and hi == want.max()
 
 
 def test_argument_errors(ctx):
