@@ -186,7 +186,7 @@ def end_to_end(ctx, torch, occ_dev, shape, res):
                           "end_to_end": round(2 * nbytes / pageable / 1e9, 1),
                           "end_to_end_pinned": round(2 * nbytes / pinned / 1e9, 1)},
             "vs_pcie_lower_bound": round(pinned / bound, 3), "host_results_identical": same,
-            "note": "host-pointer entry point: H2D + Z scan + Y pass + X pass + D2H; end_to_end_ms from pageable "
+            "note": "host-pointer entry point: H2D, Z scan + Y pass per X chunk as it arrives, X pass per Y range, D2H per range (three streams); end_to_end_ms from pageable "
                     "host memory (page-locked by the library for the call), end_to_end_pinned_ms from pinned memory"}
 
 

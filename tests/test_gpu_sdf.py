@@ -119,6 +119,35 @@ def test_mask_entry_point(ctx, oracle):
         assert lo == want.min() and hi == want.max()
 
 
+def test_pipelined_host_entry_point(ctx, oracle, monkeypatch):
+    """Large grids through the host-pointer entry points are uploaded in X chunks, scanned and swept along Y chunk
+    by chunk, swept along X in ranges of Y and downloaded range by range on separate streams.  The size threshold
+    is lowered so that small grids take that path: ragged chunk sizes, the virtual border (whose Y coordinate is
+    the range's offset + the tile's), masks, and a grid just below the minimum extents (falls back)."""
+    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "1")
+    rng = np.random.default_rng(77)
+    for shape in ((32, 32, 8), (33, 47, 20), (100, 61, 36), (70, 130, 17), (31, 64, 12), (64, 600, 8), (1030, 40, 8)):
+        occ = (rng.random(shape) < 0.03).astype(np.float32)
+        occ[rng.random(shape) < 0.01] = 0.5
+        for vb in (False, True):
+            want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.07, True, vb)
+            got, lo, hi = ctx.sdf_from_occupancy(occ, 0.07, True, vb)
+            assert bits_equal(got, want), (shape, vb)
+            assert (lo, hi) == (wlo, whi), (shape, vb)
+        mask = (occ > 0.4).astype(np.uint8)
+        got, lo, hi = ctx.sdf_from_mask(mask, 0.07)
+        want = oracle.sdf_from_mask(mask, 0.07)
+        assert bits_equal(got, want), shape
+        assert lo == want.min() and hi == want.max()
+    # the same call with the pipeline turned off gives the same field
+    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "-1")
+    occ = (rng.random((100, 61, 36)) < 0.03).astype(np.float32)
+    plain = ctx.sdf_from_occupancy(occ, 0.07, True, True)
+    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "1")
+    piped = ctx.sdf_from_occupancy(occ, 0.07, True, True)
+    assert bits_equal(plain[0], piped[0]) and plain[1:] == piped[1:]
+
+
 def test_argument_errors(ctx):
     with pytest.raises(ValueError):
         ctx.sdf_from_occupancy(np.zeros((4, 4, 4), np.float32), 0.0)      # non-positive resolution

@@ -992,8 +992,8 @@ __global__ __launch_bounds__(1024) void HullPassKernel(const InT* __restrict__ i
         best = (best >= kRealLimit) ? kInf32 : best;
         if constexpr (kFinal)
         {
-          const int x = (g.pass_axis == 0) ? r : outer;
-          const int y = (g.pass_axis == 0) ? outer : r;
+          const int x = (g.pass_axis == 0) ? r : outer + g.outer_begin;
+          const int y = (g.pass_axis == 0) ? outer + g.outer_begin : r;
           if (g.add_virtual_border) best = ClampToVirtualBorder(best, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
 #ifdef VGT_HULL_DEBUG
           if (VGT_SKIP(2048))  // timing experiment: what a plain float conversion would cost (results are NOT exact)
@@ -1225,8 +1225,30 @@ hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams&
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    const SdfParams& p, hipStream_t stream, bool* handled)
 {
+  return LaunchPassXHullFinalizeRange(in32, sdf, minmax_enc, p, 0, -1, stream, handled);
+}
+
+bool LinePassesAreTiled(const SdfParams& p)
+{
+  const int wx = LinesPerTile(p.nx), wy = LinesPerTile(p.ny);
+  if (wx == 0 || wy == 0 || XBeforeY(p)) return false;
+  return p.ny * ((p.nz + wx - 1) / wx) <= 0x7fffffffLL && p.nx * ((p.nz + wy - 1) / wy) <= 0x7fffffffLL;
+}
+
+hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                        const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                        hipStream_t stream, bool* handled)
+{
   int64_t outer_count = 0;
-  const HullGeom g = PassGeometry(p, XBeforeY(p) ? 1 : 0, &outer_count);
+  HullGeom g = PassGeometry(p, XBeforeY(p) ? 1 : 0, &outer_count);
+  if (outer_count_or_all >= 0)
+  {
+    // part of the outer axis (Y positions of the X pass): same strides, shifted base, fewer tiles
+    in32 += outer_begin * g.outer_stride;
+    sdf += outer_begin * g.outer_stride;
+    g.outer_begin = static_cast<int>(outer_begin);
+    outer_count = outer_count_or_all;
+  }
   // input: squared distances within the plane of Z and the axis of the first line pass
   const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
   const int64_t first = XBeforeY(p) ? p.nx : p.ny;

@@ -600,6 +600,9 @@ hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams&
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    const SdfParams& p, hipStream_t stream, bool* handled);
+hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                        const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                        hipStream_t stream, bool* handled);
 
 namespace
 {

@@ -28,6 +28,7 @@ struct TileGeom
   int debug_skip;        // timing experiments only (VGT_HULL_SKIP)
   int z_offset;          // Z slab (multi-GPU): global z of local z = 0
   int nz_global;         // Z extent of the whole grid (virtual border)
+  int outer_begin;       // a launch over part of the outer axis: index of its first outer position (virtual border)
 };
 
 // Cooperative load of a tile into LDS as signed squared int32, F[row * W + line].  Rows are

@@ -60,6 +60,10 @@ struct vgt_hip_ctx
   // struct until the last handle is gone, so handle destructors never touch freed memory.
   std::atomic<int> children{0};
   std::atomic<bool> destroyed{false};
+  // Copy streams and events of the pipelined host-pointer SDF extraction (SdfFromHostPipelined)
+  hipStream_t copy_in = nullptr;
+  hipStream_t copy_out = nullptr;
+  std::vector<hipEvent_t> pipeline_events;
 };
 
 struct vgt_hip_grids
@@ -274,6 +278,88 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
   return VGT_HIP_OK;
 }
 
+// Large grids through the host-pointer entry points: the three phases of a call -- upload, kernels, download --
+// overlap.  The grid is uploaded in X chunks (contiguous) on a copy stream and every chunk is scanned along Z and
+// swept along Y as soon as it has arrived; the X pass then runs over ranges of Y, and every finished range
+// (nx pieces of ny_range * nz floats) goes back on a second copy stream while the next range is computed.  Only
+// with the tiled line passes (the others need whole axes per launch).  The caller holds ctx->mutex.
+constexpr int kPipelineChunks = 8;
+
+template <typename InT>
+bool CanPipelineFromHost(const vgt_hip_ctx* ctx, const vgt::SdfParams& p)
+{
+  // VGT_HIP_HOST_PIPELINE_MIN_VOXELS: smallest grid that is pipelined (default 2^27; tests lower it, a negative
+  // value turns the pipeline off)
+  int64_t min_voxels = int64_t{1} << 27;
+  if (const char* text = getenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS")) min_voxels = atoll(text);
+  if (min_voxels < 0 || ctx->variant != vgt::EdtVariant::kDefault || !vgt::LinePassesAreTiled(p)) return false;
+  return p.nx >= 4 * kPipelineChunks && p.ny >= 4 * kPipelineChunks && p.nx * p.ny * p.nz >= min_voxels;
+}
+
+template <typename InT>
+int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, const vgt::SdfParams& p,
+                         float* sdf_dev, float* sdf_host)
+{
+  const SdfWorkspace ws = CarveWorkspace(ctx->sdf_ws, p.nx, p.ny, p.nz);
+  if (ctx->sdf_ws_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
+  if (!ctx->copy_in) VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking), "create stream");
+  if (!ctx->copy_out) VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking), "create stream");
+  while (ctx->pipeline_events.size() < static_cast<size_t>(2 * kPipelineChunks + 1))
+  {
+    hipEvent_t e = nullptr;
+    VGT_TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), "create event");
+    ctx->pipeline_events.push_back(e);
+  }
+  hipEvent_t* const uploaded = ctx->pipeline_events.data();
+  hipEvent_t* const computed = uploaded + kPipelineChunks;
+  hipEvent_t const start = ctx->pipeline_events[2 * kPipelineChunks];
+  hipStream_t s = ctx->stream;
+  // the copy streams begin after whatever the context's stream still has to do with these buffers
+  VGT_TRY_HIP(hipEventRecord(start, s), "event record");
+  VGT_TRY_HIP(hipStreamWaitEvent(ctx->copy_in, start, 0), "order the upload stream");
+  VGT_TRY_HIP(hipStreamWaitEvent(ctx->copy_out, start, 0), "order the download stream");
+  const int64_t plane = p.ny * p.nz;
+  auto x_begin = [&](int c) { return p.nx * c / kPipelineChunks; };
+  auto y_begin = [&](int c) { return p.ny * c / kPipelineChunks; };
+  for (int c = 0; c < kPipelineChunks; c++)
+  {
+    const int64_t off = x_begin(c) * plane, count = (x_begin(c + 1) - x_begin(c)) * plane;
+    VGT_TRY_HIP(hipMemcpyAsync(in_dev + off, input_host + off, static_cast<size_t>(count) * sizeof(InT),
+                               hipMemcpyHostToDevice, ctx->copy_in),
+                "copy occupancy to device");
+    VGT_TRY_HIP(hipEventRecord(uploaded[c], ctx->copy_in), "event record");
+  }
+  VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
+  for (int c = 0; c < kPipelineChunks; c++)
+  {
+    vgt::SdfParams part = p;
+    part.nx = x_begin(c + 1) - x_begin(c);
+    const int64_t off = x_begin(c) * plane;
+    VGT_TRY_HIP(hipStreamWaitEvent(s, uploaded[c], 0), "wait for a chunk of the upload");
+    if constexpr (std::is_same<InT, float>::value)
+      VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
+    else
+      VGT_TRY_HIP(vgt::LaunchScanZFromMask(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
+    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16 + off, ws.t32 + off, nullptr, part, ctx->variant, s), "Y pass");
+  }
+  const size_t pitch = static_cast<size_t>(plane) * sizeof(float);
+  for (int c = 0; c < kPipelineChunks; c++)
+  {
+    const int64_t y0 = y_begin(c), rows = y_begin(c + 1) - y0;
+    bool handled = false;
+    VGT_TRY_HIP(vgt::LaunchPassXHullFinalizeRange(ws.t32, sdf_dev, ws.minmax_enc, p, y0, rows, s, &handled), "X pass");
+    if (!handled) return Fail(VGT_HIP_ERR_RUNTIME, "X pass: the tiled kernel refused a range it had accepted");
+    VGT_TRY_HIP(hipEventRecord(computed[c], s), "event record");
+    VGT_TRY_HIP(hipStreamWaitEvent(ctx->copy_out, computed[c], 0), "wait for a range of the field");
+    VGT_TRY_HIP(hipMemcpy2DAsync(sdf_host + y0 * p.nz, pitch, sdf_dev + y0 * p.nz, pitch,
+                                 static_cast<size_t>(rows * p.nz) * sizeof(float), static_cast<size_t>(p.nx),
+                                 hipMemcpyDeviceToHost, ctx->copy_out),
+                "copy SDF to host");
+  }
+  VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, ctx->minmax_out, s), "min/max");
+  return VGT_HIP_OK;
+}
+
 template <typename InT>
 int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p, float* sdf_host,
                 float* out_min, float* out_max)
@@ -300,6 +386,29 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   float* sdf_dev = static_cast<float*>(ctx->sdf_out);
   hipStream_t s = ctx->stream;
   int result = VGT_HIP_OK;
+  if (CanPipelineFromHost<InT>(ctx, p))
+  {
+    if (!ctx->minmax_out) return Fail(VGT_HIP_ERR_RUNTIME, "context has no extrema buffer");
+    result = SdfFromHostPipelined<InT>(ctx, input_host, in_dev, p, sdf_dev, sdf_host);
+    float mm[2] = {0.0f, 0.0f};
+    if (result == VGT_HIP_OK)
+    {
+      err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, s);
+      if (err != hipSuccess) result = FailHip("copy extrema to host", err);
+    }
+    // drain all three streams whatever happened: the caller's arrays are about to be unpinned
+    const hipError_t e1 = hipStreamSynchronize(ctx->copy_in);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    const hipError_t e3 = hipStreamSynchronize(ctx->copy_out);
+    if (result == VGT_HIP_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+      result = FailHip("pipelined SDF extraction", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3));
+    if (result == VGT_HIP_OK)
+    {
+      if (out_min) *out_min = mm[0];
+      if (out_max) *out_max = mm[1];
+    }
+    return result;
+  }
   err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
   if (err != hipSuccess)
     result = FailHip("copy occupancy to device", err);
@@ -528,6 +637,13 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   FreeCachedSdfBuffers(ctx);
   for (hipEvent_t e : ctx->timing_events)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->pipeline_events)
+    if (e) (void)hipEventDestroy(e);
+  ctx->pipeline_events.clear();
+  if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
+  ctx->copy_in = nullptr;
+  ctx->copy_out = nullptr;
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->minmax_out = nullptr;
   ctx->timing_events.clear();

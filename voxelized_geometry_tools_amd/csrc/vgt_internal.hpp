@@ -79,6 +79,14 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, 
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                void* line_scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
+// The tiled line passes (edt_hull_kernels.hip), for callers that pipeline parts of a grid: true when the default
+// variant runs both line passes with the tiled kernel in Y-then-X order; the Y pass then treats X slices
+// independently (call LaunchPassY with nx = slices of a contiguous part), and the X pass can be launched over a
+// range of Y positions (full-grid pointers and extents in `p`).
+bool LinePassesAreTiled(const SdfParams& p);
+hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                        const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                        hipStream_t stream, bool* handled);
 // Scratch for the line-sweep passes (edt_line_kernels.hip).
 size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
