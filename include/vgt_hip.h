@@ -168,7 +168,11 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
  * (I/occupancy_map.hpp:174-210 -> I/signed_distance_field_generation.hpp:39-285 ->
  *  S/signed_distance_field_generation.cpp:258-391).  occupancy_host / sdf_host are
  * float[nx*ny*nz]; out_min / out_max receive what SignedDistanceField::Lock() caches
- * (I/signed_distance_field.hpp:765-787) and may be NULL. */
+ * (I/signed_distance_field.hpp:765-787) and may be NULL.  Blocking.  The two host arrays are
+ * page-locked for the call, the context keeps its device buffers between calls (vgt_hip_trim
+ * returns them), and grids of 2^27 voxels and more overlap upload, kernels and download chunk
+ * by chunk on three streams (environment: VGT_HIP_HOST_PIPELINE_MIN_VOXELS = smallest
+ * pipelined grid, negative = never); the result does not depend on it. */
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host,
                                    int64_t nx, int64_t ny, int64_t nz, double resolution,
                                    int unknown_is_filled, int add_virtual_border,
