@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 3]  # tiled envelope, pruned search from HBM, line sweep
+VARIANTS = [0, 1, 3, 4]  # tiled envelope, pruned search from HBM, line sweep (HBM stacks), lane sweep (LDS stacks)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -596,6 +596,10 @@ hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, c
                            hipStream_t stream);
 hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    void* scratch, const SdfParams& p, hipStream_t stream);
+hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+                            hipStream_t stream);
+hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                    const SdfParams& p, hipStream_t stream);
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -728,6 +732,8 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, 
 {
   if (variant == EdtVariant::kLine && line_scratch)
     return LaunchPassYLine(in16, out32, line_scratch, p, stream);
+  if (variant == EdtVariant::kSweep && line_scratch)
+    return LaunchPassYSweep(in16, out32, line_scratch, p, stream);
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;
@@ -746,6 +752,8 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
 {
   if (variant == EdtVariant::kLine && line_scratch)
     return LaunchPassXLineFinalize(in32, sdf, minmax_enc, line_scratch, p, stream);
+  if (variant == EdtVariant::kSweep && line_scratch)
+    return LaunchPassXSweepFinalize(in32, sdf, minmax_enc, line_scratch, p, stream);
   if (variant != EdtVariant::kBruteForce)
   {
     bool handled = false;

@@ -209,9 +209,19 @@ struct SdfWorkspace
   size_t bytes;
 };
 
-// with_line_scratch: only the line-sweep cross-check variant (3) keeps its stacks in the workspace
-SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, bool with_line_scratch = false)
+// Scratch beyond the default workspace that a variant keeps there (stacks of the line-sweep variants 3 and 4).
+size_t VariantScratchBytes(vgt::EdtVariant variant, int64_t nx, int64_t ny, int64_t nz)
 {
+  if (variant == vgt::EdtVariant::kLine) return vgt::LinePassScratchBytes(nx, ny, nz);
+  if (variant == vgt::EdtVariant::kSweep) return vgt::SweepPassScratchBytes(nx, ny, nz);
+  return 0;
+}
+
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz,
+                            vgt::EdtVariant variant = vgt::EdtVariant::kDefault)
+{
+  const size_t scratch_bytes = VariantScratchBytes(variant, nx, ny, nz);
+  const bool with_line_scratch = scratch_bytes != 0;
   SdfWorkspace ws;
   const size_t n = static_cast<size_t>(nx * ny * nz);
   size_t off = 0;
@@ -225,7 +235,7 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, bool
   if (with_line_scratch)
   {
     ws.line_scratch = static_cast<char*>(base) + off;
-    off = AlignUp(off + vgt::LinePassScratchBytes(nx, ny, nz), 256);
+    off = AlignUp(off + scratch_bytes, 256);
   }
   ws.bytes = off;
   return ws;
@@ -257,7 +267,7 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
 {
   // the line-sweep cross-check variant keeps its stacks in the workspace; a workspace without that
   // part (vgt_hip_sdf_workspace_bytes) runs the default passes instead
-  SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant == vgt::EdtVariant::kLine);
+  SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant);
   if (ws.line_scratch && workspace_bytes < ws.bytes) ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
@@ -696,7 +706,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 3 || variant == 2)  // 2 is not a variant
+  if (!ctx || variant < 0 || variant > 4 || variant == 2)  // 2 is not a variant
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
@@ -1082,7 +1092,7 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  return CarveWorkspace(nullptr, nx, ny, nz, variant == static_cast<int>(vgt::EdtVariant::kLine)).bytes;
+  return CarveWorkspace(nullptr, nx, ny, nz, static_cast<vgt::EdtVariant>(variant)).bytes;
 }
 
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,

@@ -54,8 +54,9 @@ struct SlabLineCarry
 
 // kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
 // straight from HBM (also the fallback for axes the tiled kernels do not cover); kLine: line sweep
-// with stacks in the workspace.  All exact; 1 and 3 exist for cross-checking.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kLine = 3 };
+// with stacks in the workspace; kSweep: lane-per-line sweep with the stack tops in LDS (edt_sweep_kernels.hip).
+// All exact; 1 and 3 exist for cross-checking.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kLine = 3, kSweep = 4 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -89,6 +90,8 @@ hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_
                                         hipStream_t stream, bool* handled);
 // Scratch for the line-sweep passes (edt_line_kernels.hip).
 size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
+// Scratch for the lane-per-line sweep passes (edt_sweep_kernels.hip): spilled stack entries + sign words.
+size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
 hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
 
