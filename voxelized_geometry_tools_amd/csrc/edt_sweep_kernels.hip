@@ -34,7 +34,10 @@ namespace vgt
 {
 namespace
 {
-constexpr int kBand = 32;        // rows held in registers at a time
+#ifndef VGT_SWEEP_BAND
+#define VGT_SWEEP_BAND 32
+#endif
+constexpr int kBand = VGT_SWEEP_BAND;  // rows held in registers at a time (one sign word per band)
 constexpr int kRing = 32;        // stack entries per lane resident in LDS
 constexpr int kChunk = 8;        // entries per spill / refill
 constexpr int kFar = 32768;      // "no row of the other class": kFar^2 is above every real squared distance
@@ -117,62 +120,96 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [1, 32]
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
 }
 
-// Magnitude of an input row value: squared distance so far, kInf32 when the row is no site.
-__device__ __forceinline__ int32_t Magnitude(int16_t v)
+// float(sqrt(double(d2)) * resolution) for 1 <= d2 < 2^31 by the fast evaluation of SqrtTimesResolution
+// (edt_device.hpp), without its guards: `unsure` says that the product lies so close to the midpoint of two floats
+// that only the exact evaluation can decide (2^-15 of all values); the caller also takes the exact evaluation for
+// resolutions outside (1e-30, 1e30).
+__device__ __forceinline__ float FastSqrtTimesResolution(uint32_t d2, double resolution, bool& unsure)
 {
-  const int32_t a = v < 0 ? -static_cast<int32_t>(v) : static_cast<int32_t>(v);
-  return (a == kInf16) ? kInf32 : __mul24(a, a);
+  const float xf = static_cast<float>(d2);
+  const float y0 = __frsqrt_rn(xf);
+  const double gd = static_cast<double>(xf * y0);
+  const double hd = static_cast<double>(0.5f * y0);
+  const double rem = fma(-gd, gd, static_cast<double>(d2));
+  const double p = fma(rem, hd, gd) * resolution;
+  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p)) & 0x1fffffffu;
+  unsure = (low - (0x10000000u - 8191u)) < 16383u;
+  return static_cast<float>(p);
 }
-__device__ __forceinline__ int32_t Magnitude(int32_t v) { return v < 0 ? -v : v; }
 
-template <typename InT, typename OutT, bool kFinal, bool kPacked>
-__global__ __launch_bounds__(kWaveSize, 4) void SweepPassKernel(const InT* __restrict__ in, OutT* __restrict__ out,
-                                                            typename Codec<kPacked>::Entry* __restrict__ spill,
-                                                            uint2* __restrict__ band_info,
-                                                            uint32_t* __restrict__ minmax_enc, const SweepGeom g)
+#ifndef VGT_SWEEP_WAVES
+#define VGT_SWEEP_WAVES 4
+#endif
+// kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
+template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
+__global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
+                                                                            OutT* __restrict__ out,
+                                                                            unsigned char* __restrict__ spill,
+                                                                            uint2* __restrict__ band_info,
+                                                                            uint32_t* __restrict__ minmax_enc,
+                                                                            const SweepGeom g)
 {
   using C = Codec<kPacked>;
   using Entry = typename C::Entry;
   constexpr int32_t kLimit = C::kSentinelG;  // values at or above: no site
-  constexpr InT kNoRow = static_cast<InT>(sizeof(InT) == 2 ? kInf16 : kInf32);
+  constexpr int kEntryBytes = static_cast<int>(sizeof(Entry));
+  constexpr int kShift = kPacked ? 8 : 9;                   // log2(bytes of one ring slot = 64 lanes x entry)
+  constexpr uint32_t kSlot = 1u << kShift;
+  constexpr uint32_t kRingMask = (kRing - 1) << kShift;     // slot bits of a ring byte address
+  constexpr int kChunkBytes = kChunk * kEntryBytes;
+  constexpr uint32_t kChunkSlots = static_cast<uint32_t>(kChunk) << kShift;
   __shared__ Entry ring[kRing * kWaveSize];
+  unsigned char* const ring_bytes = reinterpret_cast<unsigned char*>(ring);
 
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
   const int outer = item / g.zsegs;
-  const int z = (item - outer * g.zsegs) * kWaveSize + lane;
-  const bool live = z < g.nz;
+  const int z0 = (item - outer * g.zsegs) * kWaveSize;
+  // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
+  const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
   const int n = g.n;
   const int nbands = g.nbands;
   const int64_t rstride = g.row_stride;
-  const int64_t base = static_cast<int64_t>(outer) * g.outer_stride + z;
-  Entry* const my_spill = spill + (static_cast<int64_t>(item) * g.chunks * kWaveSize + lane) * kChunk;
-  uint2* const my_info = band_info + static_cast<int64_t>(item) * nbands * kWaveSize + lane;
-  constexpr int64_t kChunkStride = static_cast<int64_t>(kWaveSize) * kChunk;  // entries between chunks of a lane
+  const InT* const wave_in = in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
+  OutT* const wave_out = out + (static_cast<int64_t>(outer) * g.outer_stride + z0);
+  unsigned char* const wave_spill = spill + static_cast<int64_t>(item) * g.chunks * (kWaveSize * kChunkBytes);
+  uint2* const wave_info = band_info + static_cast<int64_t>(item) * nbands * kWaveSize;
+  const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
+  const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
 
-  // ---- stack state: entries [0, depth); [0, lo) live in the spill buffer, [lo, depth) in the ring ----
-  int depth = 3, lo = 0;
-  int32_t Gt = C::kSentinelG, Gs = C::kSentinelG + 1, G3 = 0;  // top, second, third
-  int rt = 0, rsec = 0, r3 = 0;
-  int A = 0;        // rt - rsec
-  int32_t nB = 1;   // Gs - Gt
-  ring[0 * kWaveSize + lane] = C::Pack(0, 0);  // never looked at: keeps "third" inside the stack
-  ring[1 * kWaveSize + lane] = C::Pack(C::kSentinelG + 1, 0);
-  ring[2 * kWaveSize + lane] = C::Pack(C::kSentinelG, 0);
+  // ---- stack state.  Entries [0, depth): [0, lo) live in the spill buffer, [lo, depth) in the ring (slot = index
+  // mod 32).  D and L are depth and lo times the slot size, so that (D & kRingMask) | lane_entry is the ring address of
+  // entry `depth` and L + lane_chunk the spill address of the chunk that starts at entry `lo`.  Registers hold the top
+  // (Gt, rt), the second entry as differences to the top (A = rt - rs >= 0, nB = Gs - Gt) and the third as it came
+  // from the ring (e3, decoded when it moves up): a pop is a few additions and only waits for the ring when it is
+  // the second pop in a row. ----
+  uint32_t D = 3u << kShift, L = 0;
+  int32_t Gt = C::kSentinelG, nB = 1;
+  int rt = 0, A = 0;
+  Entry e3 = C::Pack(0, 0);
+  auto ring_ref = [&](uint32_t scaled_index) -> Entry& {
+    return *reinterpret_cast<Entry*>(ring_bytes + ((scaled_index & kRingMask) | lane_entry));
+  };
+  ring_ref(0u << kShift) = C::Pack(0, 0);  // never looked at: keeps "third" inside the stack
+  ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 1, 0);
+  ring_ref(2u << kShift) = C::Pack(C::kSentinelG, 0);
 
-  auto ring_at = [&](int index) -> Entry& { return ring[((index & (kRing - 1)) << 6) + lane]; };
-  auto store_chunk = [&](int first) {
-    Entry buf[kChunk];
-#pragma unroll
-    for (int j = 0; j < kChunk; j++) buf[j] = ring_at(first + j);
-    C::StoreChunk(my_spill + static_cast<int64_t>(first >> 3) * kChunkStride, buf);
+  // the chunk that ends below entry lo comes back from the spill buffer (slow path: a run of pops reached it)
+  auto refill_now = [&]() {
+    L -= kChunkSlots;
+    const Entry* src = reinterpret_cast<const Entry*>(wave_spill + (L + lane_chunk));
+#pragma unroll 1
+    for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = src[j];
   };
-  auto load_chunk = [&](int first, Entry (&buf)[kChunk]) {
-    C::LoadChunk(my_spill + static_cast<int64_t>(first >> 3) * kChunkStride, buf);
-  };
-  auto commit_chunk = [&](int first, const Entry (&buf)[kChunk]) {
-#pragma unroll
-    for (int j = 0; j < kChunk; j++) ring_at(first + j) = buf[j];
+  // top <- second <- third <- ring (two sentinels above entry 0 are never popped, so the third always exists)
+  auto pop = [&]() {
+    Gt += nB;
+    rt -= A;
+    A = rt - C::Row(e3);
+    nB = C::G(e3) - Gt;
+    D -= kSlot;
+    if (D - 3 * kSlot < L) refill_now();
+    e3 = ring_ref(D - 3 * kSlot);
   };
 
   // =====================================================================================================
@@ -180,98 +217,96 @@ __global__ __launch_bounds__(kWaveSize, 4) void SweepPassKernel(const InT* __res
   // =====================================================================================================
   uint32_t any_transition = 0;
   {
-    auto load_row = [&](int q) -> InT { return (live && q < n) ? in[base + static_cast<int64_t>(q) * rstride] : kNoRow; };
-    auto pop = [&]() {
-      depth--;
-      Gt = Gs;
-      rt = rsec;
-      Gs = G3;
-      rsec = r3;
-      const int index = depth - 3;
-      if (index < lo)
-      {
-        // the entry that becomes the third one is in the spill buffer: bring its chunk back (rare: a long run of pops)
-        Entry buf[kChunk];
-        lo -= kChunk;
-        load_chunk(lo, buf);
-        commit_chunk(lo, buf);
-      }
-      const Entry e = ring_at(index);
-      G3 = C::G(e);
-      r3 = C::Row(e);
-      A = rt - rsec;
-      nB = Gs - Gt;
-    };
-
-    InT nxt[kBand];
+    const InT* row_in = wave_in;  // first row of the band being loaded
+    auto load_band = [&](int32_t (&dst)[kBand], int first_row) {
+      // rows past the end repeat the last row (not used)
 #pragma unroll
-    for (int k = 0; k < kBand; k++) nxt[k] = load_row(k);
+      for (int k = 0; k < kBand; k++)
+      {
+        const int64_t row = min(first_row + k, n - 1);
+        dst[k] = static_cast<int32_t>((wave_in + row * rstride)[zl]);
+      }
+    };
+    (void)row_in;
+    int32_t nxt[kBand];
+    load_band(nxt, 0);
     int din = kFar;          // distance from the row below this band to the nearest row of the other class below it
     uint32_t prev_bit = 0;   // class of the row below this band
     const int32_t n2m = 2 * (n - 1);
     for (int b = 0; b < nbands; b++)
     {
-      InT cur[kBand];
+      int32_t cur[kBand];
 #pragma unroll
       for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
-      if (b + 1 < nbands)
-      {
-#pragma unroll
-        for (int k = 0; k < kBand; k++) nxt[k] = load_row((b + 1) * kBand + k);
-      }
+      if (b + 1 < nbands) load_band(nxt, (b + 1) * kBand);
       uint32_t sw = 0;
       const int r0 = b * kBand;
+      const int valid = min(kBand, n - r0);
+      auto rows = [&](auto guarded) {
+        constexpr bool kGuard = decltype(guarded)::value;
 #pragma unroll
-      for (int k = 0; k < kBand; k++)
-      {
-        if (k % 16 == 0)
+        for (int k = 0; k < kBand; k++)
         {
-          // at most 16 pushes until the next check: make room for them
-          while (__any(depth - lo > kRing - 16))
+          if (k % 16 == 0)
           {
-            if (depth - lo > kRing - 16)
+            // at most 16 pushes until the next check: make room for them
+            while (__any(D - L > static_cast<uint32_t>(kRing - 16) << kShift))
             {
-              store_chunk(lo);
-              lo += kChunk;
+              if (D - L > static_cast<uint32_t>(kRing - 16) << kShift)
+              {
+                Entry buf[kChunk];
+#pragma unroll
+                for (int j = 0; j < kChunk; j++) buf[j] = ring_ref(L + (static_cast<uint32_t>(j) << kShift));
+                C::StoreChunk(reinterpret_cast<Entry*>(wave_spill + (L + lane_chunk)), buf);
+                L += kChunkSlots;
+              }
+            }
+          }
+          if (!kGuard || k < valid)
+          {
+            const int q = r0 + k;
+            const int32_t v = cur[k];
+            const int32_t sign = v >> 31;
+            sw |= static_cast<uint32_t>(sign) & (1u << k);
+            int32_t f = (v ^ sign) - sign;
+            if constexpr (sizeof(InT) == 2) f = (f == kInf16) ? kInf32 : __mul24(f, f);
+            if (f < kLimit)
+            {
+              const int32_t G = f + q * q;
+              int32_t dG = G - Gt;
+              int dr = q - rt;
+              if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
+              {
+                do
+                {
+                  pop();
+                  dG = G - Gt;
+                  dr = q - rt;
+                } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
+              }
+              if (dG < __mul24(n2m, dr))
+              {
+                ring_ref(D) = C::Pack(G, q);
+                e3 = C::Pack(Gt + nB, rt - A);
+                A = dr;
+                nB = -dG;
+                Gt = G;
+                rt = q;
+                D += kSlot;
+              }
             }
           }
         }
-        const int q = r0 + k;
-        const InT v = cur[k];
-        sw = (sw >> 1) | ((v < 0) ? 0x80000000u : 0u);
-        const int32_t f = Magnitude(v);
-        if (f < kLimit)
-        {
-          const int32_t G = f + __mul24(q, q);
-          int32_t dG = G - Gt;
-          int dr = q - rt;
-          while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
-          {
-            pop();
-            dG = G - Gt;
-            dr = q - rt;
-          }
-          if (dG < __mul24(n2m, dr))
-          {
-            ring_at(depth) = C::Pack(G, q);
-            G3 = Gs;
-            r3 = rsec;
-            Gs = Gt;
-            rsec = rt;
-            Gt = G;
-            rt = q;
-            A = dr;
-            nB = -dG;
-            depth++;
-          }
-        }
-      }
+      };
+      if (valid == kBand)
+        rows(std::false_type{});
+      else
+        rows(std::true_type{});
       // per band: sign word, distance carry for the evaluation's downward counters
-      const int valid = min(kBand, n - r0);
-      const uint32_t valid_mask = LowBits(valid);
-      uint32_t xdn = (sw ^ ((sw << 1) | prev_bit)) & valid_mask;  // bit k: row k differs from the row below it
+      uint32_t xdn = sw ^ ((sw << 1) | prev_bit);  // bit k: row k differs from the row below it (rows past the end: 0)
+      xdn &= LowBits(valid);
       if (b == 0) xdn &= ~1u;
-      if (live) my_info[static_cast<int64_t>(b) * kWaveSize] = make_uint2(sw, static_cast<uint32_t>(din));
+      (wave_info + static_cast<int64_t>(b) * kWaveSize)[lane] = make_uint2(sw, static_cast<uint32_t>(din));
       any_transition |= xdn;
       din = xdn ? (valid - (31 - __clz(static_cast<int>(xdn)))) : min(din + valid, kFar);
       prev_bit = (sw >> (valid - 1)) & 1u;
@@ -284,123 +319,161 @@ __global__ __launch_bounds__(kWaveSize, 4) void SweepPassKernel(const InT* __res
   const bool classes = __any(any_transition != 0u);
   float lo_value = INFINITY, hi_value = -INFINITY;
   {
-    int rt2 = 2 * rt;
-    Entry pf[kChunk];
-    bool pf_valid = false;
+    // Every 16 rows the chunks requested at the last boundary go into the ring and up to two more are requested
+    // when the ring has room (between two boundaries the ring only shrinks).
+    Entry pf0[kChunk], pf1[kChunk];
+    int pf_count = 0;
     auto refill_step = [&]() {
-      if (pf_valid)
+      if (pf_count > 0)
       {
-        lo -= kChunk;
-        commit_chunk(lo, pf);
-        pf_valid = false;
+        L -= kChunkSlots;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf0[j];
       }
-      if (lo > 0 && depth - lo <= kRing - kChunk - 4)
+      if (pf_count > 1)
       {
-        load_chunk(lo - kChunk, pf);
-        pf_valid = true;
+        L -= kChunkSlots;
+#pragma unroll
+        for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf1[j];
+      }
+      pf_count = 0;
+      const uint32_t resident = D - L;
+      if (L != 0 && resident <= static_cast<uint32_t>(kRing - kChunk) << kShift)
+      {
+        C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - kChunkSlots + lane_chunk)), pf0);
+        pf_count = 1;
+        if (L != kChunkSlots && resident <= static_cast<uint32_t>(kRing - 2 * kChunk) << kShift)
+        {
+          C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - 2 * kChunkSlots + lane_chunk)), pf1);
+          pf_count = 2;
+        }
       }
     };
-    auto pop = [&]() {
-      depth--;
-      Gt = Gs;
-      rt = rsec;
-      rt2 = 2 * rt;
-      Gs = G3;
-      rsec = r3;
-      const int index = depth - 3;
-      if (index < lo)
+    auto pop_eval = [&]() {
+      Gt += nB;
+      rt -= A;
+      A = rt - C::Row(e3);
+      nB = C::G(e3) - Gt;
+      D -= kSlot;
+      if (D - 3 * kSlot < L)
       {
-        if (!pf_valid) load_chunk(lo - kChunk, pf);
-        lo -= kChunk;
-        commit_chunk(lo, pf);
-        pf_valid = false;
+        refill_now();  // (prefetches of the same chunks that are still in flight are dropped)
+        pf_count = 0;
       }
-      const Entry e = ring_at(index);
-      G3 = C::G(e);
-      r3 = C::Row(e);
-      A = rt - rsec;
-      nB = Gs - Gt;
+      e3 = ring_ref(D - 3 * kSlot);
     };
 
-    auto run = [&](auto with_classes) {
-      constexpr bool kClasses = decltype(with_classes)::value;
-      int dn = kFar;             // distance from the row above the current one to ... (running, see below)
-      uint32_t above_bit0 = 0;   // class of the first row of the band above
-      uint2 next_info = make_uint2(0u, 0u);
-      if (live) next_info = my_info[static_cast<int64_t>(nbands - 1) * kWaveSize];
-      for (int b = nbands - 1; b >= 0; b--)
+    int dn = kFar;             // distance from the row above the current one to the nearest row of the other class above
+    uint32_t above_bit0 = 0;   // class of the first row of the band above
+    // sign words: this band's and the next lower band's are in registers, the one below that is on its way
+    uint2 info = (wave_info + static_cast<int64_t>(nbands - 1) * kWaveSize)[lane];
+    uint2 info_below = make_uint2(0u, 0u);
+    if (nbands > 1) info_below = (wave_info + static_cast<int64_t>(nbands - 2) * kWaveSize)[lane];
+    OutT* row_out = wave_out + static_cast<int64_t>(n - 1) * rstride;  // row being evaluated
+    for (int b = nbands - 1; b >= 0; b--)
+    {
+      uint2 info_next = make_uint2(0u, 0u);
+      if (b > 1) info_next = (wave_info + static_cast<int64_t>(b - 2) * kWaveSize)[lane];
+      const uint32_t sw = info.x;
+      const int r0 = b * kBand;
+      const int valid = min(kBand, n - r0);
+      int dp[kBand];
+      uint32_t xup = 0;
+      if (classes)
       {
-        const uint2 info = next_info;
-        if (b > 0 && live) next_info = my_info[static_cast<int64_t>(b - 1) * kWaveSize];
-        const uint32_t sw = info.x;
-        const int r0 = b * kBand;
-        const int valid = min(kBand, n - r0);
-        [[maybe_unused]] int dp[kBand];
-        [[maybe_unused]] uint32_t xup = 0;
-        if constexpr (kClasses)
-        {
-          const uint32_t prev_bit = (b > 0) ? (next_info.x >> 31) : (sw & 1u);
-          const uint32_t xdn = sw ^ ((sw << 1) | prev_bit);   // bit k: row k differs from the row below it
-          xup = sw ^ ((sw >> 1) | (above_bit0 << 31));        // bit k: row k differs from the row above it
-          if (b == nbands - 1) xup &= ~(1u << (valid - 1));   // nothing above the last row
-          int d = static_cast<int>(info.y);
+        const uint32_t prev_bit = (b > 0) ? ((info_below.x >> (kBand - 1)) & 1u) : (sw & 1u);
+        const uint32_t xdn = sw ^ ((sw << 1) | prev_bit);            // bit k: row k differs from the row below it
+        xup = sw ^ ((sw >> 1) | (above_bit0 << (kBand - 1)));        // bit k: row k differs from the row above it
+        if (b == nbands - 1) xup &= ~(1u << (valid - 1));            // nothing above the last row
+        int d = static_cast<int>(info.y);
 #pragma unroll
-          for (int k = 0; k < kBand; k++)
-          {
-            d = ((xdn >> k) & 1u) ? 1 : d + 1;
-            dp[k] = d;
-          }
+        for (int k = 0; k < kBand; k++)
+        {
+          d = ((xdn >> k) & 1u) ? 1 : d + 1;
+          dp[k] = d;
         }
+      }
+      auto rows = [&](auto guarded) {
+        constexpr bool kGuard = decltype(guarded)::value;
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
-          if (k < valid)
+          if (k % 16 == 15) refill_step();
+          if (!kGuard || k < valid)
           {
-            if (k % 16 == 15) refill_step();
             const int q = r0 + k;
             const int q2 = 2 * q;
-            while (__mul24(A, q2) + nB <= 0) pop();
-            uint32_t best = static_cast<uint32_t>(Gt + __mul24(q - rt2, q));
-            if constexpr (kClasses)
+            // the second member is at least as good at row q: the top owns nothing at or below q
+            if (__mul24(A, q2) + nB <= 0)
+            {
+              do pop_eval();
+              while (__mul24(A, q2) + nB <= 0);
+            }
+            // value of the top at q: Gt + q^2 - 2 q rt
+            uint32_t best = static_cast<uint32_t>(__mul24(rt, -q2) + Gt + q * q);
+            if (classes)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
               const uint32_t dm = static_cast<uint32_t>(min(dp[k], dn));
               best = min(best, dm * dm);
             }
-            const bool neg = (sw >> k) & 1u;
-            const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
-            if (live)
+            const int32_t sign = __builtin_amdgcn_sbfe(static_cast<int32_t>(sw), k, 1);  // -1 on the negative class
+            if constexpr (kFinal)
             {
-              const int64_t idx = base + static_cast<int64_t>(q) * rstride;
-              if constexpr (kFinal)
+              uint32_t d2 = best;
+              bool exact = false;
+              if constexpr (!kPlain)
               {
-                int32_t clamped = d2;
-                if (g.add_virtual_border)
+                if (g.add_virtual_border && d2 < static_cast<uint32_t>(kLimit))
                 {
                   const int x = (g.pass_axis == 0) ? q : outer + g.outer_begin;
                   const int y = (g.pass_axis == 0) ? outer + g.outer_begin : q;
-                  clamped = ClampToVirtualBorder(d2, x, y, z + g.z_offset, g.nx, g.ny, g.nz_global);
+                  d2 = static_cast<uint32_t>(ClampToVirtualBorder(static_cast<int32_t>(d2), x, y,
+                                                                  z0 + static_cast<int>(zl) + g.z_offset, g.nx, g.ny,
+                                                                  g.nz_global));
                 }
-                const float value = DistanceToSdf(clamped, neg, g.resolution);
-                out[idx] = value;
-                asm("v_min_f32 %0, %0, %1" : "+v"(lo_value) : "v"(value));
-                asm("v_max_f32 %0, %0, %1" : "+v"(hi_value) : "v"(value));
+                else if (g.add_virtual_border)
+                {
+                  // no site at all: the border alone
+                  d2 = static_cast<uint32_t>(ClampToVirtualBorder(kInf32, (g.pass_axis == 0) ? q : outer + g.outer_begin,
+                                                                  (g.pass_axis == 0) ? outer + g.outer_begin : q,
+                                                                  z0 + static_cast<int>(zl) + g.z_offset, g.nx, g.ny,
+                                                                  g.nz_global));
+                  if (d2 == static_cast<uint32_t>(kInf32)) d2 = static_cast<uint32_t>(kLimit);
+                }
+                exact = !(g.resolution > 1.0e-30 && g.resolution < 1.0e30);
               }
-              else
+              bool unsure;
+              float dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
+              if (__builtin_amdgcn_ballot_w64(unsure || exact) != 0ull)
               {
-                out[idx] = neg ? -d2 : d2;
+                asm volatile("; exact final conversion (rare)");  // keeps the block out of the straight-line code
+                if (unsure || exact) dist = SqrtTimesResolutionExact(static_cast<int32_t>(d2), g.resolution);
               }
+              dist = (d2 >= static_cast<uint32_t>(kLimit)) ? __uint_as_float(0x7f800000u) : dist;
+              const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
+              row_out[zl] = value;
+              asm("v_min_f32 %0, %0, %1" : "+v"(lo_value) : "v"(value));
+              asm("v_max_f32 %0, %0, %1" : "+v"(hi_value) : "v"(value));
             }
+            else
+            {
+              const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
+              row_out[zl] = (d2 ^ sign) - sign;
+            }
+            row_out -= rstride;
           }
         }
-        above_bit0 = sw & 1u;
-        if constexpr (kClasses) dn = min(dn, kFar);
-      }
-    };
-    if (classes)
-      run(std::true_type{});
-    else
-      run(std::false_type{});
+      };
+      if (valid == kBand)
+        rows(std::false_type{});
+      else
+        rows(std::true_type{});
+      above_bit0 = sw & 1u;
+      if (classes) dn = min(dn, kFar);
+      info = info_below;
+      info_below = info_next;
+    }
   }
   if constexpr (kFinal)
   {
@@ -433,12 +506,21 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
   const int64_t rows = g.n - 1;
   const bool packed = (g.n <= 1024) && (max_input + rows * rows < Codec<true>::kSentinelG);
   const dim3 grid(static_cast<unsigned>(items)), block(kWaveSize);
-  if (packed)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true>), grid, block, 0, stream, in, out,
-                       reinterpret_cast<uint32_t*>(bytes), info, minmax_enc, g);
+  unsigned char* spill = reinterpret_cast<unsigned char*>(bytes);
+  // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
+  const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
+  if (packed && general)
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, 0, stream, in, out, spill, info,
+                       minmax_enc, g);
+  else if (packed)
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, 0, stream, in, out, spill, info,
+                       minmax_enc, g);
+  else if (general)
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, 0, stream, in, out, spill, info,
+                       minmax_enc, g);
   else
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false>), grid, block, 0, stream, in, out,
-                       reinterpret_cast<uint2*>(bytes), info, minmax_enc, g);
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, 0, stream, in, out, spill, info,
+                       minmax_enc, g);
   return hipGetLastError();
 }
 
