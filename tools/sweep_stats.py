@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Event counts of the sweep passes (EDT variant 4) from a diagnostic build:
+   make -C voxelized_geometry_tools_amd/csrc OBJDIR=sstats OUT=../libvgt_hip_sstats.so HIPFLAGS="... -DVGT_SWEEP_STATS"
+   VGT_HIP_LIB=.../libvgt_hip_sstats.so python tools/sweep_stats.py [size] [dist]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+from voxelized_geometry_tools_amd import capi
+
+NAMES = ["lane refills sweep1", "wave refill events sweep1", "lane refills sweep2", "wave refill events sweep2",
+         "spilled chunks (lanes)", "wave spill events", "exact conversions (wave events)", "-", "-",
+         "waves with class changes", "waves"]
+
+
+def main():
+    size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    dist = sys.argv[2] if len(sys.argv) > 2 else "spheres"
+    shape = (size, size, size)
+    dev = torch.device("cuda", 0)
+    ctx = capi.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_edt_variant(4)
+    occ = bench.device_occupancy(torch, shape, dist, 42, dev)
+    sdf = torch.empty(shape, dtype=torch.float32, device=dev)
+    nbytes = capi.sdf_workspace_bytes(shape, 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    mm = torch.empty(2, dtype=torch.float32, device=dev)
+    lib = capi.load()
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.vgt_hip_debug_sweep_stats(buf, 1)
+    ctx.sdf_dev(occ.data_ptr(), shape, 0.01, sdf.data_ptr(), ws.data_ptr(), nbytes, mm.data_ptr(), True, False)
+    torch.cuda.synchronize()
+    lib.vgt_hip_debug_sweep_stats(buf, 1)
+    rows = size * size * size / 64.0
+    for base, name in ((0, "Y"), (16, "X")):
+        print(name, "pass: wave-rows", rows)
+        for i, label in enumerate(NAMES):
+            if label != "-":
+                print("   %-34s %12d   per wave-row %.4f" % (label, buf[base + i], buf[base + i] / rows))
+
+
+if __name__ == "__main__":
+    main()

@@ -137,8 +137,20 @@ __device__ __forceinline__ float FastSqrtTimesResolution(uint32_t d2, double res
   return static_cast<float>(p);
 }
 
+#ifndef VGT_SWEEP_PF
+#define VGT_SWEEP_PF 8
+#endif
 #ifndef VGT_SWEEP_WAVES
 #define VGT_SWEEP_WAVES 4
+#endif
+#ifdef VGT_SWEEP_STATS
+// diagnostic build (make SWEEPSTATS=1): [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the
+// same in sweep 2, [4] spilled chunks (lanes), [5] wave-level spill events, [6] exact conversions (wave events),
+// [7] wave-rows with a pop in sweep 1, [8] in sweep 2, [9] waves with class changes, [10] waves
+__device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X pass
+#define VGT_SWEEP_COUNT(i, v) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + (i)], static_cast<unsigned long long>(v))
+#else
+#define VGT_SWEEP_COUNT(i, v)
 #endif
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
 template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
@@ -195,20 +207,41 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   ring_ref(2u << kShift) = C::Pack(C::kSentinelG, 0);
 
   // the chunk that ends below entry lo comes back from the spill buffer (slow path: a run of pops reached it)
+  [[maybe_unused]] int stat_phase = 0;
   auto refill_now = [&]() {
+#ifdef VGT_SWEEP_STATS
+    VGT_SWEEP_COUNT(stat_phase, 1);
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 || true)
+    {
+      const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1)) VGT_SWEEP_COUNT(stat_phase + 1, 1);
+    }
+#endif
     L -= kChunkSlots;
     const Entry* src = reinterpret_cast<const Entry*>(wave_spill + (L + lane_chunk));
 #pragma unroll 1
-    for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = src[j];
+    for (int j = 0; j < kChunk; j += 2)
+    {
+      const Entry a = src[j], b = src[j + 1];
+      ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = a;
+      ring_ref(L + (static_cast<uint32_t>(j + 1) << kShift)) = b;
+    }
   };
   // top <- second <- third <- ring (two sentinels above entry 0 are never popped, so the third always exists)
+  // chunks requested from the spill buffer at the last boundary (a refill_now of the same chunk drops them)
+  Entry pf0[kChunk], pf1[kChunk];
+  int pf_count = 0;
   auto pop = [&]() {
     Gt += nB;
     rt -= A;
     A = rt - C::Row(e3);
     nB = C::G(e3) - Gt;
     D -= kSlot;
-    if (D - 3 * kSlot < L) refill_now();
+    if (D - 3 * kSlot < L)
+    {
+      refill_now();
+      pf_count = 0;
+    }
     e3 = ring_ref(D - 3 * kSlot);
   };
 
@@ -247,18 +280,34 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          if (k % 16 == 0)
+          if (k % 8 == 0)
           {
-            // at most 16 pushes until the next check: make room for them
-            while (__any(D - L > static_cast<uint32_t>(kRing - 16) << kShift))
+            // a chunk requested at the last boundary goes into the ring (the ring had at most 8 entries then and has
+            // taken at most 8 more)
+            if (pf_count > 0)
             {
-              if (D - L > static_cast<uint32_t>(kRing - 16) << kShift)
+              L -= kChunkSlots;
+#pragma unroll
+              for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf0[j];
+              pf_count = 0;
+            }
+            // a ring that pops have nearly emptied asks for the chunk below it before a pop has to wait for it
+            if (L != 0 && D - L <= static_cast<uint32_t>(VGT_SWEEP_PF) << kShift)
+            {
+              C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - kChunkSlots + lane_chunk)), pf0);
+              pf_count = 1;
+            }
+            // at most 8 pushes until the next check: make room for them
+            while (__any(D - L > static_cast<uint32_t>(kRing - 8) << kShift))
+            {
+              if (D - L > static_cast<uint32_t>(kRing - 8) << kShift)
               {
                 Entry buf[kChunk];
 #pragma unroll
                 for (int j = 0; j < kChunk; j++) buf[j] = ring_ref(L + (static_cast<uint32_t>(j) << kShift));
                 C::StoreChunk(reinterpret_cast<Entry*>(wave_spill + (L + lane_chunk)), buf);
                 L += kChunkSlots;
+                VGT_SWEEP_COUNT(4, 1);
               }
             }
           }
@@ -317,12 +366,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Sweep 2: evaluate, last row first.
   // =====================================================================================================
   const bool classes = __any(any_transition != 0u);
+#ifdef VGT_SWEEP_STATS
+  stat_phase = 2;
+  if (lane == 0) { VGT_SWEEP_COUNT(10, 1); VGT_SWEEP_COUNT(9, classes ? 1 : 0); }
+#endif
   float lo_value = INFINITY, hi_value = -INFINITY;
   {
     // Every 16 rows the chunks requested at the last boundary go into the ring and up to two more are requested
     // when the ring has room (between two boundaries the ring only shrinks).
-    Entry pf0[kChunk], pf1[kChunk];
-    int pf_count = 0;
+    pf_count = 0;  // (sweep 1 may leave a request behind: dropped)
     auto refill_step = [&]() {
       if (pf_count > 0)
       {
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             // the second member is at least as good at row q: the top owns nothing at or below q
             if (__mul24(A, q2) + nB <= 0)
             {
-              do pop_eval();
+              do pop();
               while (__mul24(A, q2) + nB <= 0);
             }
             // value of the top at q: Gt + q^2 - 2 q rt
@@ -448,6 +500,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               if (__builtin_amdgcn_ballot_w64(unsure || exact) != 0ull)
               {
                 asm volatile("; exact final conversion (rare)");  // keeps the block out of the straight-line code
+#ifdef VGT_SWEEP_STATS
+                if (lane == 0) VGT_SWEEP_COUNT(6, 1);
+#endif
                 if (unsure || exact) dist = SqrtTimesResolutionExact(static_cast<int32_t>(d2), g.resolution);
               }
               dist = (d2 >= static_cast<uint32_t>(kLimit)) ? __uint_as_float(0x7f800000u) : dist;
@@ -586,3 +641,17 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
   return LaunchSweep<int32_t, float, true>(in32, sdf, scratch, minmax_enc, g, outer_count, max_input, stream);
 }
 }  // namespace vgt
+
+#ifdef VGT_SWEEP_STATS
+extern "C" int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
+{
+  hipError_t err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_sweep_stats), 32 * sizeof(unsigned long long));
+  if (err == hipSuccess && reset)
+  {
+    unsigned long long zeros[32] = {0};
+    err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_stats), zeros, sizeof(zeros));
+  }
+  return err == hipSuccess ? 0 : 2;
+}
+#endif
