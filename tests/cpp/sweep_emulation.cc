@@ -1,0 +1,231 @@
+// CPU check of the lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, EDT variant 4): the kernel source is compiled by
+// g++ against tests/cpp/hip_shim and run one lane at a time, on random lines, against a brute-force evaluation of
+//     out(q) = min( min_r (q-r)^2 + |F[r]|,  min over rows r of the other class (q-r)^2 ),
+// i.e. the per-line contract of the Y and X passes (edt_hull_kernels.hip header).  It exercises what the GPU parity tests
+// cannot reach cheaply: deep stacks (ring spills / refills in both sweeps), every ring / band size the kernel can be
+// built with (-DVGT_SWEEP_BAND / _RING / _CHUNK), packed and 64-bit entries, partial waves, partial bands, the virtual
+// border and the final conversion.  The GPU tests (tests/test_gpu_sdf.py) pin the same kernels to the oracle.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#define BlockMinMax BlockMinMaxOnDevice
+#include "../../voxelized_geometry_tools_amd/csrc/edt_device.hpp"
+#undef BlockMinMax
+namespace vgt
+{
+void SetLastError(const std::string&) {}
+inline void BlockMinMax(uint32_t lo, uint32_t hi, uint32_t* minmax_enc)
+{
+  minmax_enc[0] = std::min(minmax_enc[0], lo);
+  minmax_enc[1] = std::max(minmax_enc[1], hi);
+}
+}  // namespace vgt
+#include "../../voxelized_geometry_tools_amd/csrc/edt_sweep_kernels.hip"
+
+namespace
+{
+struct Case
+{
+  int nx, ny, nz;
+  int mode;      // value distribution
+  int p_site;    // percent of rows that are sites
+  int p_flip;    // percent chance of a class change per row
+  bool border;
+};
+
+int64_t BruteRow(const std::vector<int64_t>& f, const std::vector<uint8_t>& neg, int n, int q)
+{
+  int64_t best = INT64_MAX;
+  for (int r = 0; r < n; r++)
+  {
+    const int64_t d = static_cast<int64_t>(q - r) * (q - r);
+    if (f[r] >= 0) best = std::min(best, d + f[r]);
+    if (neg[r] != neg[q]) best = std::min(best, d);
+  }
+  return best;
+}
+
+int failures = 0;
+
+// Y-pass shaped run: lines along y of an [nx][ny][nz] grid, int16 input (signed Z distance), int32 output.
+void CheckY(const Case& c, std::mt19937& rng)
+{
+  const int nx = c.nx, ny = c.ny, nz = c.nz;
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  std::vector<int16_t> in(total);
+  for (int x = 0; x < nx; x++)
+    for (int z = 0; z < nz; z++)
+    {
+      int cls = rng() & 1;
+      for (int y = 0; y < ny; y++)
+      {
+        if (static_cast<int>(rng() % 100) < c.p_flip) cls ^= 1;
+        int d;
+        switch (c.mode)
+        {
+          case 0: d = 1 + rng() % 2; break;
+          case 1: d = 1 + rng() % std::max(1, nz - 1); break;
+          case 2: d = 1 + (std::abs(y - ny / 2) % std::max(1, nz - 1)); break;
+          default: d = 1; break;
+        }
+        d = std::min(d, std::max(1, nz - 1));
+        if (static_cast<int>(rng() % 100) >= c.p_site) d = vgt::kInf16;
+        in[(static_cast<int64_t>(x) * ny + y) * nz + z] = static_cast<int16_t>(cls ? -d : d);
+      }
+    }
+  std::vector<int32_t> out(total, 12345);
+  vgt::SdfParams p{};
+  p.nx = nx; p.ny = ny; p.nz = std::max(nz, 2);  // (max_input is derived from nz: keep it >= the largest distance used)
+  p.nz = nz;
+  p.resolution = 0.01;
+  std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
+  vgt::LaunchPassYSweep(in.data(), out.data(), scratch.data(), p, nullptr);
+  std::vector<int64_t> f(ny);
+  std::vector<uint8_t> neg(ny);
+  for (int x = 0; x < nx; x++)
+    for (int z = 0; z < nz; z++)
+    {
+      for (int y = 0; y < ny; y++)
+      {
+        const int v = in[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        neg[y] = v < 0;
+        const int a = std::abs(v);
+        f[y] = (a == vgt::kInf16) ? -1 : static_cast<int64_t>(a) * a;
+      }
+      for (int y = 0; y < ny; y++)
+      {
+        int64_t want = BruteRow(f, neg, ny, y);
+        want = (want == INT64_MAX) ? vgt::kInf32 : want;
+        const int64_t signed_want = neg[y] ? -want : want;
+        const int32_t got = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        if (got != signed_want)
+        {
+          if (failures++ < 10)
+            std::printf("Y MISMATCH shape %dx%dx%d mode %d line (x=%d,z=%d) row %d: got %d want %lld\n", nx, ny, nz, c.mode, x,
+                        z, y, got, static_cast<long long>(signed_want));
+        }
+      }
+    }
+}
+
+// X-pass shaped run: lines along x, int32 input (signed squared YZ distance), float output + extrema.
+void CheckX(const Case& c, std::mt19937& rng)
+{
+  const int nx = c.nx, ny = c.ny, nz = c.nz;
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  const int64_t max_f = static_cast<int64_t>(nz - 1) * (nz - 1) + static_cast<int64_t>(ny - 1) * (ny - 1);
+  std::vector<int32_t> in(total);
+  for (int y = 0; y < ny; y++)
+    for (int z = 0; z < nz; z++)
+    {
+      int cls = rng() & 1;
+      for (int x = 0; x < nx; x++)
+      {
+        if (static_cast<int>(rng() % 100) < c.p_flip) cls ^= 1;
+        int64_t v;
+        switch (c.mode)
+        {
+          case 0: v = 1 + rng() % 3; break;
+          case 1: v = 1 + rng() % std::max<int64_t>(1, max_f); break;
+          case 2: v = 1 + static_cast<int64_t>(x - nx / 2) * (x - nx / 2) % std::max<int64_t>(1, max_f); break;
+          case 3: v = std::max<int64_t>(1, max_f - static_cast<int64_t>(x) * x / 4); break;
+          default: v = 1; break;
+        }
+        v = std::min<int64_t>(std::max<int64_t>(v, 1), std::max<int64_t>(max_f, 1));
+        if (static_cast<int>(rng() % 100) >= c.p_site) v = vgt::kInf32;
+        in[(static_cast<int64_t>(x) * ny + y) * nz + z] = static_cast<int32_t>(cls ? -v : v);
+      }
+    }
+  std::vector<float> out(total, 12345.0f);
+  vgt::SdfParams p{};
+  p.nx = nx; p.ny = ny; p.nz = nz;
+  p.resolution = 0.37;
+  p.add_virtual_border = c.border ? 1 : 0;
+  std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
+  uint32_t minmax[2] = {0xffffffffu, 0u};
+  vgt::LaunchPassXSweepFinalize(in.data(), out.data(), minmax, scratch.data(), p, nullptr);
+  std::vector<int64_t> f(nx);
+  std::vector<uint8_t> neg(nx);
+  float lo = INFINITY, hi = -INFINITY;
+  for (int y = 0; y < ny; y++)
+    for (int z = 0; z < nz; z++)
+    {
+      for (int x = 0; x < nx; x++)
+      {
+        const int32_t v = in[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        neg[x] = v < 0;
+        const int64_t a = std::llabs(static_cast<long long>(v));
+        f[x] = (a == vgt::kInf32) ? -1 : a;
+      }
+      for (int x = 0; x < nx; x++)
+      {
+        int64_t d2 = BruteRow(f, neg, nx, x);
+        if (c.border)
+        {
+          int64_t b = INT64_MAX;
+          if (nx > 1) b = std::min<int64_t>(b, std::min(x + 1, nx - x));
+          if (ny > 1) b = std::min<int64_t>(b, std::min(y + 1, ny - y));
+          if (nz > 1) b = std::min<int64_t>(b, std::min(z + 1, nz - z));
+          if (b != INT64_MAX) d2 = std::min(d2, b * b);
+        }
+        float want = (d2 == INT64_MAX) ? INFINITY : static_cast<float>(std::sqrt(static_cast<double>(d2)) * p.resolution);
+        if (neg[x]) want = -want;
+        lo = std::min(lo, want);
+        hi = std::max(hi, want);
+        const float got = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        if (std::memcmp(&got, &want, 4) != 0)
+        {
+          if (failures++ < 10)
+            std::printf("X MISMATCH shape %dx%dx%d mode %d border %d line (y=%d,z=%d) row %d: got %g want %g\n", nx, ny, nz,
+                        c.mode, c.border, y, z, x, got, want);
+        }
+      }
+    }
+  const float got_lo = vgt::DecodeOrdered(minmax[0]), got_hi = vgt::DecodeOrdered(minmax[1]);
+  if (got_lo != lo || got_hi != hi)
+  {
+    if (failures++ < 10) std::printf("X EXTREMA shape %dx%dx%d: got (%g, %g) want (%g, %g)\n", nx, ny, nz, got_lo, got_hi, lo, hi);
+  }
+}
+}  // namespace
+
+int main(int argc, char** argv)
+{
+  const int rounds = argc > 1 ? std::atoi(argv[1]) : 1;
+  std::mt19937 rng(4242);
+  int cases = 0;
+  for (int round = 0; round < rounds; round++)
+  {
+    // {nx, ny, nz, mode, p_site, p_flip, border}
+    const Case y_cases[] = {
+        {2, 1, 3, 0, 100, 10, false},    {3, 2, 5, 0, 100, 50, false},   {2, 33, 7, 0, 100, 0, false},
+        {1, 300, 4, 0, 100, 0, false},   {2, 300, 3, 1, 100, 2, false},  {1, 1024, 2, 0, 100, 0, false},
+        {1, 1024, 70, 1, 30, 1, false},  {2, 700, 5, 2, 100, 0, false},  {1, 1500, 3, 0, 100, 1, false},
+        {1, 2050, 2, 3, 100, 0, false},  {3, 97, 66, 1, 60, 20, false},  {2, 64, 64, 0, 0, 5, false},
+        {1, 513, 3, 1, 5, 0, false},     {1, 999, 2, 0, 100, 100, false},
+    };
+    for (const Case& c : y_cases)
+    {
+      CheckY(c, rng);
+      cases++;
+    }
+    const Case x_cases[] = {
+        {1, 2, 3, 0, 100, 10, false},    {2, 3, 5, 0, 100, 50, true},    {33, 2, 7, 0, 100, 0, false},
+        {300, 1, 4, 0, 100, 0, false},   {300, 2, 3, 1, 100, 2, true},   {1024, 1, 2, 0, 100, 0, false},
+        {1024, 2, 67, 1, 30, 1, false},  {700, 2, 5, 2, 100, 0, true},   {1500, 1, 3, 0, 100, 1, false},
+        {2050, 1, 2, 3, 100, 0, false},  {97, 3, 66, 1, 60, 20, true},   {64, 2, 64, 0, 0, 5, false},
+        {513, 1, 3, 3, 100, 0, false},   {999, 1, 2, 0, 100, 100, true}, {1024, 3, 3, 3, 100, 0, false},
+        {64, 2, 64, 0, 0, 5, true},
+    };
+    for (const Case& c : x_cases)
+    {
+      CheckX(c, rng);
+      cases++;
+    }
+  }
+  std::printf("%d cases, %d mismatches (band %d, ring %d, chunk %d)\n", cases, failures, vgt::kBand, vgt::kRing, vgt::kChunk);
+  return failures ? 1 : 0;
+}

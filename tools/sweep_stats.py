@@ -14,8 +14,9 @@ import bench
 from voxelized_geometry_tools_amd import capi
 
 NAMES = ["lane refills sweep1", "wave refill events sweep1", "lane refills sweep2", "wave refill events sweep2",
-         "spilled chunks (lanes)", "wave spill events", "exact conversions (wave events)", "-", "-",
-         "waves with class changes", "waves"]
+         "spilled chunks (lanes)", "wave spill events", "exact conversions (wave events)", "wave pop iterations sweep1",
+         "wave pop iterations sweep2", "waves with class changes", "waves", "lane pops sweep1", "lane pops sweep2",
+         "lane pushes"]
 
 
 def main():

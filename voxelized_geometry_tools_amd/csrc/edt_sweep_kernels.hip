@@ -15,19 +15,25 @@
 //   * Two sentinel entries at row 0 with values above every real one sit at the bottom of every stack (a site
 //     T0 and, below it, V0 = (G(T0) + 1, row 0), which makes T0's own test come out false): the stack is never
 //     empty, no depth checks in the loops, and a line without any site evaluates to "no site" by itself.
-//   * The three topmost entries live in registers, so a pop never waits for memory unless it is the third in a
-//     row; the stack itself is a ring of 32 entries per lane in LDS ([slot][lane]: conflict-free whatever the
-//     lanes' depths), spilled to / refilled from a scratch buffer in chunks of 8 entries: 16-row boundaries check
-//     the ring once for the whole wave; the evaluation prefetches its next chunk one boundary ahead.
+//   * Registers hold the top, the second entry as differences to the top and the third entry as it came from the
+//     ring; the stack itself is a ring of kRing entries per lane in LDS ([slot][lane]: conflict-free whatever the
+//     lanes' depths), spilled to / refilled from a scratch buffer in chunks of kChunk entries.  The ring is checked
+//     once per kChunk rows for the whole wave (a lane-by-lane check would run on every row because SOME lane
+//     always needs it); chunks that will be needed soon are requested one check ahead.
 //   * Entries are 32-bit words (22 bits of G, 10 bits of row) when the host can bound G below 2^22 - 2 on lines of
 //     at most 1024 rows (both passes of a 1024^3 grid), otherwise 64-bit.
 //   * Sweep 2 walks the line backwards: the owner of a row is found by comparing the two topmost members at that
 //     row (values along the envelope are unimodal), (Gs - Gt) + 2 q (rt - rs) <= 0 pops.  The distances to the
-//     bounding rows of the other class are running counters (sign bits of the line: one word per 32 rows, kept in
-//     the scratch buffer between the sweeps); waves whose 64 lines hold one class only skip that part.
+//     bounding rows of the other class are running counters fed by the line's sign bits (one word per 32 rows, kept
+//     in the scratch buffer between the sweeps); waves whose 64 lines hold one class only skip that part.
 //   * X pass: fused sqrt / resolution / sign / virtual border / min-max as in the other variants.
+//
+// The kernels are bound by instruction issue and by the latency of their dependent chains, not by HBM: rows are
+// processed kBand at a time (registers), the code below keeps rare paths (refills, exact final conversion) out of
+// the straight-line code, and register and LDS use are sized for kWaves waves per SIMD.
 #include "edt_device.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace vgt
@@ -37,17 +43,31 @@ namespace
 #ifndef VGT_SWEEP_BAND
 #define VGT_SWEEP_BAND 32
 #endif
-constexpr int kBand = VGT_SWEEP_BAND;  // rows held in registers at a time (one sign word per band)
-constexpr int kRing = 32;        // stack entries per lane resident in LDS
-constexpr int kChunk = 8;        // entries per spill / refill
-constexpr int kFar = 32768;      // "no row of the other class": kFar^2 is above every real squared distance
+#ifndef VGT_SWEEP_RING
+#define VGT_SWEEP_RING 32
+#endif
+#ifndef VGT_SWEEP_CHUNK
+#define VGT_SWEEP_CHUNK 8
+#endif
+#ifndef VGT_SWEEP_WAVES
+#define VGT_SWEEP_WAVES 4
+#endif
+#ifndef VGT_SWEEP_EXP
+#define VGT_SWEEP_EXP 0
+#endif
+constexpr int kBand = VGT_SWEEP_BAND;    // rows held in registers at a time: 8, 16 or 32
+constexpr int kWord = 32;                // rows per sign word
+constexpr int kRing = VGT_SWEEP_RING;    // stack entries per lane resident in LDS (power of two)
+constexpr int kChunk = VGT_SWEEP_CHUNK;  // entries per spill / refill = rows between two checks of the ring
+constexpr int kFar = 32768;              // "no row of the other class": kFar^2 is above every real squared distance
+static_assert(kWord % kBand == 0 && kBand % kChunk == 0 && kRing >= 4 * kChunk && (kRing & (kRing - 1)) == 0, "sizes");
 
 struct SweepGeom
 {
   int n;                 // rows along the pass axis
   int nz;                // extent of the contiguous axis
   int zsegs;             // waves per outer index
-  int nbands;            // ceil(n / 32)
+  int nwords;            // ceil(n / 32)
   int chunks;            // spill chunks per lane
   int64_t row_stride;    // elements between consecutive rows
   int64_t outer_stride;  // elements between consecutive outer indices
@@ -72,18 +92,6 @@ struct Codec<true>
   }
   static __device__ __forceinline__ int32_t G(Entry e) { return static_cast<int32_t>(e >> 10); }
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e & 1023u); }
-  // a chunk of 8 entries <-> 32 contiguous bytes
-  static __device__ __forceinline__ void StoreChunk(Entry* dst, const Entry (&e)[8])
-  {
-    reinterpret_cast<uint4*>(dst)[0] = make_uint4(e[0], e[1], e[2], e[3]);
-    reinterpret_cast<uint4*>(dst)[1] = make_uint4(e[4], e[5], e[6], e[7]);
-  }
-  static __device__ __forceinline__ void LoadChunk(const Entry* src, Entry (&e)[8])
-  {
-    const uint4 a = reinterpret_cast<const uint4*>(src)[0], b = reinterpret_cast<const uint4*>(src)[1];
-    e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w;
-    e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
-  }
 };
 template <>
 struct Codec<false>
@@ -96,26 +104,45 @@ struct Codec<false>
   }
   static __device__ __forceinline__ int32_t G(Entry e) { return static_cast<int32_t>(e.x); }
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e.y); }
-  // a chunk of 8 entries <-> 64 contiguous bytes
-  static __device__ __forceinline__ void StoreChunk(Entry* dst, const Entry (&e)[8])
-  {
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y);
-  }
-  static __device__ __forceinline__ void LoadChunk(const Entry* src, Entry (&e)[8])
-  {
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      const uint4 a = reinterpret_cast<const uint4*>(src)[j];
-      e[2 * j] = make_uint2(a.x, a.y);
-      e[2 * j + 1] = make_uint2(a.z, a.w);
-    }
-  }
 };
 
-__device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [1, 32]
+// A chunk of kChunk entries <-> contiguous bytes of the spill buffer, as 16-byte accesses.
+__device__ __forceinline__ void StoreChunk(uint32_t* dst, const uint32_t (&e)[kChunk])
+{
+#pragma unroll
+  for (int j = 0; j < kChunk / 4; j++)
+    reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+}
+__device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[kChunk])
+{
+#pragma unroll
+  for (int j = 0; j < kChunk / 4; j++)
+  {
+    const uint4 a = reinterpret_cast<const uint4*>(src)[j];
+    e[4 * j] = a.x;
+    e[4 * j + 1] = a.y;
+    e[4 * j + 2] = a.z;
+    e[4 * j + 3] = a.w;
+  }
+}
+__device__ __forceinline__ void StoreChunk(uint2* dst, const uint2 (&e)[kChunk])
+{
+#pragma unroll
+  for (int j = 0; j < kChunk / 2; j++)
+    reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y);
+}
+__device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[kChunk])
+{
+#pragma unroll
+  for (int j = 0; j < kChunk / 2; j++)
+  {
+    const uint4 a = reinterpret_cast<const uint4*>(src)[j];
+    e[2 * j] = make_uint2(a.x, a.y);
+    e[2 * j + 1] = make_uint2(a.z, a.w);
+  }
+}
+
+__device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
 }
@@ -132,32 +159,40 @@ __device__ __forceinline__ float FastSqrtTimesResolution(uint32_t d2, double res
   const double hd = static_cast<double>(0.5f * y0);
   const double rem = fma(-gd, gd, static_cast<double>(d2));
   const double p = fma(rem, hd, gd) * resolution;
-  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p)) & 0x1fffffffu;
-  unsure = (low - (0x10000000u - 8191u)) < 16383u;
+  // the 29 bits below the float mantissa within 2^13 of one half: (low29 - (2^28 - 8191)) mod 2^29 < 16383
+  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p));
+  unsure = ((low << 3) - ((0x10000000u - 8191u) << 3)) < (16383u << 3);
   return static_cast<float>(p);
 }
 
-#ifndef VGT_SWEEP_PF
-#define VGT_SWEEP_PF 8
+// Host emulation (tests/cpp/sweep_emulation.cc compiles this file with g++ and runs the lanes one by one): no GPU asm.
+#ifdef VGT_HOST_EMULATION
+#define VGT_COLD_PATH()
+#define VGT_MIN_F32(acc, v) acc = fminf(acc, v)
+#define VGT_MAX_F32(acc, v) acc = fmaxf(acc, v)
+#else
+#define VGT_COLD_PATH() asm volatile("; rare path")
+// plain instructions: no NaN can occur, so no canonicalisation is needed
+#define VGT_MIN_F32(acc, v) asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(v))
+#define VGT_MAX_F32(acc, v) asm("v_max_f32 %0, %0, %1" : "+v"(acc) : "v"(v))
 #endif
-#ifndef VGT_SWEEP_WAVES
-#define VGT_SWEEP_WAVES 4
-#endif
+
 #ifdef VGT_SWEEP_STATS
-// diagnostic build (make SWEEPSTATS=1): [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the
-// same in sweep 2, [4] spilled chunks (lanes), [5] wave-level spill events, [6] exact conversions (wave events),
-// [7] wave-rows with a pop in sweep 1, [8] in sweep 2, [9] waves with class changes, [10] waves
+// diagnostic build: [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the same in
+// sweep 2, [4] spilled chunks (lanes), [6] exact conversions (wave events), [7] / [8] wave-level pop iterations in
+// sweep 1 / 2, [9] waves with class changes, [10] waves, [11] / [12] lane pops in sweep 1 / 2, [13] lane pushes
 __device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X pass
 #define VGT_SWEEP_COUNT(i, v) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + (i)], static_cast<unsigned long long>(v))
 #else
 #define VGT_SWEEP_COUNT(i, v)
 #endif
+
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
 template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
 __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
                                                                             OutT* __restrict__ out,
                                                                             unsigned char* __restrict__ spill,
-                                                                            uint2* __restrict__ band_info,
+                                                                            uint2* __restrict__ word_info,
                                                                             uint32_t* __restrict__ minmax_enc,
                                                                             const SweepGeom g)
 {
@@ -180,21 +215,20 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
   const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
   const int n = g.n;
-  const int nbands = g.nbands;
   const int64_t rstride = g.row_stride;
   const InT* const wave_in = in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
   OutT* const wave_out = out + (static_cast<int64_t>(outer) * g.outer_stride + z0);
   unsigned char* const wave_spill = spill + static_cast<int64_t>(item) * g.chunks * (kWaveSize * kChunkBytes);
-  uint2* const wave_info = band_info + static_cast<int64_t>(item) * nbands * kWaveSize;
+  uint2* const wave_info = word_info + static_cast<int64_t>(item) * g.nwords * kWaveSize;
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
 
   // ---- stack state.  Entries [0, depth): [0, lo) live in the spill buffer, [lo, depth) in the ring (slot = index
-  // mod 32).  D and L are depth and lo times the slot size, so that (D & kRingMask) | lane_entry is the ring address of
-  // entry `depth` and L + lane_chunk the spill address of the chunk that starts at entry `lo`.  Registers hold the top
-  // (Gt, rt), the second entry as differences to the top (A = rt - rs >= 0, nB = Gs - Gt) and the third as it came
-  // from the ring (e3, decoded when it moves up): a pop is a few additions and only waits for the ring when it is
-  // the second pop in a row. ----
+  // mod kRing).  D and L are depth and lo times the slot size, so that (D & kRingMask) | lane_entry is the ring
+  // address of entry `depth` and L + lane_chunk the spill address of the chunk that starts at entry `lo`.  Registers
+  // hold the top (Gt, rt), the second entry as differences to the top (A = rt - rs >= 0, nB = Gs - Gt) and the third
+  // as it came from the ring (e3, decoded when it moves up): a pop is a few additions and only waits for the ring
+  // when it is the second pop in a row. ----
   uint32_t D = 3u << kShift, L = 0;
   int32_t Gt = C::kSentinelG, nB = 1;
   int rt = 0, A = 0;
@@ -202,23 +236,29 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   auto ring_ref = [&](uint32_t scaled_index) -> Entry& {
     return *reinterpret_cast<Entry*>(ring_bytes + ((scaled_index & kRingMask) | lane_entry));
   };
+  auto spill_ptr = [&](uint32_t scaled_first) -> Entry* {
+    return reinterpret_cast<Entry*>(wave_spill + (scaled_first + lane_chunk));
+  };
   ring_ref(0u << kShift) = C::Pack(0, 0);  // never looked at: keeps "third" inside the stack
   ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 1, 0);
   ring_ref(2u << kShift) = C::Pack(C::kSentinelG, 0);
 
-  // the chunk that ends below entry lo comes back from the spill buffer (slow path: a run of pops reached it)
+  // chunks requested from the spill buffer at the last check (a refill_now of the same chunk drops them)
+  Entry pf0[kChunk], pf1[kChunk];
+  int pf_count = 0;
   [[maybe_unused]] int stat_phase = 0;
+  // the chunk that ends below entry lo comes back from the spill buffer (slow path: a run of pops reached it)
   auto refill_now = [&]() {
 #ifdef VGT_SWEEP_STATS
-    VGT_SWEEP_COUNT(stat_phase, 1);
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 || true)
     {
       const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1)) VGT_SWEEP_COUNT(stat_phase + 1, 1);
+      VGT_SWEEP_COUNT(stat_phase, 1);
+      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
+        VGT_SWEEP_COUNT(stat_phase + 1, 1);
     }
 #endif
     L -= kChunkSlots;
-    const Entry* src = reinterpret_cast<const Entry*>(wave_spill + (L + lane_chunk));
+    const Entry* src = spill_ptr(L);
 #pragma unroll 1
     for (int j = 0; j < kChunk; j += 2)
     {
@@ -226,23 +266,30 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = a;
       ring_ref(L + (static_cast<uint32_t>(j + 1) << kShift)) = b;
     }
+    pf_count = 0;
   };
   // top <- second <- third <- ring (two sentinels above entry 0 are never popped, so the third always exists)
-  // chunks requested from the spill buffer at the last boundary (a refill_now of the same chunk drops them)
-  Entry pf0[kChunk], pf1[kChunk];
-  int pf_count = 0;
   auto pop = [&]() {
+#ifdef VGT_SWEEP_STATS
+    {
+      const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+      VGT_SWEEP_COUNT(stat_phase == 0 ? 11 : 12, 1);
+      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
+        VGT_SWEEP_COUNT(stat_phase == 0 ? 7 : 8, 1);
+    }
+#endif
     Gt += nB;
     rt -= A;
     A = rt - C::Row(e3);
     nB = C::G(e3) - Gt;
     D -= kSlot;
-    if (D - 3 * kSlot < L)
-    {
-      refill_now();
-      pf_count = 0;
-    }
+    if (D - 3 * kSlot < L) refill_now();
     e3 = ring_ref(D - 3 * kSlot);
+  };
+  auto commit = [&](const Entry (&buf)[kChunk]) {
+    L -= kChunkSlots;
+#pragma unroll
+    for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = buf[j];
   };
 
   // =====================================================================================================
@@ -250,7 +297,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // =====================================================================================================
   uint32_t any_transition = 0;
   {
-    const InT* row_in = wave_in;  // first row of the band being loaded
     auto load_band = [&](int32_t (&dst)[kBand], int first_row) {
       // rows past the end repeat the last row (not used)
 #pragma unroll
@@ -260,63 +306,67 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         dst[k] = static_cast<int32_t>((wave_in + row * rstride)[zl]);
       }
     };
-    (void)row_in;
+    // every kChunk rows: the ring must have room for kChunk pushes
+    auto check_ring = [&]() {
+      // nothing to do while no request is pending, the ring has room and is not about to run dry
+      const uint32_t resident = D - L;
+      const bool busy = pf_count != 0 || (L != 0 && resident <= kChunkSlots) ||
+                        resident > (static_cast<uint32_t>(kRing - kChunk) << kShift);
+      if (__builtin_amdgcn_ballot_w64(busy) != 0ull)
+      {
+        // a chunk requested at the last check goes into the ring (the ring had at most kChunk entries then and
+        // has taken at most kChunk more)
+        if (pf_count != 0)
+        {
+          commit(pf0);
+          pf_count = 0;
+        }
+        // a ring that pops have nearly emptied asks for the chunk below it before a pop has to wait for it
+        if (L != 0 && D - L <= kChunkSlots)
+        {
+          LoadChunk(spill_ptr(L - kChunkSlots), pf0);
+          pf_count = 1;
+        }
+        while (__builtin_amdgcn_ballot_w64(D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift)) != 0ull)
+        {
+          if (D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift))
+          {
+            Entry buf[kChunk];
+#pragma unroll
+            for (int j = 0; j < kChunk; j++) buf[j] = ring_ref(L + (static_cast<uint32_t>(j) << kShift));
+            StoreChunk(spill_ptr(L), buf);
+            L += kChunkSlots;
+            VGT_SWEEP_COUNT(4, 1);
+          }
+        }
+      }
+    };
+
     int32_t nxt[kBand];
     load_band(nxt, 0);
-    int din = kFar;          // distance from the row below this band to the nearest row of the other class below it
-    uint32_t prev_bit = 0;   // class of the row below this band
+    int din = kFar;          // distance from the row below this word to the nearest row of the other class below it
+    uint32_t prev_bit = 0;   // class of the row below this word
+    uint32_t sw = 0;         // sign bits of the word being swept
     const int32_t n2m = 2 * (n - 1);
-    for (int b = 0; b < nbands; b++)
+    for (int r0 = 0; r0 < n; r0 += kBand)
     {
       int32_t cur[kBand];
 #pragma unroll
       for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
-      if (b + 1 < nbands) load_band(nxt, (b + 1) * kBand);
-      uint32_t sw = 0;
-      const int r0 = b * kBand;
-      const int valid = min(kBand, n - r0);
+      if (r0 + kBand < n) load_band(nxt, r0 + kBand);
+      uint32_t bits = 0;  // sign bits of this band
       auto rows = [&](auto guarded) {
         constexpr bool kGuard = decltype(guarded)::value;
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          if (k % 8 == 0)
-          {
-            // a chunk requested at the last boundary goes into the ring (the ring had at most 8 entries then and has
-            // taken at most 8 more)
-            if (pf_count > 0)
-            {
-              L -= kChunkSlots;
-#pragma unroll
-              for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf0[j];
-              pf_count = 0;
-            }
-            // a ring that pops have nearly emptied asks for the chunk below it before a pop has to wait for it
-            if (L != 0 && D - L <= static_cast<uint32_t>(VGT_SWEEP_PF) << kShift)
-            {
-              C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - kChunkSlots + lane_chunk)), pf0);
-              pf_count = 1;
-            }
-            // at most 8 pushes until the next check: make room for them
-            while (__any(D - L > static_cast<uint32_t>(kRing - 8) << kShift))
-            {
-              if (D - L > static_cast<uint32_t>(kRing - 8) << kShift)
-              {
-                Entry buf[kChunk];
-#pragma unroll
-                for (int j = 0; j < kChunk; j++) buf[j] = ring_ref(L + (static_cast<uint32_t>(j) << kShift));
-                C::StoreChunk(reinterpret_cast<Entry*>(wave_spill + (L + lane_chunk)), buf);
-                L += kChunkSlots;
-                VGT_SWEEP_COUNT(4, 1);
-              }
-            }
-          }
-          if (!kGuard || k < valid)
+          if (k % kChunk == 0) check_ring();
+          if (!kGuard || r0 + k < n)
           {
             const int q = r0 + k;
             const int32_t v = cur[k];
             const int32_t sign = v >> 31;
-            sw |= static_cast<uint32_t>(sign) & (1u << k);
+            bits |= static_cast<uint32_t>(sign) & (1u << k);
             int32_t f = (v ^ sign) - sign;
             if constexpr (sizeof(InT) == 2) f = (f == kInf16) ? kInf32 : __mul24(f, f);
             if (f < kLimit)
@@ -335,6 +385,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               }
               if (dG < __mul24(n2m, dr))
               {
+                VGT_SWEEP_COUNT(13, 1);
                 ring_ref(D) = C::Pack(G, q);
                 e3 = C::Pack(Gt + nB, rt - A);
                 A = dr;
@@ -347,97 +398,114 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           }
         }
       };
-      if (valid == kBand)
+      if (r0 + kBand <= n)
         rows(std::false_type{});
       else
         rows(std::true_type{});
-      // per band: sign word, distance carry for the evaluation's downward counters
-      uint32_t xdn = sw ^ ((sw << 1) | prev_bit);  // bit k: row k differs from the row below it (rows past the end: 0)
-      xdn &= LowBits(valid);
-      if (b == 0) xdn &= ~1u;
-      (wave_info + static_cast<int64_t>(b) * kWaveSize)[lane] = make_uint2(sw, static_cast<uint32_t>(din));
-      any_transition |= xdn;
-      din = xdn ? (valid - (31 - __clz(static_cast<int>(xdn)))) : min(din + valid, kFar);
-      prev_bit = (sw >> (valid - 1)) & 1u;
+      const int sub = r0 & (kWord - 1);
+      sw |= bits << sub;
+      if (sub + kBand == kWord || r0 + kBand >= n)
+      {
+        // the word is complete: sign word and distance carry for the evaluation's downward counters
+        const int word_first = r0 - sub;
+        const int valid = min(kWord, n - word_first);
+        uint32_t xdn = sw ^ ((sw << 1) | prev_bit);  // bit k: row k differs from the row below it (rows past the end: 0)
+        xdn &= LowBits(valid);
+        if (word_first == 0) xdn &= ~1u;
+        (wave_info + static_cast<int64_t>(word_first / kWord) * kWaveSize)[lane] = make_uint2(sw, static_cast<uint32_t>(din));
+        any_transition |= xdn;
+        din = xdn ? (valid - (31 - __clz(static_cast<int>(xdn)))) : min(din + valid, kFar);
+        prev_bit = (sw >> (valid - 1)) & 1u;
+        sw = 0;
+      }
     }
   }
 
   // =====================================================================================================
   // Sweep 2: evaluate, last row first.
   // =====================================================================================================
-  const bool classes = __any(any_transition != 0u);
+  const bool classes = (VGT_SWEEP_EXP & 2) ? false : (__builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull);
 #ifdef VGT_SWEEP_STATS
   stat_phase = 2;
-  if (lane == 0) { VGT_SWEEP_COUNT(10, 1); VGT_SWEEP_COUNT(9, classes ? 1 : 0); }
+  if (lane == 0)
+  {
+    VGT_SWEEP_COUNT(10, 1);
+    VGT_SWEEP_COUNT(9, classes ? 1 : 0);
+  }
 #endif
   float lo_value = INFINITY, hi_value = -INFINITY;
+  if (!(VGT_SWEEP_EXP & 8) || any_transition == 0x12345u)
   {
-    // Every 16 rows the chunks requested at the last boundary go into the ring and up to two more are requested
-    // when the ring has room (between two boundaries the ring only shrinks).
+    // Every kStep rows the chunks requested at the last step go into the ring and up to two more are requested
+    // when the ring has room (between two steps the ring only shrinks).
     pf_count = 0;  // (sweep 1 may leave a request behind: dropped)
     auto refill_step = [&]() {
-      if (pf_count > 0)
+      if (__builtin_amdgcn_ballot_w64(pf_count != 0 ||
+                                      (L != 0 && D - L <= (static_cast<uint32_t>(kRing - kChunk) << kShift))) != 0ull)
       {
-        L -= kChunkSlots;
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf0[j];
-      }
-      if (pf_count > 1)
-      {
-        L -= kChunkSlots;
-#pragma unroll
-        for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = pf1[j];
-      }
-      pf_count = 0;
-      const uint32_t resident = D - L;
-      if (L != 0 && resident <= static_cast<uint32_t>(kRing - kChunk) << kShift)
-      {
-        C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - kChunkSlots + lane_chunk)), pf0);
-        pf_count = 1;
-        if (L != kChunkSlots && resident <= static_cast<uint32_t>(kRing - 2 * kChunk) << kShift)
+        if (pf_count > 0) commit(pf0);
+        if (pf_count > 1) commit(pf1);
+        pf_count = 0;
+        const uint32_t resident = D - L;  // (after the commits)
+        if (L != 0 && resident <= (static_cast<uint32_t>(kRing - kChunk) << kShift))
         {
-          C::LoadChunk(reinterpret_cast<const Entry*>(wave_spill + (L - 2 * kChunkSlots + lane_chunk)), pf1);
-          pf_count = 2;
+          LoadChunk(spill_ptr(L - kChunkSlots), pf0);
+          pf_count = 1;
+          if (L != kChunkSlots && resident <= (static_cast<uint32_t>(kRing - 2 * kChunk) << kShift))
+          {
+            LoadChunk(spill_ptr(L - 2 * kChunkSlots), pf1);
+            pf_count = 2;
+          }
         }
       }
     };
-    auto pop_eval = [&]() {
-      Gt += nB;
-      rt -= A;
-      A = rt - C::Row(e3);
-      nB = C::G(e3) - Gt;
-      D -= kSlot;
-      if (D - 3 * kSlot < L)
-      {
-        refill_now();  // (prefetches of the same chunks that are still in flight are dropped)
-        pf_count = 0;
-      }
-      e3 = ring_ref(D - 3 * kSlot);
-    };
+    constexpr int kStep = (kChunk < 8) ? 8 : kChunk;  // rows between two refill steps
 
     int dn = kFar;             // distance from the row above the current one to the nearest row of the other class above
-    uint32_t above_bit0 = 0;   // class of the first row of the band above
-    // sign words: this band's and the next lower band's are in registers, the one below that is on its way
-    uint2 info = (wave_info + static_cast<int64_t>(nbands - 1) * kWaveSize)[lane];
+    uint32_t above_bit0 = 0;   // class of the first row of the word above
+    // sign words: this word's and the next lower word's are in registers, the one below that is on its way
+    const int nwords = g.nwords;
+    uint2 info = (wave_info + static_cast<int64_t>(nwords - 1) * kWaveSize)[lane];
     uint2 info_below = make_uint2(0u, 0u);
-    if (nbands > 1) info_below = (wave_info + static_cast<int64_t>(nbands - 2) * kWaveSize)[lane];
+    if (nwords > 1) info_below = (wave_info + static_cast<int64_t>(nwords - 2) * kWaveSize)[lane];
+    uint2 info_next = make_uint2(0u, 0u);
+    uint32_t xdn_word = 0, xup_word = 0;
     OutT* row_out = wave_out + static_cast<int64_t>(n - 1) * rstride;  // row being evaluated
-    for (int b = nbands - 1; b >= 0; b--)
+    const int last_band = (n - 1) / kBand * kBand;
+    for (int r0 = last_band; r0 >= 0; r0 -= kBand)
     {
-      uint2 info_next = make_uint2(0u, 0u);
-      if (b > 1) info_next = (wave_info + static_cast<int64_t>(b - 2) * kWaveSize)[lane];
-      const uint32_t sw = info.x;
-      const int r0 = b * kBand;
-      const int valid = min(kBand, n - r0);
+      const int sub = r0 & (kWord - 1);
+      if (sub + kBand == kWord || r0 == last_band)
+      {
+        // a new word starts (from its top)
+        const int w = r0 / kWord;
+        if (r0 != last_band)
+        {
+          above_bit0 = info.x & 1u;
+          info = info_below;
+          info_below = info_next;
+        }
+        if (w > 1) info_next = (wave_info + static_cast<int64_t>(w - 2) * kWaveSize)[lane];
+        if (classes)
+        {
+          const uint32_t sw = info.x;
+          const int valid = min(kWord, n - w * kWord);
+          const uint32_t prev_bit = (w > 0) ? (info_below.x >> (kWord - 1)) : (sw & 1u);
+          xdn_word = sw ^ ((sw << 1) | prev_bit);                    // bit k: row k differs from the row below it
+          xup_word = sw ^ ((sw >> 1) | (above_bit0 << (kWord - 1)));  // bit k: row k differs from the row above it
+          if (r0 == last_band) xup_word &= ~(1u << (valid - 1));      // nothing above the last row
+        }
+      }
+      const uint32_t swb = info.x >> sub;  // bit k: class of row r0 + k
       int dp[kBand];
       uint32_t xup = 0;
       if (classes)
       {
-        const uint32_t prev_bit = (b > 0) ? ((info_below.x >> (kBand - 1)) & 1u) : (sw & 1u);
-        const uint32_t xdn = sw ^ ((sw << 1) | prev_bit);            // bit k: row k differs from the row below it
-        xup = sw ^ ((sw >> 1) | (above_bit0 << (kBand - 1)));        // bit k: row k differs from the row above it
-        if (b == nbands - 1) xup &= ~(1u << (valid - 1));            // nothing above the last row
-        int d = static_cast<int>(info.y);
+        xup = xup_word >> sub;
+        // distance from the row below this band to the nearest row of the other class below it
+        const uint32_t below = xdn_word & LowBits(sub);
+        int d = below ? (sub - (31 - __clz(static_cast<int>(below)))) : static_cast<int>(info.y) + sub;
+        const uint32_t xdn = xdn_word >> sub;
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
@@ -450,13 +518,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
-          if (k % 16 == 15) refill_step();
-          if (!kGuard || k < valid)
+          if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4)) refill_step();
+          if (!kGuard || r0 + k < n)
           {
             const int q = r0 + k;
             const int q2 = 2 * q;
             // the second member is at least as good at row q: the top owns nothing at or below q
-            if (__mul24(A, q2) + nB <= 0)
+            if (!(VGT_SWEEP_EXP & 16) && __mul24(A, q2) + nB <= 0)
             {
               do pop();
               while (__mul24(A, q2) + nB <= 0);
@@ -469,37 +537,36 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               const uint32_t dm = static_cast<uint32_t>(min(dp[k], dn));
               best = min(best, dm * dm);
             }
-            const int32_t sign = __builtin_amdgcn_sbfe(static_cast<int32_t>(sw), k, 1);  // -1 on the negative class
+            const int32_t sign = __builtin_amdgcn_sbfe(static_cast<int32_t>(swb), k, 1);  // -1 on the negative class
             if constexpr (kFinal)
             {
               uint32_t d2 = best;
               bool exact = false;
               if constexpr (!kPlain)
               {
-                if (g.add_virtual_border && d2 < static_cast<uint32_t>(kLimit))
+                if (g.add_virtual_border)
                 {
                   const int x = (g.pass_axis == 0) ? q : outer + g.outer_begin;
                   const int y = (g.pass_axis == 0) ? outer + g.outer_begin : q;
-                  d2 = static_cast<uint32_t>(ClampToVirtualBorder(static_cast<int32_t>(d2), x, y,
-                                                                  z0 + static_cast<int>(zl) + g.z_offset, g.nx, g.ny,
-                                                                  g.nz_global));
-                }
-                else if (g.add_virtual_border)
-                {
-                  // no site at all: the border alone
-                  d2 = static_cast<uint32_t>(ClampToVirtualBorder(kInf32, (g.pass_axis == 0) ? q : outer + g.outer_begin,
-                                                                  (g.pass_axis == 0) ? outer + g.outer_begin : q,
-                                                                  z0 + static_cast<int>(zl) + g.z_offset, g.nx, g.ny,
-                                                                  g.nz_global));
-                  if (d2 == static_cast<uint32_t>(kInf32)) d2 = static_cast<uint32_t>(kLimit);
+                  const int32_t site = (d2 >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(d2);
+                  const int32_t clamped = ClampToVirtualBorder(site, x, y, z0 + static_cast<int>(zl) + g.z_offset, g.nx,
+                                                               g.ny, g.nz_global);
+                  d2 = (clamped == kInf32) ? static_cast<uint32_t>(kLimit) : static_cast<uint32_t>(clamped);
                 }
                 exact = !(g.resolution > 1.0e-30 && g.resolution < 1.0e30);
               }
               bool unsure;
-              float dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
+              float dist;
+              if (VGT_SWEEP_EXP & 1)
+              {
+                unsure = false;
+                dist = __uint_as_float(d2);
+              }
+              else
+                dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
               if (__builtin_amdgcn_ballot_w64(unsure || exact) != 0ull)
               {
-                asm volatile("; exact final conversion (rare)");  // keeps the block out of the straight-line code
+                VGT_COLD_PATH();  // keeps the block out of the straight-line code
 #ifdef VGT_SWEEP_STATS
                 if (lane == 0) VGT_SWEEP_COUNT(6, 1);
 #endif
@@ -508,8 +575,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               dist = (d2 >= static_cast<uint32_t>(kLimit)) ? __uint_as_float(0x7f800000u) : dist;
               const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
               row_out[zl] = value;
-              asm("v_min_f32 %0, %0, %1" : "+v"(lo_value) : "v"(value));
-              asm("v_max_f32 %0, %0, %1" : "+v"(hi_value) : "v"(value));
+              VGT_MIN_F32(lo_value, value);
+              VGT_MAX_F32(hi_value, value);
             }
             else
             {
@@ -520,14 +587,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           }
         }
       };
-      if (valid == kBand)
+      if (r0 + kBand <= n)
         rows(std::false_type{});
       else
         rows(std::true_type{});
-      above_bit0 = sw & 1u;
       if (classes) dn = min(dn, kFar);
-      info = info_below;
-      info_below = info_next;
     }
   }
   if constexpr (kFinal)
@@ -549,33 +613,35 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
                        int64_t max_input, hipStream_t stream)
 {
   g.zsegs = (g.nz + kWaveSize - 1) / kWaveSize;
-  g.nbands = (g.n + kBand - 1) / kBand;
+  g.nwords = (g.n + kWord - 1) / kWord;
   g.chunks = static_cast<int>(SpillChunks(g.n));
   const int64_t items = outer_count * g.zsegs;
   if (items <= 0) return hipSuccess;
   if (items > 0x7fffffffLL) return hipErrorInvalidValue;
-  // scratch: spill chunks (8 bytes per entry reserved), then one (sign word, carry) pair per band and lane
+  // scratch: spill chunks (8 bytes per entry reserved), then one (sign word, carry) pair per 32 rows and lane
   char* bytes = static_cast<char*>(scratch);
   const size_t spill_bytes = static_cast<size_t>(items) * g.chunks * kWaveSize * kChunk * sizeof(uint2);
   uint2* info = reinterpret_cast<uint2*>(bytes + spill_bytes);
   const int64_t rows = g.n - 1;
   const bool packed = (g.n <= 1024) && (max_input + rows * rows < Codec<true>::kSentinelG);
   const dim3 grid(static_cast<unsigned>(items)), block(kWaveSize);
+  // occupancy experiments: extra dynamic LDS per workgroup (bytes)
+  static const int extra_lds = getenv("VGT_SWEEP_EXTRA_LDS") ? atoi(getenv("VGT_SWEEP_EXTRA_LDS")) : 0;
   unsigned char* spill = reinterpret_cast<unsigned char*>(bytes);
   // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
   const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
   if (packed && general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, 0, stream, in, out, spill, info,
-                       minmax_enc, g);
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, extra_lds, stream, in, out,
+                       spill, info, minmax_enc, g);
   else if (packed)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, 0, stream, in, out, spill, info,
-                       minmax_enc, g);
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, extra_lds, stream, in, out, spill,
+                       info, minmax_enc, g);
   else if (general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, 0, stream, in, out, spill, info,
-                       minmax_enc, g);
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, extra_lds, stream, in, out,
+                       spill, info, minmax_enc, g);
   else
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, 0, stream, in, out, spill, info,
-                       minmax_enc, g);
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, extra_lds, stream, in, out, spill,
+                       info, minmax_enc, g);
   return hipGetLastError();
 }
 
@@ -614,9 +680,9 @@ size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz)
   const int64_t zsegs = (nz + kWaveSize - 1) / kWaveSize;
   auto pass_bytes = [&](int64_t n, int64_t outer) {
     const int64_t items = outer * zsegs;
-    const int64_t nbands = (n + kBand - 1) / kBand;
+    const int64_t nwords = (n + kWord - 1) / kWord;
     return static_cast<size_t>(items) * (SpillChunks(n) * kWaveSize * kChunk * sizeof(uint2) +
-                                         nbands * kWaveSize * sizeof(uint2));
+                                         nwords * kWaveSize * sizeof(uint2));
   };
   const size_t y = pass_bytes(ny, nx), x = pass_bytes(nx, ny);
   return (y > x ? y : x) + 256;
