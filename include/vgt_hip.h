@@ -189,8 +189,10 @@ int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, 
  * in HBM, the caller provides the scratch workspace.  minmax_dev, if non-NULL, receives
  * {min, max} as two floats on the device after the call (stream-ordered). */
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
-/* As above for a context set to EDT variant `variant`: only the line-sweep cross-check variant (3)
- * needs more (its per-line stacks, 8 B/voxel); every other variant returns the size above. */
+/* As above for a context set to EDT variant `variant` (kept for callers of earlier versions: every variant runs in
+ * the workspace of vgt_hip_sdf_workspace_bytes).  The workspace holds the two intermediate fields (2 + 4 bytes per
+ * voxel) and the line passes' scratch, which grows with the axis lengths, not with the volume (the spilled stack
+ * entries and sign words of the at most 5120 waves in flight: 2.8 GB for a 1024^3 grid, 5.5 GB at 2048 x 2048 x 1024). */
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant);
 int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                     int64_t nz, double resolution, int unknown_is_filled,
@@ -203,9 +205,9 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
 /* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
- * 0 = default (LDS-tiled lower envelope: stack + merge), 1 = pruned outward search from HBM
- * (any size), 3 = line sweep (one lane per line, stacks in the workspace; needs
- * vgt_hip_sdf_workspace_bytes_for_variant, otherwise the default passes run).  2 is not a variant. */
+ * 0 = default (lane-per-line sweeps: one lane runs the Felzenszwalb-Huttenlocher stack of one line, stack tops in
+ * LDS, any extent), 1 = pruned outward search from HBM (any size), 2 = LDS-tiled lower envelope (band hulls + merge;
+ * axes up to 2048, longer ones take the pruned search). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 /* Diagnostic: the final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation
  * with an exact fallback (csrc/edt_device.hpp); this runs both over d2 in

@@ -87,6 +87,9 @@ inline uint32_t __float_as_uint(float v)
 #define __builtin_amdgcn_ballot_w64(pred) (static_cast<unsigned long long>((pred) ? 1ull : 0ull))
 #define __builtin_amdgcn_sbfe(value, offset, width) \
   (static_cast<int32_t>(static_cast<uint32_t>(value) << (32 - (offset) - (width))) >> (32 - (width)))
+#define __builtin_amdgcn_alignbit(hi, lo, shift) \
+  (static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>(lo)) >> (shift)))
+#define __builtin_amdgcn_readfirstlane(value) (value)
 inline int __any(int pred) { return pred != 0; }
 inline int __shfl_xor(int v, int) { return v; }
 inline void __syncthreads() {}

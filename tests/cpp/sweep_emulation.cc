@@ -1,4 +1,4 @@
-// CPU check of the lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, EDT variant 4): the kernel source is compiled by
+// CPU check of the lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, the default EDT line passes): the kernel source is compiled by
 // g++ against tests/cpp/hip_shim and run one lane at a time, on random lines, against a brute-force evaluation of
 //     out(q) = min( min_r (q-r)^2 + |F[r]|,  min over rows r of the other class (q-r)^2 ),
 // i.e. the per-line contract of the Y and X passes (edt_hull_kernels.hip header).  It exercises what the GPU parity tests

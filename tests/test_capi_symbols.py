@@ -38,12 +38,18 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_workspace_size(lib):
     assert lib.vgt_hip_abi_version() == 1
-    # int16 + int32 intermediates and a small min/max block, 256-byte aligned pieces; only the
-    # line-sweep cross-check variant (3) adds its stacks (8 B per voxel) + sign words (one bit per voxel)
+    # int16 + int32 intermediates, a small min/max block and the line passes' scratch (work counter + per slot:
+    # spill chunks of 8 entries x 8 bytes x 64 lanes and one 8-byte word record per 32 rows and lane), 256-byte
+    # aligned pieces; the same for every EDT variant
     n = 64 * 64 * 64
-    assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256
-    assert capi.sdf_workspace_bytes((64, 64, 64), 1) == n * 2 + n * 4 + 256
-    assert capi.sdf_workspace_bytes((64, 64, 64), 3) == n * 2 + n * 4 + 256 + n * 8 + n // 8 + 256
+    slots, chunks, words = 64, (64 + 3 + 7) // 8 + 1, 2
+    scratch = 256 + slots * (chunks * 64 * 8 * 8 + words * 64 * 8) + 256
+    assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256 + scratch
+    assert capi.sdf_workspace_bytes((64, 64, 64), 1) == capi.sdf_workspace_bytes((64, 64, 64))
+    assert capi.sdf_workspace_bytes((64, 64, 64), 2) == capi.sdf_workspace_bytes((64, 64, 64))
+    # the scratch grows with the axis lengths, not with the volume: at most 5120 workgroups are in flight
+    big = capi.sdf_workspace_bytes((1024, 1024, 1024))
+    assert big - 6 * 2 ** 30 - 256 < 3 * 2 ** 30
     assert capi.sdf_workspace_bytes((0, 4, 4)) == 0
 
 

@@ -1,4 +1,4 @@
-"""(not gpu) The lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, EDT variant 4) compiled by g++ against a host
+"""(not gpu) The lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, the default EDT line passes) compiled by g++ against a host
 stand-in for the HIP runtime (tests/cpp/hip_shim) and run one lane at a time on random lines, against a brute-force line
 transform: tests/cpp/sweep_emulation.cc.  Covers every ring / band size the kernels can be built with, so that a change
 of the tuning constants cannot silently break the ring / spill bookkeeping (the GPU tests pin the shipped build only)."""

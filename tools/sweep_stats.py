@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Event counts of the sweep passes (EDT variant 4) from a diagnostic build:
+"""Event counts of the sweep passes (the default EDT line passes) from a diagnostic build:
    make -C voxelized_geometry_tools_amd/csrc OBJDIR=sstats OUT=../libvgt_hip_sstats.so HIPFLAGS="... -DVGT_SWEEP_STATS"
    VGT_HIP_LIB=.../libvgt_hip_sstats.so python tools/sweep_stats.py [size] [dist]"""
 import ctypes
@@ -26,10 +26,9 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_edt_variant(4)
-    occ = bench.device_occupancy(torch, shape, dist, 42, dev)
+        occ = bench.device_occupancy(torch, shape, dist, 42, dev)
     sdf = torch.empty(shape, dtype=torch.float32, device=dev)
-    nbytes = capi.sdf_workspace_bytes(shape, 4)
+    nbytes = capi.sdf_workspace_bytes(shape)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     mm = torch.empty(2, dtype=torch.float32, device=dev)
     lib = capi.load()

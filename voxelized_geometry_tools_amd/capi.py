@@ -364,7 +364,7 @@ def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtua
 
 
 def sdf_workspace_bytes(shape, variant=0):
-    """Workspace of the device-resident SDF entry points; only EDT variant 3 (line sweep) needs more."""
+    """Workspace of the device-resident SDF entry points (the same for every EDT variant)."""
     return int(load().vgt_hip_sdf_workspace_bytes_for_variant(*[int(s) for s in shape], int(variant)))
 
 

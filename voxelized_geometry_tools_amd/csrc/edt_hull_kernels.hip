@@ -1211,6 +1211,10 @@ bool XBeforeY(const SdfParams& p)
 }
 }  // namespace
 
+hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
+                                        const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                        hipStream_t stream, bool* handled);
+
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled)
 {
@@ -1228,7 +1232,7 @@ hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* mi
   return LaunchPassXHullFinalizeRange(in32, sdf, minmax_enc, p, 0, -1, stream, handled);
 }
 
-bool LinePassesAreTiled(const SdfParams& p)
+bool HullPassesAreTiled(const SdfParams& p)
 {
   const int wx = LinesPerTile(p.nx), wy = LinesPerTile(p.ny);
   if (wx == 0 || wy == 0 || XBeforeY(p)) return false;

@@ -17,8 +17,8 @@
 //
 // This file holds the Z scan and the simple pruned-search line pass (EdtVariant::kBruteForce,
 // exact for any size, the fallback for axes longer than the tiled kernels support).  The
-// LDS-tiled line passes live in edt_hull_kernels.hip (default: lower envelope), the line-sweep
-// cross-check variant in edt_line_kernels.hip.
+// default line passes live in edt_sweep_kernels.hip (lane-per-line sweeps), the LDS-tiled
+// lower-envelope passes (cross-check variant 2) in edt_hull_kernels.hip.
 #include "edt_device.hpp"
 
 namespace vgt
@@ -591,19 +591,17 @@ int GridFor(int64_t work_items, int block)
 }
 }  // namespace
 
-// Defined in edt_line_kernels.hip / edt_hull_kernels.hip.
-hipError_t LaunchPassYLine(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
-                           hipStream_t stream);
-hipError_t LaunchPassXLineFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                                   void* scratch, const SdfParams& p, hipStream_t stream);
+// Defined in edt_sweep_kernels.hip / edt_hull_kernels.hip.
 hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                             hipStream_t stream);
-hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
-                                    const SdfParams& p, hipStream_t stream);
+hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                         const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                         hipStream_t stream);
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                    const SdfParams& p, hipStream_t stream, bool* handled);
+bool HullPassesAreTiled(const SdfParams& p);
 hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                         const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
                                         hipStream_t stream, bool* handled);
@@ -727,14 +725,11 @@ hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const Sd
   return hipGetLastError();
 }
 
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, const SdfParams& p,
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream)
 {
-  if (variant == EdtVariant::kLine && line_scratch)
-    return LaunchPassYLine(in16, out32, line_scratch, p, stream);
-  if (variant == EdtVariant::kSweep && line_scratch)
-    return LaunchPassYSweep(in16, out32, line_scratch, p, stream);
-  if (variant != EdtVariant::kBruteForce)
+  if (variant == EdtVariant::kDefault) return LaunchPassYSweep(in16, out32, scratch, p, stream);
+  if (variant == EdtVariant::kHull)
   {
     bool handled = false;
     const hipError_t err = LaunchPassYHull(in16, out32, p, stream, &handled);
@@ -747,14 +742,12 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, 
 }
 
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               void* line_scratch, const SdfParams& p, EdtVariant variant,
+                               void* scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream)
 {
-  if (variant == EdtVariant::kLine && line_scratch)
-    return LaunchPassXLineFinalize(in32, sdf, minmax_enc, line_scratch, p, stream);
-  if (variant == EdtVariant::kSweep && line_scratch)
-    return LaunchPassXSweepFinalize(in32, sdf, minmax_enc, line_scratch, p, stream);
-  if (variant != EdtVariant::kBruteForce)
+  if (variant == EdtVariant::kDefault)
+    return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
+  if (variant == EdtVariant::kHull)
   {
     bool handled = false;
     const hipError_t err = LaunchPassXHullFinalize(in32, sdf, minmax_enc, p, stream, &handled);
@@ -767,6 +760,24 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                      static_cast<int>(p.z_offset),
                      static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz));
   return hipGetLastError();
+}
+
+bool LinePassesTakeRanges(const SdfParams& p, EdtVariant variant)
+{
+  if (variant == EdtVariant::kDefault) return true;
+  return variant == EdtVariant::kHull && HullPassesAreTiled(p);
+}
+
+hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                    const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
+                                    hipStream_t stream)
+{
+  if (variant == EdtVariant::kDefault)
+    return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, outer_begin, outer_count, stream);
+  bool handled = false;
+  const hipError_t err = LaunchPassXHullFinalizeRange(in32, sdf, minmax_enc, p, outer_begin, outer_count, stream, &handled);
+  if (err != hipSuccess) return err;
+  return handled ? hipSuccess : hipErrorInvalidValue;
 }
 
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream)

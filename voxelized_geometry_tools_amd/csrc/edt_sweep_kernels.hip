@@ -41,7 +41,7 @@ namespace vgt
 namespace
 {
 #ifndef VGT_SWEEP_BAND
-#define VGT_SWEEP_BAND 32
+#define VGT_SWEEP_BAND 16
 #endif
 #ifndef VGT_SWEEP_RING
 #define VGT_SWEEP_RING 32
@@ -67,6 +67,7 @@ struct SweepGeom
   int n;                 // rows along the pass axis
   int nz;                // extent of the contiguous axis
   int zsegs;             // waves per outer index
+  int items;             // outer indices x zsegs: units of work, dealt to the workgroups through a counter
   int nwords;            // ceil(n / 32)
   int chunks;            // spill chunks per lane
   int64_t row_stride;    // elements between consecutive rows
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                                                                             unsigned char* __restrict__ spill,
                                                                             uint2* __restrict__ word_info,
                                                                             uint32_t* __restrict__ minmax_enc,
+                                                                            int* __restrict__ work_counter,
                                                                             const SweepGeom g)
 {
   using C = Codec<kPacked>;
@@ -209,19 +211,35 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   unsigned char* const ring_bytes = reinterpret_cast<unsigned char*>(ring);
 
   const int lane = threadIdx.x;
-  const int item = blockIdx.x;
+  const int n = g.n;
+  const int64_t rstride = g.row_stride;
+  // The workgroup (one wave) owns one slot of the scratch buffer -- spilled stack entries and sign words -- for all
+  // the lines it works on, so the scratch is sized by the number of workgroups in flight, not by the grid.
+  unsigned char* const wave_spill = spill + static_cast<int64_t>(blockIdx.x) * g.chunks * (kWaveSize * kChunkBytes);
+  uint2* const wave_info = word_info + static_cast<int64_t>(blockIdx.x) * g.nwords * kWaveSize;
+  const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
+  const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
+  float lo_value = INFINITY, hi_value = -INFINITY;
+#ifdef VGT_HOST_EMULATION
+  int emulated_round = 0;
+#endif
+  for (;;)
+  {
+  // ---- next unit of work: 64 neighbouring lines of one outer index ----
+  int item = 0;
+#ifdef VGT_HOST_EMULATION
+  item = static_cast<int>(blockIdx.x + gridDim.x * emulated_round++);  // (lanes run one after the other: fixed deal)
+#else
+  if (lane == 0) item = atomicAdd(work_counter, 1);
+  item = __builtin_amdgcn_readfirstlane(item);
+#endif
+  if (item >= g.items) break;
   const int outer = item / g.zsegs;
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
   const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
-  const int n = g.n;
-  const int64_t rstride = g.row_stride;
   const InT* const wave_in = in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
   OutT* const wave_out = out + (static_cast<int64_t>(outer) * g.outer_stride + z0);
-  unsigned char* const wave_spill = spill + static_cast<int64_t>(item) * g.chunks * (kWaveSize * kChunkBytes);
-  uint2* const wave_info = word_info + static_cast<int64_t>(item) * g.nwords * kWaveSize;
-  const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
-  const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
 
   // ---- stack state.  Entries [0, depth): [0, lo) live in the spill buffer, [lo, depth) in the ring (slot = index
   // mod kRing).  D and L are depth and lo times the slot size, so that (D & kRingMask) | lane_entry is the ring
@@ -361,12 +379,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         for (int k = 0; k < kBand; k++)
         {
           if (k % kChunk == 0) check_ring();
+          if (kGuard && r0 + k >= n) bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
           if (!kGuard || r0 + k < n)
           {
             const int q = r0 + k;
             const int32_t v = cur[k];
             const int32_t sign = v >> 31;
-            bits |= static_cast<uint32_t>(sign) & (1u << k);
+            bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
             int32_t f = (v ^ sign) - sign;
             if constexpr (sizeof(InT) == 2) f = (f == kInf16) ? kInf32 : __mul24(f, f);
             if (f < kLimit)
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       else
         rows(std::true_type{});
       const int sub = r0 & (kWord - 1);
-      sw |= bits << sub;
+      sw |= (bits >> (32 - kBand)) << sub;
       if (sub + kBand == kWord || r0 + kBand >= n)
       {
         // the word is complete: sign word and distance carry for the evaluation's downward counters
@@ -433,7 +452,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     VGT_SWEEP_COUNT(9, classes ? 1 : 0);
   }
 #endif
-  float lo_value = INFINITY, hi_value = -INFINITY;
   if (!(VGT_SWEEP_EXP & 8) || any_transition == 0x12345u)
   {
     // Every kStep rows the chunks requested at the last step go into the ring and up to two more are requested
@@ -497,28 +515,30 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         }
       }
       const uint32_t swb = info.x >> sub;  // bit k: class of row r0 + k
-      int dp[kBand];
+      // distances to the nearest row of the other class below, for 8 rows at a time (dp[k & 7]): counted upwards from
+      // the carry of the word and the class changes below the group
+      int dp[8];
       uint32_t xup = 0;
-      if (classes)
-      {
-        xup = xup_word >> sub;
-        // distance from the row below this band to the nearest row of the other class below it
-        const uint32_t below = xdn_word & LowBits(sub);
-        int d = below ? (sub - (31 - __clz(static_cast<int>(below)))) : static_cast<int>(info.y) + sub;
-        const uint32_t xdn = xdn_word >> sub;
-#pragma unroll
-        for (int k = 0; k < kBand; k++)
-        {
-          d = ((xdn >> k) & 1u) ? 1 : d + 1;
-          dp[k] = d;
-        }
-      }
+      if (classes) xup = xup_word >> sub;
       auto rows = [&](auto guarded) {
         constexpr bool kGuard = decltype(guarded)::value;
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
           if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4)) refill_step();
+          if (classes && k % 8 == 7)
+          {
+            const int first = sub + k - 7;  // position of the group's first row in the word
+            const uint32_t below = xdn_word & LowBits(first);
+            int d = below ? (first - (31 - __clz(static_cast<int>(below)))) : static_cast<int>(info.y) + first;
+            const uint32_t xdn = xdn_word >> first;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+              d = ((xdn >> j) & 1u) ? 1 : d + 1;
+              dp[j] = d;
+            }
+          }
           if (!kGuard || r0 + k < n)
           {
             const int q = r0 + k;
@@ -534,7 +554,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             if (classes)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
-              const uint32_t dm = static_cast<uint32_t>(min(dp[k], dn));
+              const uint32_t dm = static_cast<uint32_t>(min(dp[k & 7], dn));
               best = min(best, dm * dm);
             }
             const int32_t sign = __builtin_amdgcn_sbfe(static_cast<int32_t>(swb), k, 1);  // -1 on the negative class
@@ -594,6 +614,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       if (classes) dn = min(dn, kFar);
     }
   }
+  }  // next unit of work
   if constexpr (kFinal)
   {
     uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
@@ -606,7 +627,32 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   }
 }
 
+// Workgroups per launch = slots of the scratch buffer.  More than the 256 CUs x 16 waves of an MI355X hold at four
+// waves per SIMD, so the chip is always full; extra workgroups find the work counter exhausted and leave.
+#ifdef VGT_HOST_EMULATION
+constexpr int64_t kSweepSlots = 3;  // (the CPU test wants slots that are used again and again)
+#else
+constexpr int64_t kSweepSlots = 5120;
+#endif
+constexpr size_t kCounterBytes = 256;  // the work counter, alone on its cache lines
+
 int64_t SpillChunks(int64_t n) { return (n + 3 + kChunk - 1) / kChunk + 1; }
+
+// Entries of a line of n rows fit 32 bits when every G = F + row^2 stays below the sentinels.
+bool PackedEntries(int64_t n, int64_t max_input)
+{
+  return n <= 1024 && max_input + (n - 1) * (n - 1) < Codec<true>::kSentinelG;
+}
+
+// Scratch of one pass: work counter, spill chunks and sign words of `slots` workgroups.  Sized for 64-bit entries
+// whatever the launch will use, so that the size depends on the extents only.
+size_t PassScratchBytes(int64_t n, int64_t items)
+{
+  const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
+  const int64_t nwords = (n + kWord - 1) / kWord;
+  return kCounterBytes + static_cast<size_t>(slots) * (SpillChunks(n) * kWaveSize * kChunk * sizeof(uint2) +
+                                                       nwords * kWaveSize * sizeof(uint2));
+}
 
 template <typename InT, typename OutT, bool kFinal>
 hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax_enc, SweepGeom g, int64_t outer_count,
@@ -618,30 +664,39 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
   const int64_t items = outer_count * g.zsegs;
   if (items <= 0) return hipSuccess;
   if (items > 0x7fffffffLL) return hipErrorInvalidValue;
-  // scratch: spill chunks (8 bytes per entry reserved), then one (sign word, carry) pair per 32 rows and lane
+  g.items = static_cast<int>(items);
+  const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
+  const bool packed = PackedEntries(g.n, max_input);
+  // scratch: work counter | spill chunks of every slot | one (sign word, carry) pair per 32 rows, lane and slot
   char* bytes = static_cast<char*>(scratch);
-  const size_t spill_bytes = static_cast<size_t>(items) * g.chunks * kWaveSize * kChunk * sizeof(uint2);
-  uint2* info = reinterpret_cast<uint2*>(bytes + spill_bytes);
-  const int64_t rows = g.n - 1;
-  const bool packed = (g.n <= 1024) && (max_input + rows * rows < Codec<true>::kSentinelG);
-  const dim3 grid(static_cast<unsigned>(items)), block(kWaveSize);
+  int* counter = reinterpret_cast<int*>(bytes);
+  unsigned char* spill = reinterpret_cast<unsigned char*>(bytes + kCounterBytes);
+  const size_t spill_bytes =
+      static_cast<size_t>(slots) * g.chunks * kWaveSize * kChunk * (packed ? sizeof(uint32_t) : sizeof(uint2));
+  uint2* info = reinterpret_cast<uint2*>(bytes + kCounterBytes + spill_bytes);
+#ifdef VGT_HOST_EMULATION
+  *counter = 0;
+#else
+  const hipError_t err = hipMemsetAsync(counter, 0, sizeof(int), stream);
+  if (err != hipSuccess) return err;
+#endif
+  const dim3 grid(static_cast<unsigned>(slots)), block(kWaveSize);
   // occupancy experiments: extra dynamic LDS per workgroup (bytes)
   static const int extra_lds = getenv("VGT_SWEEP_EXTRA_LDS") ? atoi(getenv("VGT_SWEEP_EXTRA_LDS")) : 0;
-  unsigned char* spill = reinterpret_cast<unsigned char*>(bytes);
   // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
   const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
   if (packed && general)
     hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, extra_lds, stream, in, out,
-                       spill, info, minmax_enc, g);
+                       spill, info, minmax_enc, counter, g);
   else if (packed)
     hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, extra_lds, stream, in, out, spill,
-                       info, minmax_enc, g);
+                       info, minmax_enc, counter, g);
   else if (general)
     hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, extra_lds, stream, in, out,
-                       spill, info, minmax_enc, g);
+                       spill, info, minmax_enc, counter, g);
   else
     hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, extra_lds, stream, in, out, spill,
-                       info, minmax_enc, g);
+                       info, minmax_enc, counter, g);
   return hipGetLastError();
 }
 
@@ -672,19 +727,22 @@ SweepGeom SweepGeometry(const SdfParams& p, int axis, int64_t* outer_count)
   g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
   return g;
 }
+
+// Largest magnitudes the passes can meet: squared Z distances in the Y pass, plus squared Y distances in the X pass.
+int64_t MaxInputY(const SdfParams& p)
+{
+  const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
+  return (nzg - 1) * (nzg - 1);
+}
+int64_t MaxInputX(const SdfParams& p) { return MaxInputY(p) + (p.ny - 1) * (p.ny - 1); }
 }  // namespace
 
-// Scratch of the sweep passes for a grid: the larger of the two passes' needs.
+// Scratch of the sweep passes for a grid: the larger of the two passes' needs (they use the same bytes, one after
+// the other).
 size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz)
 {
   const int64_t zsegs = (nz + kWaveSize - 1) / kWaveSize;
-  auto pass_bytes = [&](int64_t n, int64_t outer) {
-    const int64_t items = outer * zsegs;
-    const int64_t nwords = (n + kWord - 1) / kWord;
-    return static_cast<size_t>(items) * (SpillChunks(n) * kWaveSize * kChunk * sizeof(uint2) +
-                                         nwords * kWaveSize * sizeof(uint2));
-  };
-  const size_t y = pass_bytes(ny, nx), x = pass_bytes(nx, ny);
+  const size_t y = PassScratchBytes(ny, nx * zsegs), x = PassScratchBytes(nx, ny * zsegs);
   return (y > x ? y : x) + 256;
 }
 
@@ -692,19 +750,31 @@ hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, 
 {
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);
-  const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
-  const int64_t max_input = (nzg - 1) * (nzg - 1);
-  return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch, nullptr, g, outer_count, max_input, stream);
+  return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch, nullptr, g, outer_count, MaxInputY(p), stream);
+}
+
+// X pass over the Y positions [outer_begin, outer_begin + outer_count) of the grid (outer_count < 0: all of them):
+// full-grid pointers and extents in `p`.
+hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                         const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
+                                         hipStream_t stream)
+{
+  int64_t outer_count = 0;
+  SweepGeom g = SweepGeometry(p, 0, &outer_count);
+  if (outer_count_or_all >= 0)
+  {
+    in32 += outer_begin * g.outer_stride;
+    sdf += outer_begin * g.outer_stride;
+    g.outer_begin = static_cast<int>(outer_begin);
+    outer_count = outer_count_or_all;
+  }
+  return LaunchSweep<int32_t, float, true>(in32, sdf, scratch, minmax_enc, g, outer_count, MaxInputX(p), stream);
 }
 
 hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
                                     const SdfParams& p, hipStream_t stream)
 {
-  int64_t outer_count = 0;
-  const SweepGeom g = SweepGeometry(p, 0, &outer_count);
-  const int64_t nzg = p.nz_global > 0 ? p.nz_global : p.nz;
-  const int64_t max_input = (nzg - 1) * (nzg - 1) + (p.ny - 1) * (p.ny - 1);
-  return LaunchSweep<int32_t, float, true>(in32, sdf, scratch, minmax_enc, g, outer_count, max_input, stream);
+  return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
 }
 }  // namespace vgt
 

@@ -205,23 +205,12 @@ struct SdfWorkspace
   int16_t* t16;
   int32_t* t32;
   uint32_t* minmax_enc;
-  void* line_scratch;  // stacks + sign words of the line-sweep passes
+  void* sweep_scratch;  // work counter, spilled stack entries and sign words of the line passes
   size_t bytes;
 };
 
-// Scratch beyond the default workspace that a variant keeps there (stacks of the line-sweep variants 3 and 4).
-size_t VariantScratchBytes(vgt::EdtVariant variant, int64_t nx, int64_t ny, int64_t nz)
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
 {
-  if (variant == vgt::EdtVariant::kLine) return vgt::LinePassScratchBytes(nx, ny, nz);
-  if (variant == vgt::EdtVariant::kSweep) return vgt::SweepPassScratchBytes(nx, ny, nz);
-  return 0;
-}
-
-SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz,
-                            vgt::EdtVariant variant = vgt::EdtVariant::kDefault)
-{
-  const size_t scratch_bytes = VariantScratchBytes(variant, nx, ny, nz);
-  const bool with_line_scratch = scratch_bytes != 0;
   SdfWorkspace ws;
   const size_t n = static_cast<size_t>(nx * ny * nz);
   size_t off = 0;
@@ -231,12 +220,8 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz,
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
   off += 256;
-  ws.line_scratch = nullptr;
-  if (with_line_scratch)
-  {
-    ws.line_scratch = static_cast<char*>(base) + off;
-    off = AlignUp(off + scratch_bytes, 256);
-  }
+  ws.sweep_scratch = static_cast<char*>(base) + off;
+  off = AlignUp(off + vgt::SweepPassScratchBytes(nx, ny, nz), 256);
   ws.bytes = off;
   return ws;
 }
@@ -265,10 +250,7 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
                    void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                    hipEvent_t* events)
 {
-  // the line-sweep cross-check variant keeps its stacks in the workspace; a workspace without that
-  // part (vgt_hip_sdf_workspace_bytes) runs the default passes instead
-  SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant);
-  if (ws.line_scratch && workspace_bytes < ws.bytes) ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   hipStream_t s = ctx->stream;
@@ -279,9 +261,9 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
   else
     VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, nullptr, s), "Z scan");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.line_scratch, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.line_scratch, p, ctx->variant, s),
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s),
               "X pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
@@ -302,7 +284,7 @@ bool CanPipelineFromHost(const vgt_hip_ctx* ctx, const vgt::SdfParams& p)
   // value turns the pipeline off)
   int64_t min_voxels = int64_t{1} << 27;
   if (const char* text = getenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS")) min_voxels = atoll(text);
-  if (min_voxels < 0 || ctx->variant != vgt::EdtVariant::kDefault || !vgt::LinePassesAreTiled(p)) return false;
+  if (min_voxels < 0 || !vgt::LinePassesTakeRanges(p, ctx->variant)) return false;
   return p.nx >= 4 * kPipelineChunks && p.ny >= 4 * kPipelineChunks && p.nx * p.ny * p.nz >= min_voxels;
 }
 
@@ -350,15 +332,14 @@ int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, c
       VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
     else
       VGT_TRY_HIP(vgt::LaunchScanZFromMask(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
-    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16 + off, ws.t32 + off, nullptr, part, ctx->variant, s), "Y pass");
+    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16 + off, ws.t32 + off, ws.sweep_scratch, part, ctx->variant, s), "Y pass");
   }
   const size_t pitch = static_cast<size_t>(plane) * sizeof(float);
   for (int c = 0; c < kPipelineChunks; c++)
   {
     const int64_t y0 = y_begin(c), rows = y_begin(c + 1) - y0;
-    bool handled = false;
-    VGT_TRY_HIP(vgt::LaunchPassXHullFinalizeRange(ws.t32, sdf_dev, ws.minmax_enc, p, y0, rows, s, &handled), "X pass");
-    if (!handled) return Fail(VGT_HIP_ERR_RUNTIME, "X pass: the tiled kernel refused a range it had accepted");
+    VGT_TRY_HIP(vgt::LaunchPassXFinalizeRange(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, y0, rows, s),
+                "X pass");
     VGT_TRY_HIP(hipEventRecord(computed[c], s), "event record");
     VGT_TRY_HIP(hipStreamWaitEvent(ctx->copy_out, computed[c], 0), "wait for a range of the field");
     VGT_TRY_HIP(hipMemcpy2DAsync(sdf_host + y0 * p.nz, pitch, sdf_dev + y0 * p.nz, pitch,
@@ -380,7 +361,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   if (rc != VGT_HIP_OK) return rc;
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
-  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes_for_variant(p.nx, p.ny, p.nz, static_cast<int>(ctx->variant));
+  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes(p.nx, p.ny, p.nz);
   const ScopedHostPin pin_in(input_host, nvox * sizeof(InT));
   const ScopedHostPin pin_out(sdf_host, nvox * sizeof(float));
   std::lock_guard<std::mutex> lock(ctx->mutex);
@@ -706,8 +687,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 4 || variant == 2)  // 2 is not a variant
-    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
+  if (!ctx || variant < 0 || variant > 2) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
 }
@@ -1092,7 +1072,8 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  return CarveWorkspace(nullptr, nx, ny, nz, static_cast<vgt::EdtVariant>(variant)).bytes;
+  (void)variant;  // every variant runs in the same workspace
+  return CarveWorkspace(nullptr, nx, ny, nz).bytes;
 }
 
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,
@@ -1789,10 +1770,10 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
               "slab fix-up");
   VGT_TRY_HIP(timer.Mark(1, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[5], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.line_scratch, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
   VGT_TRY_HIP(timer.Mark(2, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[6], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.line_scratch, p, ctx->variant, s), "X pass");
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s), "X pass");
   VGT_TRY_HIP(timer.Mark(3, s), "event record");
   if (slot)
   {

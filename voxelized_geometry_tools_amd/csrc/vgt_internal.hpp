@@ -52,11 +52,11 @@ struct SlabLineCarry
   int16_t prev_filled, next_filled, prev_free, next_free;
 };
 
-// kDefault: LDS-tiled lower-envelope passes (stack + merge); kBruteForce: pruned outward search
-// straight from HBM (also the fallback for axes the tiled kernels do not cover); kLine: line sweep
-// with stacks in the workspace; kSweep: lane-per-line sweep with the stack tops in LDS (edt_sweep_kernels.hip).
-// All exact; 1 and 3 exist for cross-checking.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kLine = 3, kSweep = 4 };
+// kDefault: lane-per-line sweep passes, Felzenszwalb-Huttenlocher stacks with their tops in LDS
+// (edt_sweep_kernels.hip; any extent); kBruteForce: pruned outward search straight from HBM; kHull: LDS-tiled
+// lower-envelope passes (band hulls + merge, edt_hull_kernels.hip; axes up to 2048, longer ones fall back to the
+// pruned search).  All exact; 1 and 2 exist for cross-checking.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -73,24 +73,23 @@ hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int ra
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* line_scratch, const SdfParams& p,
+// `scratch`: SweepPassScratchBytes bytes (part of the SDF workspace).
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream);
 // X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
 // order-preserving encoding, must be pre-initialised by InitMinMax).
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               void* line_scratch, const SdfParams& p, EdtVariant variant,
+                               void* scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
-// The tiled line passes (edt_hull_kernels.hip), for callers that pipeline parts of a grid: true when the default
-// variant runs both line passes with the tiled kernel in Y-then-X order; the Y pass then treats X slices
-// independently (call LaunchPassY with nx = slices of a contiguous part), and the X pass can be launched over a
-// range of Y positions (full-grid pointers and extents in `p`).
-bool LinePassesAreTiled(const SdfParams& p);
-hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                                        const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
-                                        hipStream_t stream, bool* handled);
-// Scratch for the line-sweep passes (edt_line_kernels.hip).
-size_t LinePassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
-// Scratch for the lane-per-line sweep passes (edt_sweep_kernels.hip): spilled stack entries + sign words.
+// For callers that pipeline parts of a grid: the Y pass treats X slices independently (call LaunchPassY with nx =
+// slices of a contiguous part), and the X pass can be launched over a range of Y positions (full-grid pointers and
+// extents in `p`; outer_count < 0: the whole axis).  LinePassesTakeRanges: whether `variant` supports that for `p`.
+bool LinePassesTakeRanges(const SdfParams& p, EdtVariant variant);
+hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                    const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
+                                    hipStream_t stream);
+// Scratch for the lane-per-line sweep passes (edt_sweep_kernels.hip): work counter, spilled stack entries and sign
+// words of the workgroups in flight.
 size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
 hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
