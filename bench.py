@@ -5,10 +5,13 @@
 
 One "step" = one full ExtractSignedDistanceField<float> pass (Z scan, Y pass, X pass +
 finalize + min/max) over a synthetic occupancy grid that is already resident in HBM; the
-SDF is left in HBM.  N = 1 runs BASELINE config 4 (1024^3, distribution D1 "spheres", seed
-42, resolution 0.01).  N > 1 runs BASELINE config 5 (2048 x 2048 x 1024) partitioned into
-Z slabs, one process per GPU, with one RCCL exchange of per-line boundary summaries
-(voxelized_geometry_tools_amd/multi_gpu.py).  Rank 0 prints ONE JSON line.
+SDF is left in HBM.  Workloads (--workload): c4 = BASELINE config 4 (1024^3, distribution D1
+"spheres", seed 42, resolution 0.01), the headline and the default at N = 1; c5 = BASELINE
+config 5 (2048 x 2048 x 1024), the default at N > 1, where the grid is partitioned into Z slabs,
+one process per GPU, with one RCCL exchange of 4-byte per-line boundary summaries
+(voxelized_geometry_tools_amd/multi_gpu.py).  `--gpus 1 --workload c5` runs config 5 on one GPU
+(the reference point of the scaling series: an N > 1 line names it in `same_workload_one_gpu`).
+Rank 0 prints ONE JSON line.
 
 Launching: `python bench.py --gpus N` starts the N ranks itself (a `torch.distributed.run`
 child, started before this process touches the GPU) unless it already runs under a launcher
@@ -37,7 +40,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=0, help="cube edge for N=1 (default 1024)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c4", "c5"],
+                    help="c4 = 1024^3 (BASELINE config 4), c5 = 2048x2048x1024 (config 5); auto: c4 at N = 1, c5 at N > 1")
+    ap.add_argument("--size", type=int, default=0, help="cube edge instead of the workload's shape (experiments)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
     ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2 cross-check implementations)")
@@ -46,6 +51,7 @@ def parse_args():
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-raycast", action="store_true", help="skip the raycast voxelizer section (BASELINE config 3)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -85,18 +91,40 @@ def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=No
     return occ
 
 
-def profiled_traffic(kernel, default_workload):
+def profiled_traffic(kernel, default_workload, timed_kernel_ms):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, tools/collect_profiles.sh): counters cannot be read from inside this process."""
+    WRITE_SIZE, tools/collect_profiles.sh): counters cannot be read from inside this process.  The file
+    names the commit, the kernel and the kernel's duration it was collected with; the value is only
+    reported when the kernel timed in THIS run is within 5 % of that duration (else null)."""
     if not default_workload:
         return None, None
     path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_current.json")
     try:
         with open(path) as fh:
-            entry = json.load(fh)["kernels"][kernel]
-        return round(entry["hbm_bytes"] / 1e9, 3), "profiles/pmc_hbm_traffic_current.json (GB per launch)"
-    except (OSError, KeyError, ValueError):
+            doc = json.load(fh)
+        entry = doc["kernels"][kernel]
+        recorded_ms = float(entry["kernel_ns"]) * 1e-6
+        if recorded_ms <= 0 or abs(timed_kernel_ms - recorded_ms) > 0.05 * recorded_ms:
+            return None, "profiles/pmc_hbm_traffic_current.json is for a %.3f ms kernel (commit %s): not this build" % (
+                recorded_ms, doc.get("commit", "?"))
+        return round(entry["hbm_bytes"] / 1e9, 3), (
+            "profiles/pmc_hbm_traffic_current.json (GB per launch; commit %s, %s, %.3f ms)" % (
+                doc.get("commit", "?"), entry.get("kernel_name", kernel)[:60], recorded_ms))
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None
+
+
+def one_gpu_reference(workload_key):
+    """ms per step of the same workload on ONE GPU, from the committed bench line of that run (the scaling series'
+    reference point: the N = 1 default of this script is the c4 headline, not c5)."""
+    path = os.path.join(ROOT, "profiles", "bench_%s_one_gpu_current.json" % workload_key)
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+        return {"ms_per_step": doc["ms_per_step"], "source": "profiles/bench_%s_one_gpu_current.json" % workload_key,
+                "commit": doc.get("commit")}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(budget_s):
@@ -172,22 +200,76 @@ def end_to_end(ctx, torch, occ_dev, shape, res):
     del scratch
     occ_np = occ_pinned.numpy()
     out_np = out_pinned.numpy()
-    ctx.sdf_from_occupancy(occ_np, res, out=out_np)          # warm: the context allocates its cached buffers
+    # cold: what a first-time caller pays -- fresh pageable arrays (the output's pages never touched), a context
+    # without cached device buffers: page-locking both arrays, hipMalloc of in / out / workspace, then the pipeline
+    ctx.trim()
+    occ_cold = np.array(occ_np, copy=True)
+    out_cold = np.empty(shape, dtype=np.float32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.sdf_from_occupancy(occ_cold, res, out=out_cold)
+    cold = time.perf_counter() - t0
+    del occ_cold, out_cold
+    # page-locking alone: hipHostRegister + hipHostUnregister of one fresh pageable array of the grid's size
+    register_ms = None
+    try:
+        probe = np.empty(shape, dtype=np.float32)
+        probe[...] = 0.0
+        rt = torch.cuda.cudart()
+        t0 = time.perf_counter()
+        rc = rt.cudaHostRegister(probe.ctypes.data, probe.nbytes, 0)
+        t1 = time.perf_counter()
+        if int(rc) == 0:
+            rt.cudaHostUnregister(probe.ctypes.data)
+            register_ms = round((t1 - t0) * 1e3, 2)
+        del probe
+    except Exception:
+        register_ms = None
     pinned = timed(lambda: ctx.sdf_from_occupancy(occ_np, res, out=out_np))
     occ_pageable = np.array(occ_np, copy=True)
     out_pageable = np.zeros(shape, dtype=np.float32)         # zeros: pages touched before the timed call
+    ctx.sdf_from_occupancy(occ_pageable, res, out=out_pageable)
     pageable = timed(lambda: ctx.sdf_from_occupancy(occ_pageable, res, out=out_pageable))
     same = bool(np.array_equal(out_pageable.view(np.uint32), out_np.view(np.uint32)))
     ctx.trim()
     bound = h2d + d2h
     return {"end_to_end_ms": round(pageable * 1e3, 2), "end_to_end_pinned_ms": round(pinned * 1e3, 2),
+            "end_to_end_cold_ms": round(cold * 1e3, 2), "register_ms": register_ms,
             "pcie_lower_bound_ms": round(bound * 1e3, 2),
             "pcie_GBps": {"h2d": round(nbytes / h2d / 1e9, 1), "d2h": round(nbytes / d2h / 1e9, 1),
                           "end_to_end": round(2 * nbytes / pageable / 1e9, 1),
                           "end_to_end_pinned": round(2 * nbytes / pinned / 1e9, 1)},
             "vs_pcie_lower_bound": round(pinned / bound, 3), "host_results_identical": same,
-            "note": "host-pointer entry point: H2D, Z scan + Y pass per X chunk as it arrives, X pass per Y range, D2H per range (three streams); end_to_end_ms from pageable "
-                    "host memory (page-locked by the library for the call), end_to_end_pinned_ms from pinned memory"}
+            "note": "host-pointer entry point: H2D, Z scan + Y pass per X chunk as it arrives, X pass per Y range, D2H "
+                    "per range (three streams).  end_to_end_ms: warm call from pageable host memory (the library "
+                    "page-locks the two arrays per call; after one earlier call on the same arrays the pages are "
+                    "resident and the device buffers cached); end_to_end_pinned_ms: from pinned memory; "
+                    "end_to_end_cold_ms: FIRST call on fresh pageable arrays with no cached device buffers (page "
+                    "faults of the untouched output, page-locking, hipMalloc); register_ms: hipHostRegister of one "
+                    "fresh array of the grid's size alone"}
+
+
+def raycast_section():
+    """BASELINE config 3 in the driver-run line: the raycast kernel on clouds A and B (bench_raycast.measure: points
+    resident in HBM, counts checked bit for bit against the CPU oracle) and the voxelizer end to end through the C++
+    host layer (HipPointCloudVoxelizer::VoxelizePointClouds: upload of points and static grid, raycast, filter,
+    download) for 1, 2 and 8 concurrent clouds, measured by tests/cpp/bench_voxelize (a child process)."""
+    import subprocess
+    import bench_raycast
+    out = {"workload": "BASELINE config 3: 1M-point cloud -> 256^3 grid, max_range 3.0, every 100th point NaN",
+           "bytes_convention": "12 B/point + 8 B/visit (SURVEY 8d)"}
+    out.update(bench_raycast.measure(steps=5, warmup=2, check=True))
+    binary = os.path.join(ROOT, "tests", "cpp", "bench_voxelize")
+    if os.path.exists(binary):
+        try:
+            run = subprocess.run([binary], capture_output=True, text=True, timeout=120)
+            out["voxelize_end_to_end"] = json.loads(run.stdout.strip().splitlines()[-1]) if run.returncode == 0 else {
+                "error": (run.stdout + run.stderr)[-400:]}
+        except Exception as exc:
+            out["voxelize_end_to_end"] = {"error": repr(exc)}
+    else:
+        out["voxelize_end_to_end"] = {"error": "tests/cpp/bench_voxelize not built (make -C tests/cpp bench_voxelize)"}
+    return out
 
 
 def launch_ranks(args):
@@ -245,19 +327,19 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     res = 0.01
+    workload_key = args.workload if args.workload != "auto" else ("c5" if dist_on else "c4")
+    base_shape = (1024, 1024, 1024) if workload_key == "c4" else (2048, 2048, 1024)
+    full_shape = (args.size,) * 3 if args.size else base_shape
+    shape_text = "x".join(str(v) for v in full_shape) if len(set(full_shape)) > 1 else "%d^3" % full_shape[0]
     if not dist_on:
-        edge = args.size or 1024
-        full_shape = (edge, edge, edge)
         local_shape = full_shape
         z_offset = 0
-        workload = "%d^3 float SDF, D1 %s seed 42, res 0.01, device-resident" % (edge, args.dist)
+        workload = "%s float SDF, D1 %s seed 42, res 0.01, device-resident" % (shape_text, args.dist)
         parallelism = "single GPU"
     else:
         from voxelized_geometry_tools_amd import multi_gpu
-        full_shape = (2048, 2048, 1024) if not args.size else (args.size,) * 3
         local_shape, z_offset = multi_gpu.slab_of(full_shape, rank, world)
-        workload = "%dx%dx%d float SDF, D1 %s seed 42, res 0.01, Z-slab x%d, device-resident" % (
-            full_shape + (args.dist, world))
+        workload = "%s float SDF, D1 %s seed 42, res 0.01, Z-slab x%d, device-resident" % (shape_text, args.dist, world)
         parallelism = "zslab%d" % world
 
     occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape, args.salt_p)
@@ -271,11 +353,17 @@ def main():
     if dist_on:
         runner = multi_gpu.SlabSdf(ctx, torch, dist, full_shape, rank, world, device)
 
-    def step():
+    phase_events = []  # per timed step: 4 events (start, scan done, exchange done, end)
+
+    def step(record=False):
         if not dist_on:
             ctx.sdf_dev(occ.data_ptr(), local_shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes, minmax.data_ptr())
         else:
-            runner.run(occ, sdf, ws, minmax, res)
+            events = None
+            if record:
+                events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                phase_events.append(events)
+            runner.run(occ, sdf, ws, minmax, res, events=events)
 
     def fence():
         torch.cuda.synchronize()
@@ -291,7 +379,7 @@ def main():
     ctx.timing_start(args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(record=True)
     fence()
     elapsed = time.perf_counter() - t0
     per_step_ms = ctx.timing_stop()
@@ -305,6 +393,19 @@ def main():
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kernel_sum = kt.cpu().numpy()
 
+    phase_ms = None
+    if dist_on and phase_events:
+        # whole-step phases from the stream's events; the last interval is split with the library's kernel events
+        # (fix-up / Y / X), the remainder being the carry kernel, the extrema all-reduce and launch gaps
+        steps = float(len(phase_events))
+        scan = sum(e[0].elapsed_time(e[1]) for e in phase_events) / steps
+        exchange = sum(e[1].elapsed_time(e[2]) for e in phase_events) / steps
+        rest = sum(e[2].elapsed_time(e[3]) for e in phase_events) / steps
+        ky, kx = kernel_sum[1] / steps, kernel_sum[2] / steps
+        pt = torch.tensor([scan, exchange, max(rest - ky - kx, 0.0), ky, kx], dtype=torch.float64, device=device)
+        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+        phase_ms = {k: round(float(v), 4) for k, v in zip(multi_gpu.SlabSdf.PHASES, pt.cpu().numpy())}
+
     total_vox = float(np.prod(full_shape))
     ms_per_step = elapsed / args.steps * 1e3
     value = total_vox / (elapsed / args.steps) / 1e6
@@ -316,16 +417,18 @@ def main():
     mm = minmax.cpu().numpy()
 
     if rank == 0:
-        traffic, traffic_src = profiled_traffic(
-            KERNEL_NAMES[dom], not dist_on and not args.size and args.dist == "spheres" and args.variant == 0)
+        headline = not dist_on and not args.size and workload_key == "c4" and args.dist == "spheres" and args.variant == 0
+        traffic, traffic_src = profiled_traffic(KERNEL_NAMES[dom], headline, float(avg_ms[dom]))
         line = {
             "metric": "Mvoxels/s for %s float SDF extract @%d GPU%s; %% HBM roofline%s" % (
-                "x".join(str(v) for v in full_shape) if len(set(full_shape)) > 1 else "%d^3" % full_shape[0],
-                world, "" if world == 1 else "s", " (per device, slowest rank)" if dist_on else ""),
+                shape_text, world, "" if world == 1 else "s", " (per device, slowest rank)" if dist_on else ""),
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            # N > 1: the SAME grid (config 5) cut into more slabs = strong scaling, against the one-GPU run of that
+            # grid named in same_workload_one_gpu -- never against the N = 1 default of this script (config 4)
             "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload, "shape": list(full_shape), "parallelism": parallelism,
+            "config": {"workload": workload, "workload_key": workload_key if not args.size else "custom",
+                       "shape": list(full_shape), "parallelism": parallelism,
                        "edt_variant": args.variant, "sdf_min_max": [float(mm[0]), float(mm[1])]},
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -336,7 +439,18 @@ def main():
                          "whole_sdf_frac": round(whole / HBM_PEAK_GBPS, 4),
                          "algorithmic_bytes_per_voxel": {"per_pass": 8, "whole_sdf": 24}},
         }
-        if not dist_on and not args.no_end_to_end:
+        if dist_on:
+            line["phase_ms"] = phase_ms
+            line["exchange"] = {"collective": "all_gather_into_tensor", "record_bytes_per_line": 4,
+                                "bytes_received_per_rank": runner.exchange_bytes_received}
+            if not args.size:
+                line["same_workload_one_gpu"] = one_gpu_reference(workload_key)
+        if headline and not args.no_raycast:
+            try:
+                line["raycast"] = raycast_section()
+            except Exception as exc:
+                line["raycast"] = {"error": repr(exc)}
+        if not dist_on and not args.no_end_to_end and workload_key == "c4":
             try:
                 line["host_path"] = end_to_end(ctx, torch, occ, local_shape, res)
             except Exception as exc:  # the headline number must not depend on host RAM for pinned buffers

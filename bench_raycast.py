@@ -20,39 +20,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--points", type=int, default=1_000_000)
-    ap.add_argument("--grid", type=int, default=256)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--threads-per-block", type=int, default=-1, help="HIP_THREADS_PER_BLOCK of the helper (-1 = default)")
-    args = ap.parse_args()
+def measure(points=1_000_000, grid=256, steps=10, warmup=3, check=True, threads_per_block=-1, ctx=None):
+    """-> {"A_inside": {...}, "B_outside": {...}}: per cloud the raycast time (points resident in HBM), visits, rates and,
+    with `check`, whether every tracking count equals the CPU oracle's."""
     import torch
     from voxelized_geometry_tools_amd import capi, synthetic
 
-    n = args.grid
+    n = grid
     counts = (n, n, n)
     vs = np.float32(5.12 / n)
     ivs = np.float32(1.0) / vs
     sizes = [np.float32(c) * vs for c in counts]
-    pts = synthetic.raycast_cloud(args.points, seed=42)
+    pts = synthetic.raycast_cloud(points, seed=42)
     env = np.zeros(counts, dtype=np.float32)
     env[:, :, 0] = 1.0
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", torch.cuda.current_device())
     pts_dev = torch.from_numpy(pts).to(dev)
-    ctx = capi.Context(0, args.threads_per_block)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = capi.Context(0, threads_per_block)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     out = {}
     for name, sensor in (("A_inside", (2.56, 2.56, 2.56)), ("B_outside", (-1.0, 2.56, 2.56))):
         xf = synthetic.translation_xform(*sensor).astype(np.float32)
         grids = ctx.tracking_grids(n ** 3, 1)
 
         def step():
-            grids.raycast_f32_dev(0, pts_dev.data_ptr(), args.points, 3.0, xf, vs, ivs, sizes, counts)
+            grids.raycast_f32_dev(0, pts_dev.data_ptr(), points, 3.0, xf, vs, ivs, sizes, counts)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         grids.clear()
         torch.cuda.synchronize()
@@ -67,10 +63,10 @@ def main():
         grids.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        ms = (time.perf_counter() - t0) / steps * 1e3
         fg = ctx.filter_grid(env)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -78,23 +74,38 @@ def main():
         ctx.synchronize()
         filter_ms = (time.perf_counter() - t0) * 1e3
         entry = {"raycast_ms": round(ms, 4), "first_call_ms": round(single_ms, 4),
-                 "Mpoints_per_s": round(args.points / ms / 1e3, 1),
+                 "Mpoints_per_s": round(points / ms / 1e3, 1),
                  "Mvisits_per_s": round(visits / ms / 1e3, 1), "visits": visits,
                  "filter_ms": round(filter_ms, 4),
                  # algorithmic bytes: 12 B/point + 8 B/visit (4-byte atomic RMW), SURVEY.md 8d
-                 "achieved_GBps": round((12.0 * args.points + 8.0 * visits) / (ms * 1e-3) / 1e9, 1)}
-        if not args.no_check:
+                 "achieved_GBps": round((12.0 * points + 8.0 * visits) / (ms * 1e-3) / 1e9, 1)}
+        if check:
             from oracle import oracle as O
             t0 = time.perf_counter()
             want = O.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
             cpu_s = time.perf_counter() - t0
             entry["counts_bit_exact"] = bool(np.array_equal(got, want))
-            entry["cpu_oracle_Mpoints_per_s"] = round(args.points / cpu_s / 1e6, 2)
+            entry["cpu_oracle_Mpoints_per_s"] = round(points / cpu_s / 1e6, 2)
             entry["cpu_threads"] = O.max_threads()
         out[name] = entry
         grids.close()
-    print(json.dumps({"metric": "Mpoints/s, 1M-point cloud -> %d^3 occupancy, HIP DDA raycast" % n,
-                      "config": {"workload": "BASELINE config 3", "points": args.points, "grid": n},
+    if own_ctx:
+        ctx.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--threads-per-block", type=int, default=-1, help="HIP_THREADS_PER_BLOCK of the helper (-1 = default)")
+    args = ap.parse_args()
+    out = measure(args.points, args.grid, args.steps, args.warmup, not args.no_check, args.threads_per_block)
+    print(json.dumps({"metric": "Mpoints/s, 1M-point cloud -> %d^3 occupancy, HIP DDA raycast" % args.grid,
+                      "config": {"workload": "BASELINE config 3", "points": args.points, "grid": args.grid},
                       "results": out}))
 
 

@@ -326,27 +326,32 @@ int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, in
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
  * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest
  * filled / free voxel below and above.  So:
- *   1. vgt_hip_sdf_slab_begin_dev   local Z scan + per-line summary of this slab
- *                                    (4 x int16 per line: global z of the first / last filled and
- *                                    first / last free voxel, -1 when absent)
+ *   1. vgt_hip_sdf_slab_begin_dev   local Z scan + per-line summary of this slab: 4 bytes per line.  A slab's
+ *                                    first voxel is filled or free, so the record holds, for the slab's first and
+ *                                    for its last voxel, the class (bit 15: filled) and the global z of the first /
+ *                                    last voxel of the OTHER class inside the slab (bits 0-14, 0x7fff when absent)
  *   2. the caller all-gathers the summaries (one RCCL all-gather; torch.distributed in
  *      voxelized_geometry_tools_amd/multi_gpu.py) into [world][lines] records and
  *      vgt_hip_sdf_slab_carries_dev reduces them to this slab's per-line carries
  *      (4 x int16: prev_filled, next_filled, prev_free, next_free as global z, -1 when absent)
  *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
+ * The slabs must be the ranges of vgt_hip_sdf_slab_range (equal shares of nz_global, earlier slabs take the
+ * remainder): the carries are decoded with them.
  * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
  * in both calls.  kernel_ms (optional): begin -> [scan]; finish -> [fix-up, Y pass, X pass];
  * when given, the call blocks until the work has finished.
- * Limits: summaries and carries hold GLOBAL z as int16, so the whole grid's Z extent (nz_global,
+ * Limits: summaries and carries hold GLOBAL z in 15 / 16 bits, so the whole grid's Z extent (nz_global,
  * and z_offset + nz_local of every slab) must not exceed 16384 -- the per-axis limit of every SDF
  * entry point; larger values are rejected with VGT_HIP_ERR_INVALID_ARGUMENT. */
+int vgt_hip_sdf_slab_range(int64_t nz_global, int32_t world, int32_t rank, int64_t* z_offset, int64_t* nz_local);
 size_t vgt_hip_sdf_slab_summary_bytes(int64_t nx, int64_t ny);
 int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                                int64_t nz_local, int64_t z_offset, int unknown_is_filled,
                                void* workspace_dev, size_t workspace_bytes, void* summary_dev,
                                float* kernel_ms);
+size_t vgt_hip_sdf_slab_carries_bytes(int64_t nx, int64_t ny);
 int vgt_hip_sdf_slab_carries_dev(vgt_hip_ctx* ctx, const void* gathered_summaries_dev, int32_t world,
-                                 int32_t rank, int64_t nx, int64_t ny, void* carries_dev);
+                                 int32_t rank, int64_t nx, int64_t ny, int64_t nz_global, void* carries_dev);
 int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_t nz_local,
                                 int64_t z_offset, int64_t nz_global, double resolution,
                                 int add_virtual_border, const void* carries_dev, float* sdf_dev,

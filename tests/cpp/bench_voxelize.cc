@@ -1,0 +1,140 @@
+// End-to-end timing of the voxelizer through the C++ host layer, for bench.py's `raycast` section:
+// HipPointCloudVoxelizer::VoxelizePointClouds (csrc/host/hip_pointcloud_voxelizer.cc, the restatement of
+// DevicePointCloudVoxelizer::DoVoxelizePointClouds, device_pointcloud_voxelization.cpp:65-181) on BASELINE config 3:
+// a 256^3 static grid (floor filled), clouds of 1M points (unit directions x range in [0.5, 4] m, max_range 3, every
+// 100th point NaN, sensor at the grid centre), filter (1.0, 1, 1) -- upload of the static grid and of every cloud,
+// raycast, filter, download -- for 1, 2 and 8 clouds dispatched in parallel as the reference does.  Prints one JSON
+// line.  The clouds hand their points over as one strided FLOAT32 buffer (PointCloud2 layout) and, for
+// comparison, through the per-point virtual copy of the plain PointCloudWrapper interface.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <random>
+
+#include "../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
+
+using namespace vgt_hip;
+namespace hip_helpers = voxelized_geometry_tools::pointcloud_voxelization::hip_helpers;
+
+namespace
+{
+class BufferCloud : public PointCloudWrapper
+{
+public:
+  BufferCloud(int64_t points, uint64_t seed, bool strided) : strided_(strided)
+  {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    xyz_.resize(static_cast<size_t>(points) * 3);
+    for (int64_t i = 0; i < points; i++)
+    {
+      const double zc = 2.0 * uni(rng) - 1.0, phi = 2.0 * M_PI * uni(rng), s = std::sqrt(std::max(0.0, 1.0 - zc * zc));
+      const double range = 0.5 + 3.5 * uni(rng);
+      float* p = &xyz_[static_cast<size_t>(i) * 3];
+      p[0] = static_cast<float>(s * std::cos(phi) * range);
+      p[1] = static_cast<float>(s * std::sin(phi) * range);
+      p[2] = static_cast<float>(zc * range);
+      if (i % 100 == 0) p[0] = p[1] = p[2] = std::numeric_limits<float>::quiet_NaN();
+    }
+    origin_ = Isometry3::Translation(2.56, 2.56, 2.56);
+  }
+  double MaxRange() const override { return 3.0; }
+  int64_t Size() const override { return static_cast<int64_t>(xyz_.size() / 3); }
+  const Isometry3& PointCloudOriginTransform() const override { return origin_; }
+  bool StridedFloat32Layout(const uint8_t** data, int64_t* point_step, int64_t* xyz_offset) const override
+  {
+    if (!strided_) return false;
+    *data = reinterpret_cast<const uint8_t*>(xyz_.data());
+    *point_step = 12;
+    *xyz_offset = 0;
+    return true;
+  }
+
+private:
+  void CopyPointLocationIntoFloatPtrImpl(int64_t i, float* dst) const override
+  {
+    for (int a = 0; a < 3; a++) dst[a] = xyz_[static_cast<size_t>(i) * 3 + a];
+  }
+  std::vector<float> xyz_;
+  Isometry3 origin_;
+  bool strided_;
+};
+
+double TimeOnce(const HipPointCloudVoxelizer& voxelizer, const OccupancyMap& env,
+                const std::vector<PointCloudWrapperSharedPtr>& clouds, double* raycast_s, double* filter_s)
+{
+  const PointCloudVoxelizationFilterOptions filter_options(1.0, 1, 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  const OccupancyMap out = voxelizer.VoxelizePointClouds(env, filter_options, clouds, [&](const VoxelizerRuntime& rt) {
+    *raycast_s = rt.RaycastingTime();
+    *filter_s = rt.FilteringTime();
+  });
+  const auto t1 = std::chrono::steady_clock::now();
+  if (out.NumXVoxels() != env.NumXVoxels()) std::printf("unexpected output\n");
+  return std::chrono::duration<double>(t1 - t0).count();
+}
+}  // namespace
+
+int main()
+{
+  try
+  {
+    const auto devices = hip_helpers::GetAvailableDevices();
+    if (devices.empty())
+    {
+      std::printf("{\"error\": \"no HIP device\"}\n");
+      return 1;
+    }
+    std::map<std::string, int32_t> options = devices[0].DeviceOptions();
+    options["DISPATCH_PARALLELIZE"] = 1;
+    options["DISPATCH_NUM_THREADS"] = 8;
+    const HipPointCloudVoxelizer voxelizer(options);
+    OccupancyMap env = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.02, 5.12, 5.12, 5.12, 0.0f);
+    for (int64_t x = 0; x < env.NumXVoxels(); x++)
+      for (int64_t y = 0; y < env.NumYVoxels(); y++) env.SetIndex(x, y, 0, 1.0f);
+    std::vector<PointCloudWrapperSharedPtr> strided, gathered;
+    for (int c = 0; c < 8; c++)
+    {
+      strided.push_back(std::make_shared<BufferCloud>(1000000, 42 + c, true));
+      gathered.push_back(std::make_shared<BufferCloud>(1000000, 42 + c, false));
+    }
+    std::printf("{\"grid\": [%lld, %lld, %lld], \"points_per_cloud\": 1000000, \"dispatch_threads\": 8, \"clouds\": {",
+                static_cast<long long>(env.NumXVoxels()), static_cast<long long>(env.NumYVoxels()),
+                static_cast<long long>(env.NumZVoxels()));
+    bool first = true;
+    for (const int n : {1, 2, 8})
+    {
+      double best[2] = {1e30, 1e30}, ray[2] = {0, 0}, fil[2] = {0, 0};
+      for (int kind = 0; kind < 2; kind++)
+      {
+        const auto& all = kind == 0 ? strided : gathered;
+        const std::vector<PointCloudWrapperSharedPtr> clouds(all.begin(), all.begin() + n);
+        for (int rep = 0; rep < 3; rep++)  // the first call also allocates the helper's device buffers
+        {
+          double r = 0, f = 0;
+          const double t = TimeOnce(voxelizer, env, clouds, &r, &f);
+          if (t < best[kind])
+          {
+            best[kind] = t;
+            ray[kind] = r;
+            fil[kind] = f;
+          }
+        }
+      }
+      std::printf("%s\"%d\": {\"voxelize_end_to_end_ms\": %.3f, \"raycast_phase_ms\": %.3f, \"filter_phase_ms\": %.3f, "
+                  "\"per_point_copy_interface_ms\": %.3f}",
+                  first ? "" : ", ", n, best[0] * 1e3, ray[0] * 1e3, fil[0] * 1e3, best[1] * 1e3);
+      first = false;
+    }
+    std::printf("}, \"note\": \"best of 3; voxelize_end_to_end_ms = VoxelizePointClouds with clouds handed over as one strided "
+                "FLOAT32 buffer (H2D of points and static grid, raycast, filter, D2H of the 64 MiB grid); "
+                "per_point_copy_interface_ms = the same through CopyPointLocationIntoFloatPtr point by point\"}\n");
+    return 0;
+  }
+  catch (const std::exception& ex)
+  {
+    std::printf("{\"error\": \"%s\"}\n", ex.what());
+    return 1;
+  }
+}

@@ -450,29 +450,27 @@ def test_deferred_kernel_timing(ctx):
 
 
 def test_slab_carry_kernel_matches_torch_reduction(ctx):
-    """vgt_hip_sdf_slab_carries_dev vs multi_gpu.carries_from_summaries (the torch restatement the gloo tests use)."""
+    """vgt_hip_sdf_slab_carries_dev vs multi_gpu.carries_from_summaries (the torch restatement the gloo tests use), on
+    packed 4-byte summaries of random slabs with an uneven split (203 = 5 x 40 + 3)."""
     import torch
     from voxelized_geometry_tools_amd import multi_gpu
     rng = np.random.default_rng(17)
-    world, nx, ny = 5, 23, 31
+    world, nx, ny, nz = 5, 23, 31, 203
     lines = nx * ny
-    summaries = np.full((world, lines, 4), -1, dtype=np.int16)
+    filled = rng.random((nx, ny, nz)) < 0.02
+    filled[rng.random((nx, ny)) < 0.3] = False          # many lines without any filled voxel
+    filled[rng.random((nx, ny)) < 0.05] = True          # some without any free one
+    records = []
     for r in range(world):
-        z0 = r * 40
-        for col_first, col_last in ((multi_gpu.FIRST_FILLED, multi_gpu.LAST_FILLED),
-                                    (multi_gpu.FIRST_FREE, multi_gpu.LAST_FREE)):
-            has = rng.random(lines) < 0.6
-            a = rng.integers(0, 40, size=lines)
-            b = rng.integers(0, 40, size=lines)
-            summaries[r, :, col_first] = np.where(has, z0 + np.minimum(a, b), -1)
-            summaries[r, :, col_last] = np.where(has, z0 + np.maximum(a, b), -1)
-    gathered = torch.from_numpy(summaries).cuda()
+        local_shape, z0 = multi_gpu.slab_of((nx, ny, nz), r, world)
+        records.append(multi_gpu.summary_reference(filled[:, :, z0:z0 + local_shape[2]], z0))
+    gathered = torch.from_numpy(np.stack(records)).cuda()
     ctx.set_stream(None)
     try:
         for rank in range(world):
-            want = multi_gpu.carries_from_summaries(torch, gathered, rank)
+            want = multi_gpu.carries_from_summaries(torch, gathered, rank, nz)
             got = torch.empty((lines, 4), dtype=torch.int16, device="cuda")
-            ctx.sdf_slab_carries(gathered.data_ptr(), world, rank, nx, ny, got.data_ptr())
+            ctx.sdf_slab_carries(gathered.data_ptr(), world, rank, nx, ny, nz, got.data_ptr())
             torch.cuda.synchronize()
             assert torch.equal(got, want), rank
     finally:

@@ -51,7 +51,8 @@ def _worker(rank, world, port, shape, seed, queue):
         local_shape, z0 = multi_gpu.slab_of(shape, rank, world)
         local = filled[:, :, z0:z0 + local_shape[2]]
         summary = torch.from_numpy(multi_gpu.summary_reference(local, z0))
-        carries = multi_gpu.exchange_carries(torch, dist, summary, rank, world).numpy()
+        assert summary.shape == (shape[0] * shape[1], 2)  # 4 bytes per line
+        carries = multi_gpu.exchange_carries(torch, dist, summary, rank, world, shape[2]).numpy()
         # fold the carries into the slab-local distances exactly as SlabFixupKernel does
         d_local = _z_distance_reference(local)
         zg = np.arange(z0, z0 + local_shape[2])[None, None, :]
@@ -104,13 +105,46 @@ def test_slab_bounds_and_carries():
     assert multi_gpu.slab_of((2, 3, 1024), 5, 8) == ((2, 3, 128), 640)
     with pytest.raises(ValueError):
         multi_gpu.slab_of((2, 2, 2), 2, 3)
-    # two lines, three slabs: [first_filled, last_filled, first_free, last_free]
-    g = torch.tensor([[[3, 5, 0, 9], [-1, -1, 0, 9]],
-                      [[-1, -1, 10, 19], [12, 12, 10, 19]],
-                      [[25, 29, 20, 28], [-1, -1, 20, 29]]], dtype=torch.int16)
-    c1 = multi_gpu.carries_from_summaries(torch, g, 1).tolist()
+    # two lines, three slabs of 10 voxels; per slab (first_filled, last_filled, first_free, last_free) is
+    #   line 0: (3, 5, 0, 9) | (-, -, 10, 19) | (25, 29, 20, 28)      line 1: (-, -, 0, 9) | (12, 12, 10, 19) | (-, -, 20, 29)
+    # as packed records (class bit of the first / last voxel, position of the first / last voxel of the other class)
+    F, N = multi_gpu.FILLED_BIT, multi_gpu.OTHER_NONE
+    g = torch.tensor([[[3, 5], [N, N]],
+                      [[N, N], [12, 12]],
+                      [[25, F | 28], [N, N]]], dtype=torch.int32).to(torch.int16)
+    full = multi_gpu.decode_summaries(torch, g, 30).tolist()
+    assert full[0] == [[3, 5, 0, 9], [-1, -1, 0, 9]]
+    assert full[1] == [[-1, -1, 10, 19], [12, 12, 10, 19]]
+    assert full[2] == [[25, 29, 20, 28], [-1, -1, 20, 29]]
+    c1 = multi_gpu.carries_from_summaries(torch, g, 1, 30).tolist()
     assert c1 == [[5, 25, 9, 20], [-1, -1, 9, 20]]
-    c0 = multi_gpu.carries_from_summaries(torch, g, 0).tolist()
+    c0 = multi_gpu.carries_from_summaries(torch, g, 0, 30).tolist()
     assert c0 == [[-1, 25, -1, 10], [-1, 12, -1, 10]]
-    c2 = multi_gpu.carries_from_summaries(torch, g, 2).tolist()
+    c2 = multi_gpu.carries_from_summaries(torch, g, 2, 30).tolist()
     assert c2 == [[5, -1, 19, -1], [12, -1, 19, -1]]
+
+
+def test_summary_reference_packs_both_classes():
+    """The 4-byte record against the plain four-value summary on random slabs (uneven splits included)."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    rng = np.random.default_rng(5)
+    shape, world = (4, 5, 23), 4
+    filled = rng.random(shape) < 0.2
+    filled[0, 0, :] = True
+    filled[1, 1, :] = False
+    records = []
+    for r in range(world):
+        local_shape, z0 = multi_gpu.slab_of(shape, r, world)
+        records.append(torch.from_numpy(multi_gpu.summary_reference(filled[:, :, z0:z0 + local_shape[2]], z0)))
+    full = multi_gpu.decode_summaries(torch, torch.stack(records), shape[2]).numpy()
+    z = np.arange(shape[2])
+    for r, (z0, z1) in enumerate(multi_gpu.slab_bounds(shape[2], world)):
+        local = filled[:, :, z0:z1].reshape(-1, z1 - z0)
+        zz = z[z0:z1]
+        for col, mask, first in ((0, local, True), (1, local, False), (2, ~local, True), (3, ~local, False)):
+            if first:
+                want = np.where(mask.any(axis=1), np.where(mask, zz, 10 ** 6).min(axis=1), -1)
+            else:
+                want = np.where(mask.any(axis=1), np.where(mask, zz, -1).max(axis=1), -1)
+            assert np.array_equal(full[r, :, col], want), (r, col)

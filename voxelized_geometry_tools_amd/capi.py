@@ -81,11 +81,14 @@ SIGNATURES = {
                                           _int, _p, _p, _p]),
     "vgt_hip_sdf_coarse_gradient_dev": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                               ctypes.c_double, _int, _p, _p, _p]),
-    "vgt_hip_sdf_slab_carries_dev": (_int, [_p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, _p]),
+    "vgt_hip_sdf_slab_carries_dev": (_int, [_p, _p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, _p]),
     "vgt_hip_timing_start": (_int, [_p, ctypes.c_int32]),
     "vgt_hip_timing_stop": (_int, [_p, _p, _p]),
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
+    "vgt_hip_sdf_slab_carries_bytes": (_sz, [_i64, _i64]),
+    "vgt_hip_sdf_slab_range": (_int, [_i64, ctypes.c_int32, ctypes.c_int32, _p, _p]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
     "vgt_hip_sdf_slab_finish_dev": (_int, [_p, _i64, _i64, _i64, _i64, _i64, _f64, _int, _p, _p, _p,
                                            _sz, _p, _p]),
@@ -326,9 +329,9 @@ class Context:
             self.handle, _ptr(occ_ptr), nx, ny, nz, int(z_offset), int(bool(unknown_is_filled)),
             _ptr(ws_ptr), ws_bytes, _ptr(summary_ptr), _ptr(kernel_ms)))
 
-    def sdf_slab_carries(self, gathered_ptr, world, rank, nx, ny, carries_ptr):
+    def sdf_slab_carries(self, gathered_ptr, world, rank, nx, ny, nz_global, carries_ptr):
         check(self._lib.vgt_hip_sdf_slab_carries_dev(self.handle, _ptr(gathered_ptr), int(world), int(rank),
-                                                     int(nx), int(ny), _ptr(carries_ptr)))
+                                                     int(nx), int(ny), int(nz_global), _ptr(carries_ptr)))
 
     def sdf_slab_finish(self, local_shape, z_offset, nz_global, resolution, carries_ptr, sdf_ptr,
                         ws_ptr, ws_bytes, minmax_ptr=None, add_virtual_border=False,

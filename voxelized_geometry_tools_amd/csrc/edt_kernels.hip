@@ -37,6 +37,16 @@ __device__ __forceinline__ bool IsFilled(float occupancy, int unknown_is_filled)
 }
 __device__ __forceinline__ bool IsFilled(uint8_t mask, int) { return mask != 0; }
 
+// Slab summary halves (vgt_internal.hpp): `boundary` = slab-local z of the slab's first (last) voxel, at_filled /
+// at_free = slab-local z of the first (last) voxel of each class, -1 when absent.
+__device__ __forceinline__ uint16_t SummaryHalf(int at_filled, int at_free, int boundary, int z_offset)
+{
+  const bool filled = at_filled == boundary;
+  const int other = filled ? at_free : at_filled;
+  return static_cast<uint16_t>((filled ? kSlabFilledBit : 0u) |
+                               (other < 0 ? kSlabNone : static_cast<uint16_t>(other + z_offset)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pass 1: one wave per Z line.  Each 64-voxel chunk becomes one ballot mask; a voxel's distance
 // to the nearest voxel of the other class is a clz/ffs on that mask, falling back to the nearest
@@ -93,11 +103,7 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
         if (F) nf = c * kWave + (__ffsll(static_cast<long long>(F)) - 1);
         if (E) ne = c * kWave + (__ffsll(static_cast<long long>(E)) - 1);
       }
-      if (summary)
-      {
-        summary[line].first_filled = static_cast<int16_t>(nf < 0 ? -1 : nf + z_offset);
-        summary[line].first_free = static_cast<int16_t>(ne < 0 ? -1 : ne + z_offset);
-      }
+      if (summary) summary[line].first = SummaryHalf(nf, ne, 0, z_offset);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -133,11 +139,7 @@ __global__ __launch_bounds__(kScanBlock) void ScanZKernel(const InT* __restrict_
       if (F) prev_filled = c * kWave + (63 - __clzll(static_cast<long long>(F)));
       if (E) prev_free = c * kWave + (63 - __clzll(static_cast<long long>(E)));
     }
-    if (summary && lane == 0)
-    {
-      summary[line].last_filled = static_cast<int16_t>(prev_filled < 0 ? -1 : prev_filled + z_offset);
-      summary[line].last_free = static_cast<int16_t>(prev_free < 0 ? -1 : prev_free + z_offset);
-    }
+    if (summary && lane == 0) summary[line].last = SummaryHalf(prev_filled, prev_free, nz - 1, z_offset);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -214,10 +216,8 @@ __global__ __launch_bounds__(kScanBlock) void ScanZUnrolledKernel(
     if (summary && lane == 0)
     {
       SlabLineSummary out_summary;
-      out_summary.first_filled = static_cast<int16_t>(nf < 0 ? -1 : nf + z_offset);
-      out_summary.last_filled = static_cast<int16_t>(prev_filled < 0 ? -1 : prev_filled + z_offset);
-      out_summary.first_free = static_cast<int16_t>(ne < 0 ? -1 : ne + z_offset);
-      out_summary.last_free = static_cast<int16_t>(prev_free < 0 ? -1 : prev_free + z_offset);
+      out_summary.first = SummaryHalf(nf, ne, 0, z_offset);
+      out_summary.last = SummaryHalf(prev_filled, prev_free, nz - 1, z_offset);
       summary[line] = out_summary;
     }
   }
@@ -390,10 +390,8 @@ __global__ __launch_bounds__(kScanBlock) void ScanZTransitionKernel(
       if (lane == 0)
       {
         SlabLineSummary out_summary;
-        out_summary.first_filled = static_cast<int16_t>(ff < 0 ? -1 : ff + z_offset);
-        out_summary.last_filled = static_cast<int16_t>(lf < 0 ? -1 : lf + z_offset);
-        out_summary.first_free = static_cast<int16_t>(fe < 0 ? -1 : fe + z_offset);
-        out_summary.last_free = static_cast<int16_t>(le < 0 ? -1 : le + z_offset);
+        out_summary.first = SummaryHalf(ff, fe, 0, z_offset);
+        out_summary.last = SummaryHalf(lf, le, nz - 1, z_offset);
         summary[line] = out_summary;
       }
     }
@@ -424,27 +422,36 @@ __global__ __launch_bounds__(256) void SlabFixupKernel(int16_t* __restrict__ io,
 }
 
 // Multi-GPU: per-line carries of slab `rank` from the gathered summaries of all slabs
-// (summaries[slab][line]): nearest filled / free voxel below = largest last_* of the slabs
-// before it, above = smallest first_* of the slabs after it (-1 when absent).
+// (summaries[slab][line], 4 bytes each, see vgt_internal.hpp): nearest filled / free voxel below = the last such
+// voxel of the nearest lower slab that has one, above = the first such voxel of the nearest upper slab (-1 when
+// absent).  A slab's first (last) voxel of one class is its first (last) voxel; where that is follows from SlabRange.
 __global__ __launch_bounds__(256) void SlabCarriesKernel(const SlabLineSummary* __restrict__ summaries,
-                                                        int world, int rank, int64_t lines,
+                                                        int world, int rank, int64_t lines, int nz_global,
                                                         SlabLineCarry* __restrict__ carries)
 {
+  const int share = nz_global / world, extra = nz_global % world;
   for (int64_t line = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; line < lines;
        line += static_cast<int64_t>(gridDim.x) * blockDim.x)
   {
     int prev_filled = -1, prev_free = -1, next_filled = -1, next_free = -1;
     for (int r = 0; r < rank; r++)
     {
-      const SlabLineSummary s = summaries[static_cast<int64_t>(r) * lines + line];
-      prev_filled = max(prev_filled, static_cast<int>(s.last_filled));
-      prev_free = max(prev_free, static_cast<int>(s.last_free));
+      const uint16_t rec = summaries[static_cast<int64_t>(r) * lines + line].last;
+      const int end = (r + 1) * share + min(r + 1, extra) - 1;  // the slab's last voxel
+      const int other = (rec & kSlabNone) == kSlabNone ? -1 : static_cast<int>(rec & kSlabNone);
+      const bool filled = (rec & kSlabFilledBit) != 0;
+      prev_filled = max(prev_filled, filled ? end : other);
+      prev_free = max(prev_free, filled ? other : end);
     }
     for (int r = world - 1; r > rank; r--)
     {
-      const SlabLineSummary s = summaries[static_cast<int64_t>(r) * lines + line];
-      if (s.first_filled >= 0) next_filled = s.first_filled;
-      if (s.first_free >= 0) next_free = s.first_free;
+      const uint16_t rec = summaries[static_cast<int64_t>(r) * lines + line].first;
+      const int begin = r * share + min(r, extra);  // the slab's first voxel
+      const int other = (rec & kSlabNone) == kSlabNone ? -1 : static_cast<int>(rec & kSlabNone);
+      const bool filled = (rec & kSlabFilledBit) != 0;
+      const int first_filled = filled ? begin : other, first_free = filled ? other : begin;
+      if (first_filled >= 0) next_filled = first_filled;
+      if (first_free >= 0) next_free = first_free;
     }
     SlabLineCarry c;
     c.prev_filled = static_cast<int16_t>(prev_filled);
@@ -701,11 +708,11 @@ hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
   return hipGetLastError();
 }
 
-hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines,
+hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines, int64_t nz_global,
                              SlabLineCarry* carries, hipStream_t stream)
 {
   hipLaunchKernelGGL(SlabCarriesKernel, dim3(GridFor(lines, 256)), dim3(256), 0, stream, summaries, world, rank,
-                     lines, carries);
+                     lines, static_cast<int>(nz_global), carries);
   return hipGetLastError();
 }
 

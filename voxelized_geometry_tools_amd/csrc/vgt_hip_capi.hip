@@ -1724,17 +1724,33 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
   return timer.Finish(ctx->stream, kernel_ms, 1);
 }
 
+int vgt_hip_sdf_slab_range(int64_t nz_global, int32_t world, int32_t rank, int64_t* z_offset, int64_t* nz_local)
+{
+  if (!z_offset || !nz_local) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (nz_global <= 0 || world <= 0 || world > nz_global || rank < 0 || rank >= world)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid slab partition");
+  vgt::SlabRange(nz_global, world, rank, z_offset, nz_local);
+  return VGT_HIP_OK;
+}
+
+size_t vgt_hip_sdf_slab_carries_bytes(int64_t nx, int64_t ny)
+{
+  if (nx <= 0 || ny <= 0) return 0;
+  return static_cast<size_t>(nx) * static_cast<size_t>(ny) * sizeof(vgt::SlabLineCarry);
+}
+
 int vgt_hip_sdf_slab_carries_dev(vgt_hip_ctx* ctx, const void* gathered_summaries_dev, int32_t world,
-                                 int32_t rank, int64_t nx, int64_t ny, void* carries_dev)
+                                 int32_t rank, int64_t nx, int64_t ny, int64_t nz_global, void* carries_dev)
 {
   if (!ctx || !gathered_summaries_dev || !carries_dev)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
-  if (world <= 0 || rank < 0 || rank >= world || nx <= 0 || ny <= 0)
+  if (world <= 0 || rank < 0 || rank >= world || nx <= 0 || ny <= 0 || nz_global < world ||
+      nz_global > vgt::kMaxExtent)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid slab partition");
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   std::lock_guard<std::mutex> lock(ctx->mutex);
   VGT_TRY_HIP(vgt::LaunchSlabCarries(static_cast<const vgt::SlabLineSummary*>(gathered_summaries_dev), world, rank,
-                                     nx * ny, static_cast<vgt::SlabLineCarry*>(carries_dev), ctx->stream),
+                                     nx * ny, nz_global, static_cast<vgt::SlabLineCarry*>(carries_dev), ctx->stream),
               "slab carries");
   return VGT_HIP_OK;
 }

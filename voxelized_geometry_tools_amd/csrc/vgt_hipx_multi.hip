@@ -223,7 +223,8 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
       if (st.slabs[a].device == st.slabs[b].device) distinct = false;
 
   const size_t lines = static_cast<size_t>(nx * ny);
-  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(nx, ny);  // 8 bytes per line
+  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(nx, ny);  // 4 bytes per line
+  const size_t carries_bytes = vgt_hip_sdf_slab_carries_bytes(nx, ny);  // 8 bytes per line
   const size_t total_bytes = static_cast<size_t>(nx * ny * nz) * sizeof(float);
   // page-lock the caller's arrays so that the strided slab copies are true asynchronous DMA (best effort)
   st.host_in = occupancy_host;
@@ -247,7 +248,7 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
     VGTX_HIP(hipMalloc(&s.workspace, s.workspace_bytes), "allocate slab workspace");
     VGTX_HIP(hipMalloc(&s.summary, record_bytes), "allocate slab summary");
     VGTX_HIP(hipMalloc(&s.gathered, record_bytes * world), "allocate gathered summaries");
-    VGTX_HIP(hipMalloc(&s.carries, record_bytes), "allocate slab carries");
+    VGTX_HIP(hipMalloc(&s.carries, carries_bytes), "allocate slab carries");
     VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.minmax), 256), "allocate extrema");
     VGTX_HIP(hipMemcpy2DAsync(s.occ, static_cast<size_t>(s.nzl) * sizeof(float), occupancy_host + s.z0,
                               static_cast<size_t>(nz) * sizeof(float), static_cast<size_t>(s.nzl) * sizeof(float), lines,
@@ -273,7 +274,7 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
     for (int r = 0; r < world; r++)
     {
       Slab& s = st.slabs[r];
-      // 8-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
+      // 4-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
       const ncclResult_t res = rccl.AllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
                                               set->comms[r], s.stream);
       if (res != ncclSuccess)
@@ -311,7 +312,7 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   {
     Slab& s = st.slabs[r];
     VGTX_HIP(hipSetDevice(s.device), "set device");
-    VGTX_CALL(vgt_hip_sdf_slab_carries_dev(s.ctx, s.gathered, world, r, nx, ny, s.carries));
+    VGTX_CALL(vgt_hip_sdf_slab_carries_dev(s.ctx, s.gathered, world, r, nx, ny, nz, s.carries));
     VGTX_CALL(vgt_hip_sdf_slab_finish_dev(s.ctx, nx, ny, s.nzl, s.z0, nz, resolution, add_virtual_border, s.carries,
                                           s.sdf, s.workspace, s.workspace_bytes, s.minmax, nullptr));
     VGTX_HIP(hipMemcpy2DAsync(sdf_host + s.z0, static_cast<size_t>(nz) * sizeof(float), s.sdf,

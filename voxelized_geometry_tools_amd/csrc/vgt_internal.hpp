@@ -39,12 +39,25 @@ struct SdfParams
   int64_t nz_global = 0;
 };
 
-// Per-line summary of a Z slab, exchanged between devices: global z of the first / last filled
-// voxel and of the first / last free voxel of the line inside the slab, -1 when absent.
+// Per-line summary of a Z slab, exchanged between devices: 4 bytes.  A slab's first voxel is filled or free, so of
+// "first filled" and "first free" one is the slab's first voxel; the record keeps the class of the first voxel and the
+// position of the first voxel of the OTHER class (the same for the last voxel):
+//   bit 15 = 1: the slab's first / last voxel is filled;  bits 0-14: global z of the first / last voxel of the other
+//   class inside the slab, kSlabNone when the slab holds one class only.
+// The slabs follow SlabRange (equal shares, earlier slabs take the remainder), which tells the reader where they begin.
 struct SlabLineSummary
 {
-  int16_t first_filled, last_filled, first_free, last_free;
+  uint16_t first, last;
 };
+constexpr uint16_t kSlabFilledBit = 0x8000u;
+constexpr uint16_t kSlabNone = 0x7fffu;
+// [z0, z0 + count) of slab `rank` of `world` along a Z axis of nz voxels.
+inline void SlabRange(int64_t nz, int world, int rank, int64_t* z0, int64_t* count)
+{
+  const int64_t share = nz / world, extra = nz % world;
+  *z0 = rank * share + (rank < extra ? rank : extra);
+  *count = share + (rank < extra ? 1 : 0);
+}
 // Per-line carries derived from the other slabs' summaries: nearest filled / free voxel of the
 // line below this slab (largest global z) and above it (smallest global z), -1 when absent.
 struct SlabLineCarry
@@ -68,7 +81,7 @@ hipError_t LaunchScanZFromMask(const uint8_t* mask, int16_t* out16, const SdfPar
 // Multi-GPU: folds the carries of the other slabs into the slab-local pass-1 distances, in place.
 hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
                                unsigned long long* result_dev, hipStream_t stream);
-hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines,
+hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines, int64_t nz_global,
                              SlabLineCarry* carries, hipStream_t stream);
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream);

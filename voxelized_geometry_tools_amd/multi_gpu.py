@@ -4,10 +4,14 @@ The grid (nx, ny, nz) is cut along Z into `world` slabs.  Lines along Y and X ar
 slab, so the two envelope passes need no communication.  Only pass 1 -- distance along Z to the
 nearest voxel of the other class -- crosses slabs, and all it needs from the other slabs is, per
 (x, y) line, the nearest filled / free voxel below and above the slab.  Each rank therefore
-publishes 4 x int16 per line (global z of its first / last filled and first / last free voxel),
-the ranks all-gather these summaries once (torch.distributed: backend "nccl" is RCCL over xGMI;
-"gloo" in the CPU tests), and every rank reduces them to per-line carries for its own slab.
-Exact for any slab count: the first pass is a nearest-site scan, not a k-voxel halo.
+publishes 4 BYTES per line: a slab's first voxel is filled or free, so "first filled" and "first
+free" are the slab's first voxel and the first voxel of the other class; the record holds, for the
+first and for the last voxel, the class (bit 15) and the global z of the first / last voxel of the
+other class (bits 0-14, 0x7fff = none).  The ranks all-gather these summaries once
+(torch.distributed: backend "nccl" is RCCL over xGMI; "gloo" in the CPU tests) -- 4 B x nx x ny
+x world received per rank, 128 MiB at 2048 x 2048 lines and 8 ranks -- and every rank reduces
+them to per-line carries for its own slab.  Exact for any slab count: the first pass is a
+nearest-site scan, not a k-voxel halo.
 
 The exchange helpers are plain torch code and run on CPU tensors too (tests/test_multi_gpu_gloo.py).
 """
@@ -15,10 +19,12 @@ import numpy as np
 
 NONE = -1
 _BIG = 32767
+FILLED_BIT = 0x8000   # summary halves: class of the slab's first / last voxel
+OTHER_NONE = 0x7FFF   # ... and "no voxel of the other class in this slab"
 
 # column layout of the per-line records (must match SlabLineSummary / SlabLineCarry in
 # csrc/vgt_internal.hpp)
-FIRST_FILLED, LAST_FILLED, FIRST_FREE, LAST_FREE = 0, 1, 2, 3
+FIRST, LAST = 0, 1
 PREV_FILLED, NEXT_FILLED, PREV_FREE, NEXT_FREE = 0, 1, 2, 3
 
 
@@ -42,33 +48,53 @@ def slab_of(full_shape, rank, world):
     return (nx, ny, z1 - z0), z0
 
 
-def carries_from_summaries(torch, gathered, rank):
-    """gathered: int16 tensor [world, lines, 4] of slab summaries -> int16 [lines, 4] carries
-    (prev_filled, next_filled, prev_free, next_free as global z, -1 = none) for `rank`."""
-    world, lines, _ = gathered.shape
-    out = torch.full((lines, 4), NONE, dtype=torch.int16, device=gathered.device)
-    if rank > 0:
-        below = gathered[:rank]
-        out[:, PREV_FILLED] = below[:, :, LAST_FILLED].max(dim=0).values
-        out[:, PREV_FREE] = below[:, :, LAST_FREE].max(dim=0).values
-    if rank + 1 < world:
-        above = gathered[rank + 1:]
-        for dst, src in ((NEXT_FILLED, FIRST_FILLED), (NEXT_FREE, FIRST_FREE)):
-            v = above[:, :, src]
-            v = torch.where(v < 0, torch.full_like(v, _BIG), v).min(dim=0).values
-            out[:, dst] = torch.where(v == _BIG, torch.full_like(v, NONE), v)
+def decode_summaries(torch, gathered, nz):
+    """gathered: int16 tensor [world, lines, 2] of packed slab summaries (the slabs are slab_bounds(nz, world)) ->
+    int32 tensor [world, lines, 4] = global z of (first_filled, last_filled, first_free, last_free), -1 = none."""
+    world = gathered.shape[0]
+    rec = gathered.to(torch.int32) & 0xFFFF
+    filled = (rec & FILLED_BIT) != 0
+    other = rec & OTHER_NONE
+    other = torch.where(other == OTHER_NONE, torch.full_like(other, NONE), other)
+    bounds = torch.tensor(slab_bounds(nz, world), dtype=torch.int32, device=gathered.device)
+    begin = bounds[:, 0].view(world, 1).expand(-1, gathered.shape[1])
+    end = (bounds[:, 1] - 1).view(world, 1).expand(-1, gathered.shape[1])
+    out = torch.empty(gathered.shape[:2] + (4,), dtype=torch.int32, device=gathered.device)
+    out[..., 0] = torch.where(filled[..., FIRST], begin, other[..., FIRST])   # first filled
+    out[..., 1] = torch.where(filled[..., LAST], end, other[..., LAST])       # last filled
+    out[..., 2] = torch.where(filled[..., FIRST], other[..., FIRST], begin)   # first free
+    out[..., 3] = torch.where(filled[..., LAST], other[..., LAST], end)       # last free
     return out
 
 
-def exchange_carries(torch, dist, summary, rank, world, gathered=None):
-    """All-gathers the [lines, 4] int16 summaries of every rank and returns this rank's carries."""
+def carries_from_summaries(torch, gathered, rank, nz):
+    """gathered: int16 tensor [world, lines, 2] of packed slab summaries -> int16 [lines, 4] carries
+    (prev_filled, next_filled, prev_free, next_free as global z, -1 = none) for `rank`."""
+    world, lines, _ = gathered.shape
+    full = decode_summaries(torch, gathered, nz)
+    out = torch.full((lines, 4), NONE, dtype=torch.int32, device=gathered.device)
+    if rank > 0:
+        below = full[:rank]
+        out[:, PREV_FILLED] = below[:, :, 1].max(dim=0).values
+        out[:, PREV_FREE] = below[:, :, 3].max(dim=0).values
+    if rank + 1 < world:
+        above = full[rank + 1:]
+        for dst, src in ((NEXT_FILLED, 0), (NEXT_FREE, 2)):
+            v = above[:, :, src]
+            v = torch.where(v < 0, torch.full_like(v, _BIG), v).min(dim=0).values
+            out[:, dst] = torch.where(v == _BIG, torch.full_like(v, NONE), v)
+    return out.to(torch.int16)
+
+
+def exchange_carries(torch, dist, summary, rank, world, nz, gathered=None):
+    """All-gathers the [lines, 2] int16 summaries of every rank and returns this rank's carries."""
     if gathered is None:
         gathered = torch.empty((world,) + tuple(summary.shape), dtype=summary.dtype,
                                device=summary.device)
-    # the records are 8 bytes per line; move them as int32 words (gloo has no int16 collectives)
+    # the records are 4 bytes per line; move them as int32 words (gloo has no int16 collectives)
     dist.all_gather_into_tensor(gathered.view(torch.int32).view(-1),
                                 summary.contiguous().view(torch.int32).view(-1))
-    return carries_from_summaries(torch, gathered, rank)
+    return carries_from_summaries(torch, gathered, rank, nz)
 
 
 def reduce_extrema(dist, minmax):
@@ -81,19 +107,21 @@ def reduce_extrema(dist, minmax):
 
 
 def summary_reference(filled, z_offset):
-    """numpy restatement of the per-line slab summary (tests): filled = bool (nx, ny, nzl)."""
+    """numpy restatement of the packed per-line slab summary (tests): filled = bool (nx, ny, nzl) -> int16 [lines, 2]."""
     nx, ny, nzl = filled.shape
     z = np.arange(nzl)
-    out = np.full((nx, ny, 4), NONE, dtype=np.int16)
-    for col, mask in ((FIRST_FILLED, filled), (FIRST_FREE, ~filled)):
-        has = mask.any(axis=2)
-        first = np.where(mask, z, nzl).min(axis=2)
-        out[..., col] = np.where(has, first + z_offset, NONE)
-    for col, mask in ((LAST_FILLED, filled), (LAST_FREE, ~filled)):
-        has = mask.any(axis=2)
-        last = np.where(mask, z, -1).max(axis=2)
-        out[..., col] = np.where(has, last + z_offset, NONE)
-    return out.reshape(nx * ny, 4)
+    out = np.zeros((nx, ny, 2), dtype=np.uint16)
+    for col, boundary, pick in ((FIRST, 0, "first"), (LAST, nzl - 1, "last")):
+        cls = filled[:, :, boundary]
+        other = filled != cls[:, :, None]                    # voxels of the other class
+        has = other.any(axis=2)
+        if pick == "first":
+            pos = np.where(other, z, nzl).min(axis=2)
+        else:
+            pos = np.where(other, z, -1).max(axis=2)
+        value = np.where(has, pos + z_offset, OTHER_NONE).astype(np.uint16)
+        out[..., col] = value | np.where(cls, FILLED_BIT, 0).astype(np.uint16)
+    return out.view(np.int16).reshape(nx * ny, 2)
 
 
 class SlabSdf:
@@ -103,6 +131,8 @@ class SlabSdf:
     .cuda_stream)) so that the library's kernels, the torch reductions and the collective are
     stream-ordered."""
 
+    PHASES = ("scan", "exchange", "carries+fixup", "Y", "X")
+
     def __init__(self, ctx, torch, dist, full_shape, rank, world, device):
         from . import capi
         self.ctx, self.torch, self.dist = ctx, torch, dist
@@ -110,32 +140,46 @@ class SlabSdf:
         self.rank, self.world = rank, world
         self.local_shape, self.z_offset = slab_of(self.full_shape, rank, world)
         lines = self.local_shape[0] * self.local_shape[1]
-        assert capi.load().vgt_hip_sdf_slab_summary_bytes(*self.local_shape[:2]) == lines * 8
-        self.summary = torch.empty((lines, 4), dtype=torch.int16, device=device)
-        self.gathered = torch.empty((world, lines, 4), dtype=torch.int16, device=device)
+        lib = capi.load()
+        assert lib.vgt_hip_sdf_slab_summary_bytes(*self.local_shape[:2]) == lines * 4
+        assert lib.vgt_hip_sdf_slab_carries_bytes(*self.local_shape[:2]) == lines * 8
+        self.summary = torch.empty((lines, 2), dtype=torch.int16, device=device)
+        self.gathered = torch.empty((world, lines, 2), dtype=torch.int16, device=device)
         self.carries = torch.empty((lines, 4), dtype=torch.int16, device=device)
+        self.exchange_bytes_received = int(self.gathered.numel() * 2)
         self.ms_begin = np.zeros(1, dtype=np.float32)
         self.ms_finish = np.zeros(3, dtype=np.float32)
 
     def run(self, occ, sdf, ws, minmax, resolution, kernel_ms=None, unknown_is_filled=True,
-            add_virtual_border=False):
+            add_virtual_border=False, events=None):
+        """events (optional): 4 torch.cuda.Event(enable_timing=True) recorded on the current stream at the start, after
+        the slab scan, after the all-gather and at the end of the step; the carries / fix-up / Y / X split of the last
+        interval comes from the library's own events (ctx.timing_start / timing_stop)."""
         torch = self.torch
         timed = kernel_ms is not None
+        if events:
+            events[0].record()
         self.ctx.sdf_slab_begin(occ.data_ptr(), self.local_shape, self.z_offset, ws.data_ptr(),
                                 ws.numel(), self.summary.data_ptr(), unknown_is_filled,
                                 self.ms_begin if timed else None)
-        # one all-gather of the 8-byte records (as int32 words), then the library's carry kernel
+        if events:
+            events[1].record()
+        # one all-gather of the 4-byte records (as int32 words), then the library's carry kernel
         self.dist.all_gather_into_tensor(self.gathered.view(torch.int32).view(-1),
                                          self.summary.view(torch.int32).view(-1))
+        if events:
+            events[2].record()
         carries = self.carries
         self.ctx.sdf_slab_carries(self.gathered.data_ptr(), self.world, self.rank, self.local_shape[0],
-                                  self.local_shape[1], carries.data_ptr())
+                                  self.local_shape[1], self.full_shape[2], carries.data_ptr())
         self.ctx.sdf_slab_finish(self.local_shape, self.z_offset, self.full_shape[2], resolution,
                                  carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), ws.numel(),
                                  minmax.data_ptr(), add_virtual_border,
                                  self.ms_finish if timed else None)
         # the field's extrema are those of all slabs: ONE two-element all-reduce, MAX over (-min, max)
         reduce_extrema(self.dist, minmax)
+        if events:
+            events[3].record()
         if timed:
             kernel_ms[0] = self.ms_begin[0] + self.ms_finish[0]
             kernel_ms[1] = self.ms_finish[1]
@@ -158,7 +202,7 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
         local = occ[:, :, z0:z0 + local_shape[2]].contiguous()
         nbytes = capi.sdf_workspace_bytes(local_shape)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        summary = torch.empty((nx * ny, 4), dtype=torch.int16, device=dev)
+        summary = torch.empty((nx * ny, 2), dtype=torch.int16, device=dev)
         ctx.sdf_slab_begin(local.data_ptr(), local_shape, z0, ws.data_ptr(), nbytes,
                            summary.data_ptr(), unknown_is_filled)
         parts.append((local_shape, z0, local, ws, nbytes, summary))
@@ -168,7 +212,7 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
     extrema = []
     for r, (local_shape, z0, local, ws, nbytes, summary) in enumerate(parts):
         carries = torch.empty((nx * ny, 4), dtype=torch.int16, device=dev)
-        ctx.sdf_slab_carries(gathered.data_ptr(), nslabs, r, nx, ny, carries.data_ptr())
+        ctx.sdf_slab_carries(gathered.data_ptr(), nslabs, r, nx, ny, nz, carries.data_ptr())
         sdf = torch.empty(local_shape, dtype=torch.float32, device=dev)
         mm = torch.zeros(2, dtype=torch.float32, device=dev)
         ctx.sdf_slab_finish(local_shape, z0, nz, resolution, carries.data_ptr(), sdf.data_ptr(),
