@@ -3,7 +3,7 @@
 //     out(q) = min( min_r (q-r)^2 + |F[r]|,  min over rows r of the other class (q-r)^2 ),
 // i.e. the per-line contract of the Y and X passes (edt_hull_kernels.hip header).  It exercises what the GPU parity tests
 // cannot reach cheaply: deep stacks (ring spills / refills in both sweeps), every ring / band size the kernel can be
-// built with (-DVGT_SWEEP_BAND / _RING / _CHUNK), packed and 64-bit entries, partial waves, partial bands, the virtual
+// built with (-DVGT_SWEEP_BAND / _RING / _CHUNK / _RING_WIDE / _CHUNK_WIDE), packed and 64-bit entries, partial waves, partial bands, the virtual
 // border and the final conversion.  The GPU tests (tests/test_gpu_sdf.py) pin the same kernels to the oracle.
 #include <hip/hip_runtime.h>
 
@@ -226,6 +226,8 @@ int main(int argc, char** argv)
       cases++;
     }
   }
-  std::printf("%d cases, %d mismatches (band %d, ring %d, chunk %d)\n", cases, failures, vgt::kBand, vgt::kRing, vgt::kChunk);
+  std::printf("%d cases, %d mismatches (band %d; 32-bit entries: ring %d, chunk %d; 64-bit entries: ring %d, chunk %d)\n", cases,
+              failures, vgt::kBand, vgt::RingShape<true>::kRing, vgt::RingShape<true>::kChunk, vgt::RingShape<false>::kRing,
+              vgt::RingShape<false>::kChunk);
   return failures ? 1 : 0;
 }

@@ -16,6 +16,7 @@ CONFIGS = [
     ("b8_r16_c4", "-DVGT_SWEEP_BAND=8 -DVGT_SWEEP_RING=16 -DVGT_SWEEP_CHUNK=4"),
     ("b16_r32_c8", "-DVGT_SWEEP_BAND=16 -DVGT_SWEEP_RING=32 -DVGT_SWEEP_CHUNK=8"),
     ("b8_r32_c8", "-DVGT_SWEEP_BAND=8 -DVGT_SWEEP_RING=32 -DVGT_SWEEP_CHUNK=8"),
+    ("b32_wide_r32_c8", "-DVGT_SWEEP_BAND=32 -DVGT_SWEEP_RING_WIDE=32 -DVGT_SWEEP_CHUNK_WIDE=8"),
 ]
 
 

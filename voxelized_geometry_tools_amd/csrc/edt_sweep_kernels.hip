@@ -57,10 +57,23 @@ namespace
 #endif
 constexpr int kBand = VGT_SWEEP_BAND;    // rows held in registers at a time: 8, 16 or 32
 constexpr int kWord = 32;                // rows per sign word
-constexpr int kRing = VGT_SWEEP_RING;    // stack entries per lane resident in LDS (power of two)
-constexpr int kChunk = VGT_SWEEP_CHUNK;  // entries per spill / refill = rows between two checks of the ring
+#ifndef VGT_SWEEP_RING_WIDE
+#define VGT_SWEEP_RING_WIDE 16
+#endif
+#ifndef VGT_SWEEP_CHUNK_WIDE
+#define VGT_SWEEP_CHUNK_WIDE 4
+#endif
+// Stack entries per lane resident in LDS (a power of two) and entries per spill / refill (= rows between two checks
+// of the ring), for 32-bit and for 64-bit entries: the ring of either takes 8 KiB of LDS per wave.
+template <bool kPacked>
+struct RingShape
+{
+  static constexpr int kRing = kPacked ? VGT_SWEEP_RING : VGT_SWEEP_RING_WIDE;
+  static constexpr int kChunk = kPacked ? VGT_SWEEP_CHUNK : VGT_SWEEP_CHUNK_WIDE;
+  static_assert(kBand % kChunk == 0 && kRing >= 4 * kChunk && (kRing & (kRing - 1)) == 0 && kChunk % 4 == 0, "sizes");
+};
 constexpr int kFar = 32768;              // "no row of the other class": kFar^2 is above every real squared distance
-static_assert(kWord % kBand == 0 && kBand % kChunk == 0 && kRing >= 4 * kChunk && (kRing & (kRing - 1)) == 0, "sizes");
+static_assert(kWord % kBand == 0, "sizes");
 
 struct SweepGeom
 {
@@ -107,17 +120,19 @@ struct Codec<false>
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e.y); }
 };
 
-// A chunk of kChunk entries <-> contiguous bytes of the spill buffer, as 16-byte accesses.
-__device__ __forceinline__ void StoreChunk(uint32_t* dst, const uint32_t (&e)[kChunk])
+// A chunk of N entries <-> contiguous bytes of the spill buffer, as 16-byte accesses.
+template <int N>
+__device__ __forceinline__ void StoreChunk(uint32_t* dst, const uint32_t (&e)[N])
 {
 #pragma unroll
-  for (int j = 0; j < kChunk / 4; j++)
+  for (int j = 0; j < N / 4; j++)
     reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
 }
-__device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[kChunk])
+template <int N>
+__device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[N])
 {
 #pragma unroll
-  for (int j = 0; j < kChunk / 4; j++)
+  for (int j = 0; j < N / 4; j++)
   {
     const uint4 a = reinterpret_cast<const uint4*>(src)[j];
     e[4 * j] = a.x;
@@ -126,16 +141,18 @@ __device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[kCh
     e[4 * j + 3] = a.w;
   }
 }
-__device__ __forceinline__ void StoreChunk(uint2* dst, const uint2 (&e)[kChunk])
+template <int N>
+__device__ __forceinline__ void StoreChunk(uint2* dst, const uint2 (&e)[N])
 {
 #pragma unroll
-  for (int j = 0; j < kChunk / 2; j++)
+  for (int j = 0; j < N / 2; j++)
     reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y);
 }
-__device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[kChunk])
+template <int N>
+__device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[N])
 {
 #pragma unroll
-  for (int j = 0; j < kChunk / 2; j++)
+  for (int j = 0; j < N / 2; j++)
   {
     const uint4 a = reinterpret_cast<const uint4*>(src)[j];
     e[2 * j] = make_uint2(a.x, a.y);
@@ -200,6 +217,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 {
   using C = Codec<kPacked>;
   using Entry = typename C::Entry;
+  constexpr int kRing = RingShape<kPacked>::kRing;
+  constexpr int kChunk = RingShape<kPacked>::kChunk;
   constexpr int32_t kLimit = C::kSentinelG;  // values at or above: no site
   constexpr int kEntryBytes = static_cast<int>(sizeof(Entry));
   constexpr int kShift = kPacked ? 8 : 9;                   // log2(bytes of one ring slot = 64 lanes x entry)
@@ -636,7 +655,7 @@ constexpr int64_t kSweepSlots = 5120;
 #endif
 constexpr size_t kCounterBytes = 256;  // the work counter, alone on its cache lines
 
-int64_t SpillChunks(int64_t n) { return (n + 3 + kChunk - 1) / kChunk + 1; }
+int64_t SpillChunks(int64_t n, int chunk) { return (n + 3 + chunk - 1) / chunk + 1; }
 
 // Entries of a line of n rows fit 32 bits when every G = F + row^2 stays below the sentinels.
 bool PackedEntries(int64_t n, int64_t max_input)
@@ -650,8 +669,9 @@ size_t PassScratchBytes(int64_t n, int64_t items)
 {
   const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
   const int64_t nwords = (n + kWord - 1) / kWord;
-  return kCounterBytes + static_cast<size_t>(slots) * (SpillChunks(n) * kWaveSize * kChunk * sizeof(uint2) +
-                                                       nwords * kWaveSize * sizeof(uint2));
+  const size_t narrow = SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t);
+  const size_t wide = SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
+  return kCounterBytes + static_cast<size_t>(slots) * ((narrow > wide ? narrow : wide) + nwords * kWaveSize * sizeof(uint2));
 }
 
 template <typename InT, typename OutT, bool kFinal>
@@ -660,19 +680,20 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
 {
   g.zsegs = (g.nz + kWaveSize - 1) / kWaveSize;
   g.nwords = (g.n + kWord - 1) / kWord;
-  g.chunks = static_cast<int>(SpillChunks(g.n));
   const int64_t items = outer_count * g.zsegs;
   if (items <= 0) return hipSuccess;
   if (items > 0x7fffffffLL) return hipErrorInvalidValue;
   g.items = static_cast<int>(items);
   const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
   const bool packed = PackedEntries(g.n, max_input);
+  const int chunk = packed ? RingShape<true>::kChunk : RingShape<false>::kChunk;
+  g.chunks = static_cast<int>(SpillChunks(g.n, chunk));
   // scratch: work counter | spill chunks of every slot | one (sign word, carry) pair per 32 rows, lane and slot
   char* bytes = static_cast<char*>(scratch);
   int* counter = reinterpret_cast<int*>(bytes);
   unsigned char* spill = reinterpret_cast<unsigned char*>(bytes + kCounterBytes);
   const size_t spill_bytes =
-      static_cast<size_t>(slots) * g.chunks * kWaveSize * kChunk * (packed ? sizeof(uint32_t) : sizeof(uint2));
+      static_cast<size_t>(slots) * g.chunks * kWaveSize * chunk * (packed ? sizeof(uint32_t) : sizeof(uint2));
   uint2* info = reinterpret_cast<uint2*>(bytes + kCounterBytes + spill_bytes);
 #ifdef VGT_HOST_EMULATION
   *counter = 0;
