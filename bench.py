@@ -272,6 +272,37 @@ def raycast_section():
     return out
 
 
+def multi_host_path(torch, shape, res):
+    """vgt_hipx_sdf_multi (one process, host arrays in and out, one Z slab per listed device) with ALL EIGHT slabs on
+    this one GPU: the data movement of the 8-GPU call -- rows of nz / 8 floats at a pitch of nz (512 B at nz = 1024) in
+    both directions -- against the PCIe time of plain pinned copies of the same bytes."""
+    from voxelized_geometry_tools_amd import capi, synthetic
+    occ = synthetic.occupancy_spheres(shape, 42)
+    out = np.zeros(shape, dtype=np.float32)
+    devices = [torch.cuda.current_device()] * 8
+    t0 = time.perf_counter()
+    capi.sdf_multi(devices, occ, res, out=out)
+    first = time.perf_counter() - t0
+    first_phases = capi.sdf_multi_last_timing()
+    best, phases = None, None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        capi.sdf_multi(devices, occ, res, out=out)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, phases = dt, capi.sdf_multi_last_timing()
+    capi.sdf_multi_release()
+    nbytes = occ.nbytes
+    return {"shape": list(shape), "slabs": 8, "row_bytes": int(shape[2] // 8 * 4), "call_ms": round(best * 1e3, 2),
+            "first_call_ms": round(first * 1e3, 2), "first_call_setup_ms": round(first_phases["setup_ms"], 2),
+            "phases_ms": {k: round(v, 2) for k, v in phases.items()},
+            "GBps": {"upload": round(nbytes / (phases["upload_ms"] * 1e-3) / 1e9, 1) if phases["upload_ms"] > 0 else None,
+                     "download": round(nbytes / (phases["download_ms"] * 1e-3) / 1e9, 1) if phases["download_ms"] > 0 else None},
+            "note": "eight slabs on ONE device (devices = [d] * 8): the slabs share the device's copy engines and CUs, so "
+                    "upload_ms / download_ms are the slowest slab's strided copies while the others run; call_ms is the "
+                    "whole call from pageable host arrays (page-locked per call), device state kept from the first call"}
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: run this script under torch.distributed.run with N ranks.
     Nothing in this (parent) process has initialised the GPU; the child is a subprocess, not an exec."""
@@ -455,6 +486,14 @@ def main():
                 line["host_path"] = end_to_end(ctx, torch, occ, local_shape, res)
             except Exception as exc:  # the headline number must not depend on host RAM for pinned buffers
                 line["host_path"] = {"error": repr(exc)}
+            if headline:
+                try:
+                    line["multi_host_path"] = multi_host_path(torch, local_shape, res)
+                    bound = line["host_path"].get("pcie_lower_bound_ms")
+                    if bound:
+                        line["multi_host_path"]["vs_pcie_lower_bound"] = round(line["multi_host_path"]["call_ms"] / bound, 3)
+                except Exception as exc:
+                    line["multi_host_path"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and not dist_on:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:

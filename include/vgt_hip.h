@@ -371,6 +371,13 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
 int vgt_hipx_sdf_multi(const int* devices, int num_devices, const float* occupancy_host, int64_t nx,
                        int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
                        int add_virtual_border, float* sdf_host, float* out_min, float* out_max);
+/* vgt_hipx_sdf_multi keeps the per-slab contexts, streams and device buffers of the last (device list, grid shape)
+ * it served for the next call with the same key (one extraction at a time per process); this frees them. */
+void vgt_hipx_release(void);
+/* Phases of the last vgt_hipx_sdf_multi call, milliseconds: [0] set-up (slab set on a miss + page-locking),
+ * [1] slowest slab's upload, [2] its scan + exchange + passes, [3] its download (events on the slab streams; the
+ * phases of different slabs overlap), [4] the whole call. */
+int vgt_hipx_last_timing(float* ms5);
 
 #ifdef __cplusplus
 }

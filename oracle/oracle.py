@@ -32,6 +32,7 @@ def load(path=None):
     global _LIB
     if path is None and _LIB is not None:
         return _LIB
+    path = path or os.environ.get("VGT_ORACLE_LIB")  # (a sanitizer build: tests/test_sanitizers.py)
     so = path or os.path.join(_HERE, "libvgt_oracle.so")
     src = os.path.join(_HERE, "vgt_oracle.c")
     if path is None and (not os.path.exists(so)

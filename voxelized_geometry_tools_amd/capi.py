@@ -68,6 +68,8 @@ SIGNATURES = {
     "vgt_hip_sdf_local_extrema_map": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p]),
     "vgt_hip_sdf_local_extrema_map_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _p]),
     "vgt_hipx_sdf_multi": (_int, [_p, _int, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
+    "vgt_hipx_release": (None, []),
+    "vgt_hipx_last_timing": (_int, [_p]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
@@ -350,7 +352,7 @@ class Context:
         return FilterGrid(self, occupancy)
 
 
-def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtual_border=False):
+def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtual_border=False, out=None):
     """vgt_hipx_sdf_multi: one process, one Z slab per entry of `devices` (a device may repeat)."""
     lib = load()
     occ = np.ascontiguousarray(occupancy, dtype=np.float32)
@@ -358,12 +360,25 @@ def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtua
         raise ValueError("occupancy must be (nx, ny, nz)")
     nx, ny, nz = occ.shape
     devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
-    out = np.empty(occ.shape, dtype=np.float32)
+    if out is None:
+        out = np.empty(occ.shape, dtype=np.float32)
     lo, hi = _f32(), _f32()
     check(lib.vgt_hipx_sdf_multi(devs, len(devices), _ptr(occ) if occ.size else None, nx, ny, nz, float(resolution),
                                  int(bool(unknown_is_filled)), int(bool(add_virtual_border)), _ptr(out),
                                  ctypes.byref(lo), ctypes.byref(hi)))
     return out, lo.value, hi.value
+
+
+def sdf_multi_release():
+    """Frees the device state vgt_hipx_sdf_multi keeps between calls."""
+    load().vgt_hipx_release()
+
+
+def sdf_multi_last_timing():
+    """Phases of the last sdf_multi call in ms: setup, upload, compute, download (slowest slab each), total."""
+    ms = (ctypes.c_float * 5)()
+    check(load().vgt_hipx_last_timing(ms))
+    return dict(zip(("setup_ms", "upload_ms", "compute_ms", "download_ms", "total_ms"), [float(v) for v in ms]))
 
 
 def sdf_workspace_bytes(shape, variant=0):

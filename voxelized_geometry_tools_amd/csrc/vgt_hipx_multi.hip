@@ -8,12 +8,13 @@
 // a pitch of nz floats in the caller's array -- moved by hipMemcpy2DAsync on the device's own
 // stream (the caller's arrays are page-locked with hipHostRegister for the duration of the call
 // when the driver allows it), so the N uploads, the N pipelines and the N downloads overlap.
-// Exchange: rccl's ncclAllGather (one call per device inside a group, 8 bytes per (x, y) line and
+// Exchange: rccl's ncclAllGather (one call per device inside a group, 4 bytes per (x, y) line and
 // slab) when the devices are distinct; when one device appears more than once in `devices`
 // (several slabs on one GPU: the single-GPU test of this path, or a grid that does not fit one
 // GPU's workspace in one piece) rccl cannot form a communicator and the summaries are copied
 // slab to slab with hipMemcpyPeerAsync instead.  Communicators are formed once per device list and kept
-// for the life of the process (CommSet below).  The field's extrema are reduced on the host: this
+// for the life of the process (CommSet below); so are the per-slab contexts, streams and device buffers of the
+// last (device list, grid shape) served (SlabSet below).  The field's extrema are reduced on the host: this
 // process already holds every device's (min, max) pair.
 #include "../../include/vgt_hip.h"
 
@@ -24,10 +25,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -111,6 +114,7 @@ struct Slab
   vgt_hip_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t summary_ready = nullptr;
+  hipEvent_t marks[4] = {nullptr, nullptr, nullptr, nullptr};  // start, uploaded, computed, downloaded
   float* occ = nullptr;
   float* sdf = nullptr;
   void* workspace = nullptr;
@@ -122,15 +126,17 @@ struct Slab
   float minmax_host[2] = {0.0f, 0.0f};
 };
 
-struct MultiState
+// Everything a (device list, grid shape) needs on the devices: contexts, streams, events and buffers of every
+// slab.  Built on the first extraction with that key and kept for the following ones -- a context, a stream and
+// seven hipMallocs per slab every call cost more than the pipeline itself on grids of a few hundred MiB -- until
+// another key displaces it (one set at a time: the buffers are the size of the grid) or vgt_hipx_release is called.
+struct SlabSet
 {
+  std::vector<int> devices;
+  int64_t nx = 0, ny = 0, nz = 0;
   std::vector<Slab> slabs;
-  std::unique_lock<std::mutex> comm_lock;  // the communicator set, held until the streams have drained
-  bool registered_in = false, registered_out = false;
-  const void* host_in = nullptr;
-  void* host_out = nullptr;
 
-  ~MultiState()
+  ~SlabSet()
   {
     for (Slab& s : slabs)
     {
@@ -138,18 +144,45 @@ struct MultiState
       (void)hipSetDevice(s.device);
       if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
-    if (comm_lock.owns_lock()) comm_lock.unlock();
     for (Slab& s : slabs)
     {
       if (s.device < 0) continue;
       (void)hipSetDevice(s.device);
       if (s.ctx) vgt_hip_destroy(s.ctx);  // drains the stream it was given first
       if (s.summary_ready) (void)hipEventDestroy(s.summary_ready);
+      for (hipEvent_t e : s.marks)
+        if (e) (void)hipEventDestroy(e);
       if (s.stream) (void)hipStreamDestroy(s.stream);
       for (void* p : {static_cast<void*>(s.occ), static_cast<void*>(s.sdf), s.workspace, s.summary, s.gathered,
                       s.carries, static_cast<void*>(s.minmax)})
         if (p) (void)hipFree(p);
     }
+  }
+};
+
+std::mutex g_set_lock;        // held for the whole of an extraction: one at a time per process
+SlabSet* g_set = nullptr;     // the cached set (guarded by g_set_lock)
+float g_last_timing[5] = {0, 0, 0, 0, 0};
+
+// Per call: the page-locking of the caller's arrays and the communicator lock; drains the streams before either goes.
+struct CallState
+{
+  SlabSet* set = nullptr;
+  std::unique_lock<std::mutex> comm_lock;  // the communicator set, held until the streams have drained
+  bool registered_in = false, registered_out = false;
+  const void* host_in = nullptr;
+  void* host_out = nullptr;
+
+  ~CallState()
+  {
+    if (set)
+      for (Slab& s : set->slabs)
+      {
+        if (s.device < 0) continue;
+        (void)hipSetDevice(s.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+      }
+    if (comm_lock.owns_lock()) comm_lock.unlock();
     if (registered_in) (void)hipHostUnregister(const_cast<void*>(host_in));
     if (registered_out) (void)hipHostUnregister(host_out);
   }
@@ -181,7 +214,50 @@ int FailMulti(int code, const std::string& msg)
     const int rc_ = (expr);              \
     if (rc_ != VGT_HIP_OK) return rc_;   \
   } while (0)
+
+// Contexts, streams, events and buffers of every slab of `set` (whose key and slab ranges are filled in).
+int BuildSlabSet(SlabSet* set)
+{
+  const size_t lines = static_cast<size_t>(set->nx * set->ny);
+  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(set->nx, set->ny);   // 4 bytes per line
+  const size_t carries_bytes = vgt_hip_sdf_slab_carries_bytes(set->nx, set->ny);  // 8 bytes per line
+  const int world = static_cast<int>(set->slabs.size());
+  for (Slab& s : set->slabs)
+  {
+    VGTX_HIP(hipSetDevice(s.device), "set device");
+    VGTX_CALL(vgt_hip_create(s.device, -1, &s.ctx));
+    VGTX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "create stream");
+    VGTX_HIP(hipEventCreateWithFlags(&s.summary_ready, hipEventDisableTiming), "create event");
+    for (hipEvent_t& e : s.marks) VGTX_HIP(hipEventCreate(&e), "create event");
+    VGTX_CALL(vgt_hip_set_stream(s.ctx, s.stream));
+    const size_t slab_voxels = lines * static_cast<size_t>(s.nzl);
+    s.workspace_bytes = vgt_hip_sdf_workspace_bytes(set->nx, set->ny, s.nzl);
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.occ), slab_voxels * sizeof(float)), "allocate slab occupancy");
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.sdf), slab_voxels * sizeof(float)), "allocate slab SDF");
+    VGTX_HIP(hipMalloc(&s.workspace, s.workspace_bytes), "allocate slab workspace");
+    VGTX_HIP(hipMalloc(&s.summary, record_bytes), "allocate slab summary");
+    VGTX_HIP(hipMalloc(&s.gathered, record_bytes * world), "allocate gathered summaries");
+    VGTX_HIP(hipMalloc(&s.carries, carries_bytes), "allocate slab carries");
+    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.minmax), 256), "allocate extrema");
+  }
+  return VGT_HIP_OK;
+}
 }  // namespace
+
+extern "C" void vgt_hipx_release(void)
+{
+  std::lock_guard<std::mutex> guard(g_set_lock);
+  delete g_set;
+  g_set = nullptr;
+}
+
+extern "C" int vgt_hipx_last_timing(float* ms5)
+{
+  if (!ms5) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  std::lock_guard<std::mutex> guard(g_set_lock);
+  for (int i = 0; i < 5; i++) ms5[i] = g_last_timing[i];
+  return VGT_HIP_OK;
+}
 
 extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const float* occupancy_host, int64_t nx,
                                   int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
@@ -201,59 +277,81 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
     if (devices[i] < 0 || devices[i] >= device_count)
       return FailMulti(VGT_HIP_ERR_UNAVAILABLE, "device " + std::to_string(devices[i]) + " out of range for " +
                                                     std::to_string(device_count) + " devices");
+  const auto t_begin = std::chrono::steady_clock::now();
 
-  // slabs along Z, as equal as possible, earlier slabs take the remainder (= multi_gpu.slab_bounds)
+  // slabs along Z: vgt_hip_sdf_slab_range (equal shares, earlier slabs take the remainder = multi_gpu.slab_bounds)
   const int world = static_cast<int>(std::min<int64_t>(num_devices, nz));
-  MultiState st;
-  st.slabs.resize(static_cast<size_t>(world));
+  const std::vector<int> devs(devices, devices + world);
+  std::lock_guard<std::mutex> set_guard(g_set_lock);
+  if (g_set && !(g_set->devices == devs && g_set->nx == nx && g_set->ny == ny && g_set->nz == nz))
   {
-    const int64_t share = nz / world, extra = nz % world;
-    int64_t z = 0;
+    delete g_set;  // another grid shape or device list: its buffers make room
+    g_set = nullptr;
+  }
+  if (!g_set)
+  {
+    auto* fresh = new SlabSet();
+    fresh->devices = devs;
+    fresh->nx = nx;
+    fresh->ny = ny;
+    fresh->nz = nz;
+    fresh->slabs.resize(static_cast<size_t>(world));
     for (int r = 0; r < world; r++)
     {
-      st.slabs[r].device = devices[r];
-      st.slabs[r].z0 = z;
-      st.slabs[r].nzl = share + (r < extra ? 1 : 0);
-      z += st.slabs[r].nzl;
+      fresh->slabs[r].device = devs[r];
+      vgt::SlabRange(nz, world, r, &fresh->slabs[r].z0, &fresh->slabs[r].nzl);
     }
+    const int rc = BuildSlabSet(fresh);
+    if (rc != VGT_HIP_OK)
+    {
+      delete fresh;
+      return rc;
+    }
+    g_set = fresh;
   }
+  SlabSet& set = *g_set;
+  CallState st;
+  st.set = &set;
   bool distinct = true;
   for (int a = 0; a < world; a++)
     for (int b = a + 1; b < world; b++)
-      if (st.slabs[a].device == st.slabs[b].device) distinct = false;
+      if (set.slabs[a].device == set.slabs[b].device) distinct = false;
 
   const size_t lines = static_cast<size_t>(nx * ny);
-  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(nx, ny);  // 4 bytes per line
-  const size_t carries_bytes = vgt_hip_sdf_slab_carries_bytes(nx, ny);  // 8 bytes per line
+  const size_t record_bytes = vgt_hip_sdf_slab_summary_bytes(nx, ny);
   const size_t total_bytes = static_cast<size_t>(nx * ny * nz) * sizeof(float);
-  // page-lock the caller's arrays so that the strided slab copies are true asynchronous DMA (best effort)
+  // page-lock the caller's arrays so that the strided slab copies are true asynchronous DMA (best effort; a few
+  // milliseconds per GiB, measured in bench.py's host_path.register_ms)
   st.host_in = occupancy_host;
   st.host_out = sdf_host;
   st.registered_in = hipHostRegister(const_cast<float*>(occupancy_host), total_bytes, hipHostRegisterPortable) == hipSuccess;
-  st.registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
   (void)hipGetLastError();
+  // the output array is not needed before the first download: it is page-locked by a helper thread while the
+  // uploads run (joined before the first download is enqueued)
+  bool registered_out = false;
+  std::thread pin_out([&registered_out, sdf_host, total_bytes] {
+    registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
+  });
+  struct Joiner
+  {
+    std::thread& t;
+    ~Joiner()
+    {
+      if (t.joinable()) t.join();
+    }
+  } joiner{pin_out};
+  const auto t_setup = std::chrono::steady_clock::now();
 
-  // per slab: context on its own stream, buffers, upload, slab scan + summary
-  for (Slab& s : st.slabs)
+  // per slab: upload, slab scan + summary
+  for (Slab& s : set.slabs)
   {
     VGTX_HIP(hipSetDevice(s.device), "set device");
-    VGTX_CALL(vgt_hip_create(s.device, -1, &s.ctx));
-    VGTX_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "create stream");
-    VGTX_HIP(hipEventCreateWithFlags(&s.summary_ready, hipEventDisableTiming), "create event");
-    VGTX_CALL(vgt_hip_set_stream(s.ctx, s.stream));
-    const size_t slab_voxels = lines * static_cast<size_t>(s.nzl);
-    s.workspace_bytes = vgt_hip_sdf_workspace_bytes(nx, ny, s.nzl);
-    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.occ), slab_voxels * sizeof(float)), "allocate slab occupancy");
-    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.sdf), slab_voxels * sizeof(float)), "allocate slab SDF");
-    VGTX_HIP(hipMalloc(&s.workspace, s.workspace_bytes), "allocate slab workspace");
-    VGTX_HIP(hipMalloc(&s.summary, record_bytes), "allocate slab summary");
-    VGTX_HIP(hipMalloc(&s.gathered, record_bytes * world), "allocate gathered summaries");
-    VGTX_HIP(hipMalloc(&s.carries, carries_bytes), "allocate slab carries");
-    VGTX_HIP(hipMalloc(reinterpret_cast<void**>(&s.minmax), 256), "allocate extrema");
+    VGTX_HIP(hipEventRecord(s.marks[0], s.stream), "record event");
     VGTX_HIP(hipMemcpy2DAsync(s.occ, static_cast<size_t>(s.nzl) * sizeof(float), occupancy_host + s.z0,
                               static_cast<size_t>(nz) * sizeof(float), static_cast<size_t>(s.nzl) * sizeof(float), lines,
                               hipMemcpyHostToDevice, s.stream),
              "copy slab occupancy to device");
+    VGTX_HIP(hipEventRecord(s.marks[1], s.stream), "record event");
     VGTX_CALL(vgt_hip_sdf_slab_begin_dev(s.ctx, s.occ, nx, ny, s.nzl, s.z0, unknown_is_filled, s.workspace,
                                          s.workspace_bytes, s.summary, nullptr));
     VGTX_HIP(hipEventRecord(s.summary_ready, s.stream), "record event");
@@ -264,19 +362,17 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   {
     const Rccl& rccl = GetRccl();
     if (!rccl.error.empty()) return FailMulti(VGT_HIP_ERR_UNAVAILABLE, rccl.error);
-    std::vector<int> devs(static_cast<size_t>(world));
-    for (int r = 0; r < world; r++) devs[r] = st.slabs[r].device;
     std::string comm_error;
-    CommSet* const set = GetCommSet(rccl, devs, &comm_error);
-    if (!set) return FailMulti(VGT_HIP_ERR_RUNTIME, comm_error);
-    st.comm_lock = std::unique_lock<std::mutex>(set->in_use);
+    CommSet* const comms = GetCommSet(rccl, devs, &comm_error);
+    if (!comms) return FailMulti(VGT_HIP_ERR_RUNTIME, comm_error);
+    st.comm_lock = std::unique_lock<std::mutex>(comms->in_use);
     VGTX_NCCL(rccl.GroupStart(), "ncclGroupStart");
     for (int r = 0; r < world; r++)
     {
-      Slab& s = st.slabs[r];
+      Slab& s = set.slabs[r];
       // 4-byte records moved as int32 words; rank r's block lands at gathered + r * record_bytes
       const ncclResult_t res = rccl.AllGather(s.summary, s.gathered, record_bytes / sizeof(int32_t), ncclInt32,
-                                              set->comms[r], s.stream);
+                                              comms->comms[r], s.stream);
       if (res != ncclSuccess)
       {
         (void)rccl.GroupEnd();
@@ -290,11 +386,11 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   {
     for (int r = 0; r < world; r++)
     {
-      Slab& dst = st.slabs[r];
+      Slab& dst = set.slabs[r];
       VGTX_HIP(hipSetDevice(dst.device), "set device");
       for (int q = 0; q < world; q++)
       {
-        Slab& src = st.slabs[q];
+        Slab& src = set.slabs[q];
         VGTX_HIP(hipStreamWaitEvent(dst.stream, src.summary_ready, 0), "wait for summary");
         char* to = static_cast<char*>(dst.gathered) + static_cast<size_t>(q) * record_bytes;
         if (src.device == dst.device)
@@ -308,29 +404,45 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   }
 
   // per slab: carries, fix-up, Y and X passes, download
+  pin_out.join();
+  st.registered_out = registered_out;
+  (void)hipGetLastError();
   for (int r = 0; r < world; r++)
   {
-    Slab& s = st.slabs[r];
+    Slab& s = set.slabs[r];
     VGTX_HIP(hipSetDevice(s.device), "set device");
     VGTX_CALL(vgt_hip_sdf_slab_carries_dev(s.ctx, s.gathered, world, r, nx, ny, nz, s.carries));
     VGTX_CALL(vgt_hip_sdf_slab_finish_dev(s.ctx, nx, ny, s.nzl, s.z0, nz, resolution, add_virtual_border, s.carries,
                                           s.sdf, s.workspace, s.workspace_bytes, s.minmax, nullptr));
+    VGTX_HIP(hipEventRecord(s.marks[2], s.stream), "record event");
     VGTX_HIP(hipMemcpy2DAsync(sdf_host + s.z0, static_cast<size_t>(nz) * sizeof(float), s.sdf,
                               static_cast<size_t>(s.nzl) * sizeof(float), static_cast<size_t>(s.nzl) * sizeof(float), lines,
                               hipMemcpyDeviceToHost, s.stream),
              "copy slab SDF to host");
+    VGTX_HIP(hipEventRecord(s.marks[3], s.stream), "record event");
     VGTX_HIP(hipMemcpyAsync(s.minmax_host, s.minmax, 2 * sizeof(float), hipMemcpyDeviceToHost, s.stream),
              "copy extrema to host");
   }
   float lo = INFINITY, hi = -INFINITY;
-  for (Slab& s : st.slabs)
+  float upload_ms = 0.0f, compute_ms = 0.0f, download_ms = 0.0f;
+  for (Slab& s : set.slabs)
   {
     VGTX_HIP(hipSetDevice(s.device), "set device");
     VGTX_HIP(hipStreamSynchronize(s.stream), "wait for slab");
     lo = std::min(lo, s.minmax_host[0]);
     hi = std::max(hi, s.minmax_host[1]);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.marks[0], s.marks[1]) == hipSuccess) upload_ms = std::max(upload_ms, ms);
+    if (hipEventElapsedTime(&ms, s.marks[1], s.marks[2]) == hipSuccess) compute_ms = std::max(compute_ms, ms);
+    if (hipEventElapsedTime(&ms, s.marks[2], s.marks[3]) == hipSuccess) download_ms = std::max(download_ms, ms);
   }
   if (out_min) *out_min = lo;
   if (out_max) *out_max = hi;
+  const auto t_end = std::chrono::steady_clock::now();
+  g_last_timing[0] = std::chrono::duration<float, std::milli>(t_setup - t_begin).count();
+  g_last_timing[1] = upload_ms;
+  g_last_timing[2] = compute_ms;
+  g_last_timing[3] = download_ms;
+  g_last_timing[4] = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   return VGT_HIP_OK;
 }
