@@ -180,36 +180,41 @@ namespace
 // runtime is not defined).  The context caches its device buffers, so a caller that extracts
 // fields repeatedly pays for context creation and hipMalloc once; the C ABI serialises concurrent
 // calls on one context.
-vgt_hip_ctx* SharedSdfContext(int device)
+std::mutex& SharedContextGuard()
 {
   static std::mutex guard;
+  return guard;
+}
+std::map<int, vgt_hip_ctx*>& SharedContexts()
+{
   static std::map<int, vgt_hip_ctx*>* contexts = new std::map<int, vgt_hip_ctx*>();
-  std::lock_guard<std::mutex> lock(guard);
-  auto found = contexts->find(device);
-  if (found != contexts->end()) return found->second;
+  return *contexts;
+}
+
+vgt_hip_ctx* SharedSdfContext(int device)
+{
+  std::lock_guard<std::mutex> lock(SharedContextGuard());
+  auto& contexts = SharedContexts();
+  auto found = contexts.find(device);
+  if (found != contexts.end()) return found->second;
   vgt_hip_ctx* ctx = nullptr;
   if (vgt_hip_create(device, -1, &ctx) != VGT_HIP_OK)
     throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
-  (*contexts)[device] = ctx;
+  contexts[device] = ctx;
   return ctx;
 }
 }  // namespace
 
 void ReleaseCachedDeviceMemory()
 {
-  // best effort: the shared contexts exist only for devices that were used
-  int count = 0;
-  if (vgt_hip_device_count(&count) != VGT_HIP_OK) return;
-  for (int d = 0; d < count; d++)
+  // only contexts that exist: a device that was never used is not touched
+  std::vector<vgt_hip_ctx*> existing;
   {
-    try
-    {
-      (void)vgt_hip_trim(SharedSdfContext(d));
-    }
-    catch (const std::exception&)
-    {
-    }
+    std::lock_guard<std::mutex> lock(SharedContextGuard());
+    for (const auto& kv : SharedContexts()) existing.push_back(kv.second);
   }
+  for (vgt_hip_ctx* ctx : existing) (void)vgt_hip_trim(ctx);
+  vgt_hipx_release();  // the multi-device entry point's slab set
 }
 
 SignedDistanceField ExtractSignedDistanceField(

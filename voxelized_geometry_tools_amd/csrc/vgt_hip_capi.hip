@@ -647,10 +647,15 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
 int vgt_hip_trim(vgt_hip_ctx* ctx)
 {
   if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
-  std::lock_guard<std::mutex> lock(ctx->mutex);
-  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
-  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
-  FreeCachedSdfBuffers(ctx);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
+    FreeCachedSdfBuffers(ctx);
+  }
+  // Lock order: an upload lane's mutex is taken BEFORE the context's (UploadAndRun holds its lane while it
+  // records an event under ctx->mutex), so the lanes are released after ctx->mutex has been dropped; a raycast that
+  // is in flight on a lane simply finishes first (FreeUploadLanes takes each lane's mutex and drains its stream).
   FreeUploadLanes(ctx, false);
   return VGT_HIP_OK;
 }
@@ -1275,11 +1280,15 @@ int vgt_hip_cells_object_ids(vgt_hip_ctx* ctx, vgt_hip_cells* cells, uint32_t* i
   // One pass: every id goes into a device hash set, the set is compacted and sorted on the host (the reference
   // collects a std::set, tagged_object_occupancy_map.hpp:268-289).  Only a grid with more distinct ids than the
   // table can hold falls back to the one-id-per-launch scan.
+  // Tagged maps usually hold a handful of ids: a 2^16-slot table (0.5 MiB) serves them; only when it overflows is the
+  // table sized for the worst case (two slots per cell, up to 2^27 slots = 1 GiB).
+  int full_log2 = 10;
+  while (full_log2 < 27 && (int64_t{1} << full_log2) < 2 * n) full_log2++;
+  const int attempts[2] = {std::min(16, full_log2), full_log2};
+  for (int attempt = 0; attempt < 2; attempt++)
   {
-    // at least two slots per cell (every cell could carry its own id), 2^10 .. 2^27 slots
-    int table_log2 = 10;
-    while (table_log2 < 27 && (int64_t{1} << table_log2) < 2 * n) table_log2++;
-    const int kTableLog2 = table_log2;
+    if (attempt == 1 && attempts[1] == attempts[0]) break;
+    const int kTableLog2 = attempts[attempt];
     const size_t slots = size_t{1} << kTableLog2;
     uint32_t* table = nullptr;
     hipError_t err = hipMalloc(reinterpret_cast<void**>(&table), (2 * slots + 64) * sizeof(uint32_t));

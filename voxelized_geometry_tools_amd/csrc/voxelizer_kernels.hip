@@ -511,7 +511,27 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   const size_t need = RaycastScratchBytes(num_points);
   // Large clouds: order by direction and count visits per workgroup in LDS.  Needs the scratch, 32-bit
   // point and cell indices.
-  if (need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL && num_cells < 0xffffffffLL)
+  // (the LDS the two kernels of that path ask for must be granted -- checked BEFORE anything is launched, so that a
+  // refusal, e.g. a large HIP_THREADS_PER_BLOCK, falls back to the plain kernel below instead of failing the call)
+  constexpr size_t kScatterLds = static_cast<size_t>(kSortBins) * sizeof(uint32_t);
+  int table_slots = 1024;
+  while (table_slots < kTableSlotsPerThread * threads_per_block) table_slots <<= 1;
+  const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
+  bool sorted_path = need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL &&
+                     num_cells < 0xffffffffLL;
+  if (sorted_path)
+  {
+    const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(ScatterOrderKernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kScatterLds));
+    const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
+    if (a != hipSuccess || b != hipSuccess)
+    {
+      (void)hipGetLastError();
+      sorted_path = false;
+    }
+  }
+  if (sorted_path)
   {
     const int num_chunks = static_cast<int>((num_points + kSortChunk - 1) / kSortChunk);
     const int64_t entries = static_cast<int64_t>(kSortBins) * num_chunks;
@@ -523,18 +543,8 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
                        point_stride, g, bins, table, num_chunks);
     hipLaunchKernelGGL(BinOffsetsKernel, dim3((kSortBins + 255) / 256), dim3(256), 0, stream, table, num_chunks,
                        bin_total);
-    constexpr size_t kScatterLds = static_cast<size_t>(kSortBins) * sizeof(uint32_t);
-    hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ScatterOrderKernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kScatterLds));
-    if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(256), kScatterLds, stream, bins, num_points, table,
                        num_chunks, bin_total, order);
-    int table_slots = 1024;
-    while (table_slots < kTableSlotsPerThread * threads_per_block) table_slots <<= 1;
-    const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
-    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
-    if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block),
                        table_lds, stream, points_dev, num_points, point_stride, order, g, tracking_dev, table_slots);
     return hipGetLastError();
