@@ -18,21 +18,33 @@ def classify(name):
         return None
     if "ScanZ" in name:
         return "ScanZ"
-    if "PassKernel" in name or "LinePass" in name or "Pass" in name:
+    if "SweepPassKernel" in name:
+        # SweepPassKernel<InT, OutT, kFinal, ...>: the X pass writes floats
+        args = name.split("SweepPassKernel", 1)[1]
+        return "PassXFinalize" if ("float" in args[:24] or "IifL" in args[:8]) else "PassY"
+    if "PassKernel" in name or "Brute" in name:
         # the bool template argument kFinal tells the X pass from the Y pass
-        return "PassXFinalize" if ("true" in name or "b1" in name) else "PassY"
+        return "PassXFinalize" if ("true" in name or "b1" in name or "Finalize" in name) else "PassY"
     return None
 
 
 def main():
     out = sys.argv[1]
+    commit = "unknown"
+    try:
+        commit = open(os.path.join(out, "commit.txt")).read().strip()
+    except OSError:
+        pass
     summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 "
                           "--warmup 1 --no-cpu-baseline (1024^3 D1 spheres), separate passes",
-               "note": "MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a wide "
-                       "(16 B/lane) coalesced read (128-B requests tallied at 64 B), WRITE_SIZE is exact.  "
-                       "'fetch_bytes_corrected' doubles the raw value: all three kernels read 16 B per lane, and with "
-                       "the XCD-aware tile order the L2 also merges the Y pass's neighbouring 32-byte row segments "
-                       "into full requests (its raw value halved, 2.15 -> 1.07 GB, when that order went in).",
+               "commit": commit,
+               "note": "MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a "
+                       "coalesced streaming read (128-B requests tallied at 64 B), WRITE_SIZE is exact.  "
+                       "'fetch_bytes_corrected' doubles the raw value: the Z scan reads 16 B per lane, the sweep passes "
+                       "one 128-B (int16) or 256-B (int32) row segment per wave instruction, which the L2 fetches as "
+                       "whole 128-B requests.  kernel_ns / kernel_name: the kernel these bytes belong to (rocprofv3 "
+                       "--kernel-trace --stats of the same build, AverageNs); bench.py reports the traffic only when "
+                       "the kernel it times agrees within 5 %.",
                "kernels": {}}
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -50,12 +62,17 @@ def main():
                                  "fetch_bytes_corrected": fetch * (2.0 if wide else 1.0), "write_bytes": write,
                                  "hbm_bytes": fetch * (2.0 if wide else 1.0) + write,
                                  "algorithmic": EXPECTED[k]}
-    json.dump(summary, open(os.path.join(out, "pmc_hbm_traffic.json"), "w"), indent=1)
     stats = glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv"))
     if stats:
         rows = list(csv.reader(open(stats[0])))
         with open(os.path.join(out, "rocprof_kernel_stats.csv"), "w") as fh:
             csv.writer(fh).writerows(rows[:12])
+        for row in csv.DictReader(open(stats[0])):
+            k = classify(row["Name"])
+            if k in summary["kernels"] and "kernel_ns" not in summary["kernels"][k]:
+                summary["kernels"][k]["kernel_ns"] = float(row["AverageNs"])
+                summary["kernels"][k]["kernel_name"] = row["Name"][:160]
+    json.dump(summary, open(os.path.join(out, "pmc_hbm_traffic.json"), "w"), indent=1)
     # SQ counters of the three SDF kernels (one pass, 8 SQ slots)
     sq = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(out, "pmc_sq", "*", "*counter_collection.csv")):
@@ -73,6 +90,8 @@ def main():
         for k, d in doc["kernels"].items():
             if "SQ_INSTS_VALU" in d:
                 d["valu_lane_instructions_per_voxel"] = round(d["SQ_INSTS_VALU"] * 1e9 * 64 / 2 ** 30, 1)
+            if "SQ_INSTS_SALU" in d:
+                d["salu_wave_instructions_per_64_voxels"] = round(d["SQ_INSTS_SALU"] * 1e9 * 64 / 2 ** 30, 1)
         json.dump(doc, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
     # raycaster
     rstats = glob.glob(os.path.join(out, "raycast_stats", "*", "*kernel_stats.csv"))

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 #include <new>
@@ -175,29 +176,70 @@ void FreeCachedSdfBuffers(vgt_hip_ctx* ctx)
 // (hipHostMalloc / hipHostRegister by the caller): copies from pageable memory go through the
 // runtime's bounce buffers at a fraction of the PCIe rate and are not asynchronous.  Best effort:
 // when the driver refuses (limits, odd mappings) the copy simply takes the pageable path.
+// Two threads may hand the same array to two contexts at once: the registration is shared through a
+// process-wide table of the ranges THIS library page-locked, with a use count, so the range stays locked until the
+// last call that relies on it has finished.
 class ScopedHostPin
 {
 public:
   ScopedHostPin(const void* ptr, size_t bytes)
   {
     if (!ptr || bytes < (size_t{1} << 20)) return;  // small copies: registration costs more than it saves
+    std::lock_guard<std::mutex> lock(TableLock());
+    auto& table = Table();
+    auto found = table.find(ptr);
+    if (found != table.end())
+    {
+      if (found->second.bytes >= bytes)
+      {
+        found->second.users++;
+        shared_ = ptr;
+      }
+      return;  // (a larger request on a locked range: the copy takes whatever path the runtime picks)
+    }
     hipPointerAttribute_t attr{};
-    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type == hipMemoryTypeHost) return;  // pinned already
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type == hipMemoryTypeHost) return;  // the caller's pin
     (void)hipGetLastError();
     if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess)
-      registered_ = const_cast<void*>(ptr);
+    {
+      table[ptr] = Entry{bytes, 1};
+      shared_ = ptr;
+    }
     else
       (void)hipGetLastError();
   }
   ~ScopedHostPin()
   {
-    if (registered_) (void)hipHostUnregister(registered_);
+    if (!shared_) return;
+    std::lock_guard<std::mutex> lock(TableLock());
+    auto& table = Table();
+    auto found = table.find(shared_);
+    if (found != table.end() && --found->second.users == 0)
+    {
+      (void)hipHostUnregister(const_cast<void*>(shared_));
+      table.erase(found);
+    }
   }
   ScopedHostPin(const ScopedHostPin&) = delete;
   ScopedHostPin& operator=(const ScopedHostPin&) = delete;
 
 private:
-  void* registered_ = nullptr;
+  struct Entry
+  {
+    size_t bytes;
+    int users;
+  };
+  static std::mutex& TableLock()
+  {
+    static std::mutex lock;
+    return lock;
+  }
+  static std::map<const void*, Entry>& Table()
+  {
+    static auto* table = new std::map<const void*, Entry>();
+    return *table;
+  }
+  const void* shared_ = nullptr;
 };
 
 struct SdfWorkspace
