@@ -406,9 +406,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             const int32_t sign = v >> 31;
             bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
             int32_t f = (v ^ sign) - sign;
-            if constexpr (sizeof(InT) == 2) f = (f == kInf16) ? kInf32 : __mul24(f, f);
-            if (f < kLimit)
+            // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
+            if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
             {
+              if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
               const int32_t G = f + q * q;
               int32_t dG = G - Gt;
               int dr = q - rt;
