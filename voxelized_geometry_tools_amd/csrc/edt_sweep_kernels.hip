@@ -160,6 +160,31 @@ __device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[N])
   }
 }
 
+// A pointer into global memory that every lane holds the same value of, told to the compiler (scalar registers, scalar
+// address arithmetic; the address space is spelled out because a pointer rebuilt from integers would be a flat one).
+#ifdef VGT_HOST_EMULATION
+#define VGT_GLOBAL
+#else
+#define VGT_GLOBAL __attribute__((address_space(1)))
+#endif
+template <typename T>
+__device__ __forceinline__ VGT_GLOBAL T* UniformPointer(const VGT_GLOBAL T* p)
+{
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return reinterpret_cast<VGT_GLOBAL T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ VGT_GLOBAL T* GlobalPointer(T* p)
+{
+#ifdef VGT_HOST_EMULATION
+  return p;
+#else
+  return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<uint64_t>(p));
+#endif
+}
+
 __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
@@ -334,13 +359,29 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // =====================================================================================================
   uint32_t any_transition = 0;
   {
+    // Rows are loaded through a wave-uniform pointer that steps by the row stride, plus the lane's 32-bit offset: the
+    // address of a row costs two scalar adds and no vector register (the readfirstlane keeps the compiler from folding
+    // the lane offset into a per-lane 64-bit base, which costs a register pair and a 64-bit vector add per row).
     auto load_band = [&](int32_t (&dst)[kBand], int first_row) {
-      // rows past the end repeat the last row (not used)
-#pragma unroll
-      for (int k = 0; k < kBand; k++)
+      const VGT_GLOBAL InT* row_in = UniformPointer(GlobalPointer(wave_in + static_cast<int64_t>(first_row) * rstride));
+      if (first_row + kBand <= n)
       {
-        const int64_t row = min(first_row + k, n - 1);
-        dst[k] = static_cast<int32_t>((wave_in + row * rstride)[zl]);
+#pragma unroll
+        for (int k = 0; k < kBand; k++)
+        {
+          dst[k] = static_cast<int32_t>(row_in[zl]);
+          row_in = UniformPointer(row_in + rstride);
+        }
+      }
+      else
+      {
+        // the last, partial band: rows past the end repeat the last row (not used)
+#pragma unroll
+        for (int k = 0; k < kBand; k++)
+        {
+          dst[k] = static_cast<int32_t>(row_in[zl]);
+          if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
+        }
       }
     };
     // every kChunk rows: the ring must have room for kChunk pushes
@@ -508,7 +549,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     if (nwords > 1) info_below = (wave_info + static_cast<int64_t>(nwords - 2) * kWaveSize)[lane];
     uint2 info_next = make_uint2(0u, 0u);
     uint32_t xdn_word = 0, xup_word = 0;
-    OutT* row_out = wave_out + static_cast<int64_t>(n - 1) * rstride;  // row being evaluated
+    VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));  // row being evaluated
     const int last_band = (n - 1) / kBand * kBand;
     for (int r0 = last_band; r0 >= 0; r0 -= kBand)
     {
@@ -623,7 +664,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
               row_out[zl] = (d2 ^ sign) - sign;
             }
-            row_out -= rstride;
+            row_out = UniformPointer(row_out - rstride);
           }
         }
       };
