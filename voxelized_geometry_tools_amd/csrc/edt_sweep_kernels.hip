@@ -428,6 +428,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     const int32_t n2m = 2 * (n - 1);
     for (int r0 = 0; r0 < n; r0 += kBand)
     {
+      __builtin_assume(r0 >= 0 && r0 < 16384);
       int32_t cur[kBand];
 #pragma unroll
       for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
@@ -463,7 +464,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                   dr = q - rt;
                 } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
               }
-              if (dG < __mul24(n2m, dr))
+              __builtin_assume(dr > 0 && dr < 16384);
+              if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
               {
                 VGT_SWEEP_COUNT(13, 1);
                 ring_ref(D) = C::Pack(G, q);
@@ -553,6 +555,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     const int last_band = (n - 1) / kBand * kBand;
     for (int r0 = last_band; r0 >= 0; r0 -= kBand)
     {
+      __builtin_assume(r0 >= 0 && r0 < 16384);
       const int sub = r0 & (kWord - 1);
       if (sub + kBand == kWord || r0 == last_band)
       {
@@ -605,13 +608,18 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             const int q = r0 + k;
             const int q2 = 2 * q;
             // the second member is at least as good at row q: the top owns nothing at or below q
-            if (!(VGT_SWEEP_EXP & 16) && __mul24(A, q2) + nB <= 0)
+            // (rows and row differences are below 2^14: plain unsigned 24-bit multiplies)
+            __builtin_assume(A >= 0 && A < 16384 && rt >= 0 && rt < 16384);
+            if (!(VGT_SWEEP_EXP & 16) && static_cast<int32_t>(__umul24(A, q2)) + nB <= 0)
             {
-              do pop();
-              while (__mul24(A, q2) + nB <= 0);
+              do
+              {
+                pop();
+                __builtin_assume(A >= 0 && A < 16384 && rt >= 0 && rt < 16384);
+              } while (static_cast<int32_t>(__umul24(A, q2)) + nB <= 0);
             }
             // value of the top at q: Gt + q^2 - 2 q rt
-            uint32_t best = static_cast<uint32_t>(__mul24(rt, -q2) + Gt + q * q);
+            uint32_t best = static_cast<uint32_t>(Gt + q * q) - __umul24(rt, q2);
             if (classes)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
