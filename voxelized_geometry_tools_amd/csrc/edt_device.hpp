@@ -72,11 +72,11 @@ __device__ __forceinline__ float SqrtTimesResolutionExact(int32_t d2, double res
 // e0^2 / 2 + e0 * e_h), so the product with the resolution is within ~2^10 double ulps of the
 // reference's doubly rounded product.  Rounding either one to float gives the same result unless
 // the product lies that close to the midpoint of two floats, i.e. its 29 bits below the float
-// mantissa are within 2^10 of 2^28; a window of 2^13 is tested and those few values (2^-15 of
-// all) take the exact path, as does everything when the float result could be subnormal or
-// overflow.  tests/test_gpu_sdf.py::test_fast_finalize_matches_exact_for_every_d2 compares the two
-// over all d2 in [0, 2^31).
-__device__ __forceinline__ float SqrtTimesResolution(int32_t d2, double resolution)
+// mantissa are within 2^10 of 2^28; a window of 2^13 is tested (`unsure`: 2^-15 of all values) and the
+// caller takes the exact path for those, as for everything when the float result could be subnormal or
+// overflow (resolution outside (1e-30, 1e30)) and for d2 <= 0.
+// tests/test_gpu_sdf.py::test_fast_finalize_matches_exact_for_every_d2 compares the two over all d2 in [0, 2^31).
+__device__ __forceinline__ float FastSqrtTimesResolution(uint32_t d2, double resolution, bool& unsure)
 {
   const float xf = static_cast<float>(d2);
   const float y0 = __frsqrt_rn(xf);
@@ -84,11 +84,18 @@ __device__ __forceinline__ float SqrtTimesResolution(int32_t d2, double resoluti
   const double hd = static_cast<double>(0.5f * y0);
   const double rem = fma(-gd, gd, static_cast<double>(d2));  // exact: gd has 24 significant bits
   const double p = fma(rem, hd, gd) * resolution;
-  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p)) & 0x1fffffffu;
-  const int off = static_cast<int>(low) - 0x10000000;
-  const bool range_ok = (resolution > 1.0e-30) && (resolution < 1.0e30);
-  if (d2 <= 0 || !range_ok || (off > -8192 && off < 8192)) return SqrtTimesResolutionExact(d2, resolution);
+  // the 29 bits below the float mantissa within 2^13 of one half: (low29 - (2^28 - 8191)) mod 2^29 < 16383
+  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p));
+  unsure = ((low << 3) - ((0x10000000u - 8191u) << 3)) < (16383u << 3);
   return static_cast<float>(p);
+}
+__device__ __forceinline__ float SqrtTimesResolution(int32_t d2, double resolution)
+{
+  const bool range_ok = (resolution > 1.0e-30) && (resolution < 1.0e30);
+  if (d2 <= 0 || !range_ok) return SqrtTimesResolutionExact(d2, resolution);
+  bool unsure;
+  const float fast = FastSqrtTimesResolution(static_cast<uint32_t>(d2), resolution, unsure);
+  return unsure ? SqrtTimesResolutionExact(d2, resolution) : fast;
 }
 
 // Virtual border (signed_distance_field_generation.hpp:134-284) through its closed form

@@ -190,24 +190,6 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
 }
 
-// float(sqrt(double(d2)) * resolution) for 1 <= d2 < 2^31 by the fast evaluation of SqrtTimesResolution
-// (edt_device.hpp), without its guards: `unsure` says that the product lies so close to the midpoint of two floats
-// that only the exact evaluation can decide (2^-15 of all values); the caller also takes the exact evaluation for
-// resolutions outside (1e-30, 1e30).
-__device__ __forceinline__ float FastSqrtTimesResolution(uint32_t d2, double resolution, bool& unsure)
-{
-  const float xf = static_cast<float>(d2);
-  const float y0 = __frsqrt_rn(xf);
-  const double gd = static_cast<double>(xf * y0);
-  const double hd = static_cast<double>(0.5f * y0);
-  const double rem = fma(-gd, gd, static_cast<double>(d2));
-  const double p = fma(rem, hd, gd) * resolution;
-  // the 29 bits below the float mantissa within 2^13 of one half: (low29 - (2^28 - 8191)) mod 2^29 < 16383
-  const uint32_t low = static_cast<uint32_t>(__double_as_longlong(p));
-  unsure = ((low << 3) - ((0x10000000u - 8191u) << 3)) < (16383u << 3);
-  return static_cast<float>(p);
-}
-
 // Host emulation (tests/cpp/sweep_emulation.cc compiles this file with g++ and runs the lanes one by one): no GPU asm.
 #ifdef VGT_HOST_EMULATION
 #define VGT_COLD_PATH()
