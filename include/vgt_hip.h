@@ -379,6 +379,27 @@ void vgt_hipx_release(void);
  * phases of different slabs overlap), [4] the whole call. */
 int vgt_hipx_last_timing(float* ms5);
 
+
+/* ---- ONE point cloud over several devices (the reference dispatches whole clouds,
+ *      S/device_pointcloud_voxelization.cpp:147-149, so a single large cloud uses one device there).
+ *      DeviceVoxelizationHelperInterface::RaycastPoints (I/device_voxelization_interface.hpp:151-158) with the
+ *      points cut into 1 + num_helpers contiguous shares (vgt_hipx_point_share: equal shares, earlier shares take
+ *      the remainder): share 0 is cast on `ctx`'s device straight into grid `grid_index`, share k on
+ *      helper_devices[k-1] into a private tracking grid, and the private grids are then ADDED into grid
+ *      `grid_index` -- rccl ncclReduce(sum, int32, root = ctx's device) when all the devices are distinct,
+ *      copy + add otherwise (a device listed twice, or the caller's own: the one-GPU test of this path).
+ *      Tracking counts are integers, so the result equals vgt_hip_raycast_points_f32 on the whole cloud bit for
+ *      bit, whatever the split; counts already in the grid are kept.  Blocking; the sum is ordered on ctx's
+ *      stream, so the filter that follows sees it.  Helper contexts and grids are kept for the next call with
+ *      the same (device, helper list, cell count); vgt_hipx_release frees them.  num_helpers = 0 is the plain call. */
+void vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count);
+int vgt_hipx_raycast_points_split(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                  const int* helper_devices, int num_helpers, const float* points_xyz_host,
+                                  int64_t num_points, float max_range, const float* grid_pointcloud_transform,
+                                  float voxel_size, float inverse_voxel_size, float grid_x_size,
+                                  float grid_y_size, float grid_z_size, int32_t num_x_voxels,
+                                  int32_t num_y_voxels, int32_t num_z_voxels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,6 +327,18 @@ static void PointCloudVoxelizationTests(int dispatch_threads)
       catch (const std::invalid_argument&) { rejected = true; }
       EXPECT_TRUE(rejected);
     }
+    {
+      // SURVEY 8e, single cloud over several devices: HIP_SPLIT_HELPERS shares every cloud of at least
+      // HIP_SPLIT_MIN_POINTS points (the helpers wrap around to this device on a one-GPU box); same grid.
+      std::map<std::string, int32_t> split = merged;
+      split["HIP_SPLIT_HELPERS"] = 3;
+      split["HIP_SPLIT_MIN_POINTS"] = 100;
+      const HipPointCloudVoxelizer split_voxelizer(split, logging_fn);
+      const OccupancyMap from_shares =
+          split_voxelizer.VoxelizePointClouds(static_environment, filter_options, {cam1, cam2, cam3});
+      check_voxelization(from_shares);
+      EXPECT_TRUE(from_shares.GetImmutableRawData() == voxelized.GetImmutableRawData());
+    }
     // argument validation of the public entry point (pointcloud_voxelization_interface.hpp:267-289)
     bool threw = false;
     try { voxelizer.VoxelizePointClouds(static_environment, filter_options, {nullptr}); }

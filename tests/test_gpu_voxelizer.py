@@ -135,6 +135,93 @@ def test_config3_full_size_counts_bit_exact(ctx, oracle, sensor):
     grids.close()
 
 
+@pytest.mark.parametrize("helpers", [[], [0], [0, 0, 0], [0] * 7])
+@pytest.mark.parametrize("sensor", [(2.56, 2.56, 2.56), (-1.0, 2.56, 2.56)])
+def test_one_cloud_split_over_devices(ctx, oracle, sensor, helpers):
+    """vgt_hipx_raycast_points_split (single cloud): shares of the points in private grids, summed into
+    the caller's grid -- bit-equal to the oracle on the whole cloud whatever the split; counts already in the grid
+    stay.  One GPU here, so the helpers are the caller's own device (copy + add branch)."""
+    counts = (96, 96, 96)
+    vs = np.float32(5.12 / 96)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(100_003, seed=7)
+    xf = synthetic.translation_xform(*sensor).astype(np.float32)
+    grids = ctx.tracking_grids(int(np.prod(counts)), 2)
+    grids.raycast_f32_split(1, helpers, pts, 3.0, xf, vs, ivs, sizes, counts)
+    want = oracle.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+    assert np.array_equal(grids.retrieve(1, counts), want)
+    assert not grids.retrieve(0).any()
+    # a second cloud into the same grid accumulates, as RaycastPoints does
+    grids.raycast_f32_split(1, helpers, pts[:1000], 3.0, xf, vs, ivs, sizes, counts)
+    want2 = want + oracle.raycast_f32(pts[:1000], 3.0, xf, vs, ivs, sizes, counts)
+    assert np.array_equal(grids.retrieve(1, counts), want2)
+    # fewer points than shares; no points at all
+    few = ctx.tracking_grids(int(np.prod(counts)), 1)
+    few.raycast_f32_split(0, helpers, pts[:3], 3.0, xf, vs, ivs, sizes, counts)
+    assert np.array_equal(few.retrieve(0, counts), oracle.raycast_f32(pts[:3], 3.0, xf, vs, ivs, sizes, counts))
+    few.clear()
+    few.raycast_f32_split(0, helpers, pts[:0], 3.0, xf, vs, ivs, sizes, counts)
+    assert not few.retrieve(0).any()
+    few.close()
+    grids.close()
+    capi.sdf_multi_release()
+
+
+def test_one_cloud_split_errors(ctx):
+    counts = (8, 8, 8)
+    grids = ctx.tracking_grids(512, 1)
+    pts = np.zeros((10, 3), dtype=np.float32)
+    xf = np.eye(4, dtype=np.float32).T
+    with pytest.raises(capi.VgtHipError, match="out of range"):
+        grids.raycast_f32_split(0, [99], pts, 1.0, xf, 1.0, 1.0, [8.0] * 3, counts)
+    with pytest.raises(ValueError, match="index out of range"):
+        grids.raycast_f32_split(3, [0], pts, 1.0, xf, 1.0, 1.0, [8.0] * 3, counts)
+    with pytest.raises(ValueError, match="do not match"):
+        grids.raycast_f32_split(0, [0], pts, 1.0, xf, 1.0, 1.0, [8.0] * 3, (8, 8, 9))
+    grids.close()
+
+
+def test_ray_split_over_torch_distributed(ctx, oracle):
+    """multi_gpu.RaySplit with a one-rank RCCL group: the library's tracking grid is the all-reduce's tensor
+    (no copy), and the share rule is the library's."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from voxelized_geometry_tools_amd import multi_gpu
+    for n, world in ((10, 3), (100_003, 8), (2, 5)):
+        for r in range(world):
+            assert multi_gpu.point_share(n, world, r) == capi.point_share(n, world, r)
+    counts = (64, 64, 64)
+    vs = np.float32(0.08)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(50_000, seed=3)
+    xf = synthetic.translation_xform(2.56, 2.56, 2.56).astype(np.float32)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+        split = multi_gpu.RaySplit(torch, dist, grids, 0, dev)
+        first, count = multi_gpu.point_share(pts.shape[0], 1, 0)
+        share = torch.from_numpy(pts[first:first + count]).to(dev)
+        total = split.run(share, 3.0, xf, vs, ivs, sizes, counts)
+        torch.cuda.synchronize()
+        want = oracle.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+        assert np.array_equal(total.cpu().numpy().reshape(counts + (2,)), want)
+        assert np.array_equal(grids.retrieve(0, counts), want)
+        grids.close()
+    finally:
+        ctx.reset_stream()
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("kind", ["one_direction", "two_points", "tiny_grid", "f64"])
 def test_accumulation_table_corner_cases(ctx, oracle, kind):
     """Clouds that stress the per-workgroup LDS accumulation: every ray identical (one hot chain of cells),

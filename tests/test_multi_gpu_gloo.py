@@ -148,3 +148,62 @@ def test_summary_reference_packs_both_classes():
             else:
                 want = np.where(mask.any(axis=1), np.where(mask, zz, -1).max(axis=1), -1)
             assert np.array_equal(full[r, :, col], want), (r, col)
+
+
+def _ray_worker(rank, world, port, queue):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from voxelized_geometry_tools_amd import multi_gpu, synthetic
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        counts = (24, 24, 24)
+        vs = np.float32(5.12 / 24)
+        ivs = np.float32(1.0) / vs
+        sizes = [np.float32(c) * vs for c in counts]
+        pts = synthetic.raycast_cloud(5_001, seed=11)
+        xf = synthetic.translation_xform(-1.0, 2.56, 2.56).astype(np.float32)
+        first, count = multi_gpu.point_share(pts.shape[0], world, rank)
+        mine = O.raycast_f32(pts[first:first + count], 3.0, xf, vs, ivs, sizes, counts)
+        want = O.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+        everywhere = multi_gpu.sum_counts(dist, torch.from_numpy(mine.copy()).view(-1))
+        ok = bool(np.array_equal(everywhere.numpy().reshape(want.shape), want))
+        on_root = multi_gpu.sum_counts(dist, torch.from_numpy(mine.copy()).view(-1), root=0)
+        if rank == 0:
+            ok = ok and bool(np.array_equal(on_root.numpy().reshape(want.shape), want))
+        queue.put((rank, ok, None))
+    except Exception as exc:  # pragma: no cover
+        queue.put((rank, False, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_cloud_ray_split_over_gloo(world):
+    """multi_gpu.point_share + sum_counts: the ranks' private tracking counts (here from the oracle) add up to the
+    whole cloud's counts bit for bit -- the property vgt_hipx_raycast_points_split and RaySplit rest on."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ray_worker, args=(r, world, port, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [queue.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, err in results:
+        assert err is None, "rank %d: %s" % (rank, err)
+        assert ok, "rank %d: summed counts differ from the whole cloud's" % rank
+
+
+def test_point_share_matches_library():
+    from voxelized_geometry_tools_amd import capi, multi_gpu
+    for n, world in ((0, 1), (1, 4), (10, 3), (1_000_000, 8), (7, 7), (100_003, 6)):
+        shares = [multi_gpu.point_share(n, world, r) for r in range(world)]
+        assert shares == [capi.point_share(n, world, r) for r in range(world)]
+        assert sum(c for _, c in shares) == n
+        assert all(shares[r][0] + shares[r][1] == shares[r + 1][0] for r in range(world - 1))

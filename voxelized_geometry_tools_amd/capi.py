@@ -70,6 +70,9 @@ SIGNATURES = {
     "vgt_hipx_sdf_multi": (_int, [_p, _int, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hipx_release": (None, []),
     "vgt_hipx_last_timing": (_int, [_p]),
+    "vgt_hipx_point_share": (None, [_i64, _i32, _i32, _p, _p]),
+    "vgt_hipx_raycast_points_split": (_int, [_p, _p, _sz, _p, _int, _p, _i64, _f32, _p, _f32, _f32, _f32, _f32,
+                                             _f32, _i32, _i32, _i32]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
@@ -369,6 +372,13 @@ def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtua
     return out, lo.value, hi.value
 
 
+def point_share(num_points, shares, share):
+    """vgt_hipx_point_share -> (first, count) of `share` among `shares` contiguous shares of a cloud."""
+    first, count = ctypes.c_int64(0), ctypes.c_int64(0)
+    load().vgt_hipx_point_share(int(num_points), int(shares), int(share), ctypes.byref(first), ctypes.byref(count))
+    return first.value, count.value
+
+
 def sdf_multi_release():
     """Frees the device state vgt_hipx_sdf_multi keeps between calls."""
     load().vgt_hipx_release()
@@ -426,6 +436,19 @@ class TrackingGrids:
         check(self._lib.vgt_hip_raycast_points_f32(
             self.ctx.handle, self.handle, index, _ptr(pts) if pts.size else None, pts.size // 3,
             float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
+            float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
+            int(counts[0]), int(counts[1]), int(counts[2])))
+
+    def raycast_f32_split(self, index, helper_devices, points, max_range, xform, voxel_size, inverse_voxel_size,
+                          grid_sizes, counts):
+        """vgt_hipx_raycast_points_split: one cloud over this context's device + `helper_devices` (a device may
+        repeat); the private grids are summed into grid `index`."""
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1)
+        T = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+        devs = (ctypes.c_int * max(len(helper_devices), 1))(*[int(d) for d in helper_devices])
+        check(self._lib.vgt_hipx_raycast_points_split(
+            self.ctx.handle, self.handle, index, devs, len(helper_devices), _ptr(pts) if pts.size else None,
+            pts.size // 3, float(max_range), _ptr(T), float(voxel_size), float(inverse_voxel_size),
             float(grid_sizes[0]), float(grid_sizes[1]), float(grid_sizes[2]),
             int(counts[0]), int(counts[1]), int(counts[2])))
 

@@ -77,6 +77,13 @@ public:
         RetrieveOptionOrDefault(options, "HIP_THREADS_PER_BLOCK", -1, logging_fn);
     const int32_t device = RetrieveOptionOrDefault(options, "HIP_DEVICE", 0, logging_fn);
     exact_fp64_ = RetrieveOptionOrDefault(options, "HIP_EXACT_FP64", 0, logging_fn) > 0;
+    // One large cloud over several devices (vgt_hipx_raycast_points_split): HIP_SPLIT_HELPERS further devices,
+    // counted on from HIP_DEVICE (wrapping around), share every cloud of at least HIP_SPLIT_MIN_POINTS points.
+    const int32_t split_helpers = RetrieveOptionOrDefault(options, "HIP_SPLIT_HELPERS", 0, logging_fn);
+    split_min_points_ = RetrieveOptionOrDefault(options, "HIP_SPLIT_MIN_POINTS", 1 << 20, logging_fn);
+    int device_count = 0;
+    if (split_helpers > 0 && vgt_hip_device_count(&device_count) == VGT_HIP_OK && device_count > 0)
+      for (int32_t k = 0; k < split_helpers; k++) split_devices_.push_back((device + 1 + k) % device_count);
     if (logging_fn)
     {
       logging_fn(threads > 0 ? "Set HIP threads per block to specified " + std::to_string(threads)
@@ -122,9 +129,17 @@ public:
       const size_t tracking_grid_index) override
   {
     HipTrackingGridsHandle& real = dynamic_cast<HipTrackingGridsHandle&>(tracking_grids);
+    const int64_t num_points = static_cast<int64_t>(raw_points.size() / 3);
+    if (!split_devices_.empty() && num_points >= split_min_points_)
+    {
+      Check(vgt_hipx_raycast_points_split(
+          ctx_, real.Get(), tracking_grid_index, split_devices_.data(), static_cast<int>(split_devices_.size()),
+          raw_points.data(), num_points, max_range, grid_pointcloud_transform, voxel_size, inverse_voxel_size,
+          grid_x_size, grid_y_size, grid_z_size, num_x_voxels, num_y_voxels, num_z_voxels));
+      return;
+    }
     Check(vgt_hip_raycast_points_f32(
-        ctx_, real.Get(), tracking_grid_index, raw_points.data(),
-        static_cast<int64_t>(raw_points.size() / 3), max_range, grid_pointcloud_transform,
+        ctx_, real.Get(), tracking_grid_index, raw_points.data(), num_points, max_range, grid_pointcloud_transform,
         voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size, num_x_voxels,
         num_y_voxels, num_z_voxels));
   }
@@ -191,6 +206,8 @@ public:
 private:
   vgt_hip_ctx* ctx_ = nullptr;
   bool exact_fp64_ = false;
+  std::vector<int> split_devices_;   // helper devices of vgt_hipx_raycast_points_split (HIP_SPLIT_HELPERS)
+  int64_t split_min_points_ = 1 << 20;
 };
 }  // namespace
 

@@ -118,6 +118,7 @@ int Fail(int code, const std::string& msg)
 namespace vgt
 {
 void SetLastError(const std::string& message) { g_last_error = message; }
+hipStream_t ContextStream(const vgt_hip_ctx* ctx) { return ctx->stream; }
 }  // namespace vgt
 namespace
 {

@@ -16,6 +16,10 @@
 // for the life of the process (CommSet below); so are the per-slab contexts, streams and device buffers of the
 // last (device list, grid shape) served (SlabSet below).  The field's extrema are reduced on the host: this
 // process already holds every device's (min, max) pair.
+//
+// vgt_hipx_raycast_points_split (end of the file): ONE point cloud over several devices -- contiguous shares of
+// the points, a private tracking grid per device, then the grids are summed onto the caller's device (the
+// counts are integers: the sum is the whole cloud's counts whatever the split).
 #include "../../include/vgt_hip.h"
 
 #include "vgt_internal.hpp"
@@ -45,6 +49,7 @@ struct Rccl
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string error;  // why it is unavailable (empty = loaded)
 };
@@ -69,8 +74,10 @@ const Rccl& GetRccl()
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(lib, "ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(lib, "ncclAllGather"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(lib, "ncclReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.GetErrorString)
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.Reduce ||
+        !r.GetErrorString)
       r.error = "librccl.so.1 lacks a required entry point";
     return r;
   }();
@@ -242,13 +249,60 @@ int BuildSlabSet(SlabSet* set)
   }
   return VGT_HIP_OK;
 }
+
+// The helper devices of vgt_hipx_raycast_points_split: per helper a context, a stream for the reduction and one
+// private tracking grid; `landing` is a buffer on the caller's device that a helper's grid is copied to when rccl
+// cannot do the sum (a device listed twice).  Kept for the next call with the same (caller device, helper list,
+// cell count), like SlabSet.
+struct RayHelper
+{
+  int device = -1;
+  vgt_hip_ctx* ctx = nullptr;
+  vgt_hip_grids* grids = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+struct RaySet
+{
+  int primary_device = -1;
+  std::vector<int> helper_devices;
+  int64_t num_cells = 0;
+  std::vector<RayHelper> helpers;
+  int32_t* landing = nullptr;
+
+  ~RaySet()
+  {
+    for (RayHelper& h : helpers)
+    {
+      if (h.device < 0) continue;
+      (void)hipSetDevice(h.device);
+      if (h.stream) (void)hipStreamSynchronize(h.stream);
+      if (h.grids) vgt_hip_tracking_grids_destroy(h.grids);
+      if (h.ctx) vgt_hip_destroy(h.ctx);
+      if (h.stream) (void)hipStreamDestroy(h.stream);
+    }
+    if (landing)
+    {
+      (void)hipSetDevice(primary_device);
+      (void)hipFree(landing);
+    }
+  }
+};
+
+std::mutex g_ray_lock;       // held for the whole of a split raycast: one at a time per process
+RaySet* g_ray_set = nullptr;  // guarded by g_ray_lock
 }  // namespace
 
 extern "C" void vgt_hipx_release(void)
 {
-  std::lock_guard<std::mutex> guard(g_set_lock);
-  delete g_set;
-  g_set = nullptr;
+  {
+    std::lock_guard<std::mutex> guard(g_set_lock);
+    delete g_set;
+    g_set = nullptr;
+  }
+  std::lock_guard<std::mutex> guard(g_ray_lock);
+  delete g_ray_set;
+  g_ray_set = nullptr;
 }
 
 extern "C" int vgt_hipx_last_timing(float* ms5)
@@ -444,5 +498,195 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   g_last_timing[2] = compute_ms;
   g_last_timing[3] = download_ms;
   g_last_timing[4] = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+  return VGT_HIP_OK;
+}
+
+extern "C" void vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count)
+{
+  // equal shares, earlier shares take the remainder (the rule of vgt_hip_sdf_slab_range)
+  vgt::SlabRange(num_points, shares, share, first, count);
+}
+
+extern "C" int vgt_hipx_raycast_points_split(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
+                                             const int* helper_devices, int num_helpers, const float* points_xyz_host,
+                                             int64_t num_points, float max_range,
+                                             const float* grid_pointcloud_transform, float voxel_size,
+                                             float inverse_voxel_size, float grid_x_size, float grid_y_size,
+                                             float grid_z_size, int32_t num_x_voxels, int32_t num_y_voxels,
+                                             int32_t num_z_voxels)
+{
+  if (!ctx || !grids) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (num_helpers < 0 || (num_helpers > 0 && !helper_devices))
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid helper device list");
+  if (num_points < 0 || (num_points > 0 && !points_xyz_host))
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid point buffer");
+  int device_count = 0;
+  if (hipGetDeviceCount(&device_count) != hipSuccess || device_count <= 0)
+    return FailMulti(VGT_HIP_ERR_UNAVAILABLE, "no usable HIP device (libvgt_hip has no CPU fallback)");
+  for (int i = 0; i < num_helpers; i++)
+    if (helper_devices[i] < 0 || helper_devices[i] >= device_count)
+      return FailMulti(VGT_HIP_ERR_UNAVAILABLE, "device " + std::to_string(helper_devices[i]) + " out of range for " +
+                                                    std::to_string(device_count) + " devices");
+  const int primary_device = vgt_hip_device_of(ctx);
+  const int64_t num_cells = vgt_hip_tracking_grids_num_cells(grids);
+  // a share nobody would miss is not worth a device: at most one helper per point beyond the caller's own
+  const int helpers = static_cast<int>(std::min<int64_t>(num_helpers, std::max<int64_t>(num_points - 1, 0)));
+  const int shares = helpers + 1;
+  int64_t first = 0, count = 0;
+  vgt::SlabRange(num_points, shares, 0, &first, &count);
+  if (helpers == 0)  // also the argument checks of the plain call
+    return vgt_hip_raycast_points_f32(ctx, grids, grid_index, points_xyz_host, num_points, max_range,
+                                      grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size,
+                                      grid_y_size, grid_z_size, num_x_voxels, num_y_voxels, num_z_voxels);
+  if (!grid_pointcloud_transform) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (grid_index >= static_cast<size_t>(vgt_hip_tracking_grids_num_grids(grids)))
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grid index out of range");
+  if (num_x_voxels <= 0 || num_y_voxels <= 0 || num_z_voxels <= 0 ||
+      static_cast<int64_t>(num_x_voxels) * num_y_voxels * num_z_voxels != num_cells)
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "voxel counts do not match the tracking grids");
+  auto* const target = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
+  if (!target) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grids have been released");
+
+  const std::vector<int> helper_list(helper_devices, helper_devices + helpers);
+  std::lock_guard<std::mutex> ray_guard(g_ray_lock);
+  if (g_ray_set && !(g_ray_set->primary_device == primary_device && g_ray_set->helper_devices == helper_list &&
+                     g_ray_set->num_cells == num_cells))
+  {
+    delete g_ray_set;
+    g_ray_set = nullptr;
+  }
+  bool distinct = true;
+  for (int a = 0; a < helpers; a++)
+  {
+    if (helper_list[a] == primary_device) distinct = false;
+    for (int b = a + 1; b < helpers; b++)
+      if (helper_list[a] == helper_list[b]) distinct = false;
+  }
+  const size_t grid_bytes = static_cast<size_t>(num_cells) * 2 * sizeof(int32_t);
+  if (!g_ray_set)
+  {
+    auto* fresh = new RaySet();
+    fresh->primary_device = primary_device;
+    fresh->helper_devices = helper_list;
+    fresh->num_cells = num_cells;
+    fresh->helpers.resize(static_cast<size_t>(helpers));
+    int rc = VGT_HIP_OK;
+    for (int k = 0; k < helpers && rc == VGT_HIP_OK; k++)
+    {
+      RayHelper& h = fresh->helpers[k];
+      h.device = helper_list[k];
+      if (hipSetDevice(h.device) != hipSuccess ||
+          hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking) != hipSuccess)
+        rc = FailMulti(VGT_HIP_ERR_RUNTIME, "[create helper stream] HIP error");
+      if (rc == VGT_HIP_OK) rc = vgt_hip_create(h.device, -1, &h.ctx);
+      if (rc == VGT_HIP_OK) rc = vgt_hip_tracking_grids_create(h.ctx, num_cells, 1, &h.grids);
+    }
+    if (rc == VGT_HIP_OK && !distinct)
+    {
+      bool need_landing = false;
+      for (int k = 0; k < helpers; k++)
+        if (helper_list[k] != primary_device) need_landing = true;
+      if (need_landing && (hipSetDevice(primary_device) != hipSuccess ||
+                           hipMalloc(reinterpret_cast<void**>(&fresh->landing), grid_bytes) != hipSuccess))
+        rc = FailMulti(VGT_HIP_ERR_RUNTIME, "[allocate landing grid] HIP error");
+    }
+    if (rc != VGT_HIP_OK)
+    {
+      delete fresh;
+      return rc;
+    }
+    g_ray_set = fresh;
+  }
+  RaySet& set = *g_ray_set;
+
+  // every share on its own device, concurrently: the helpers on threads of their own (the call uploads its share
+  // and returns when its kernel has finished), the caller's share here, straight into the caller's grid
+  std::vector<int> codes(static_cast<size_t>(helpers), VGT_HIP_OK);
+  std::vector<std::string> messages(static_cast<size_t>(helpers));
+  std::vector<std::thread> workers;
+  workers.reserve(static_cast<size_t>(helpers));
+  for (int k = 0; k < helpers; k++)
+    workers.emplace_back([&, k] {
+      RayHelper& h = set.helpers[k];
+      int64_t begin = 0, share = 0;
+      vgt::SlabRange(num_points, shares, k + 1, &begin, &share);
+      int rc = vgt_hip_tracking_grids_clear(h.ctx, h.grids);
+      if (rc == VGT_HIP_OK)
+        rc = vgt_hip_raycast_points_f32(h.ctx, h.grids, 0, points_xyz_host + 3 * begin, share, max_range,
+                                        grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size,
+                                        grid_y_size, grid_z_size, num_x_voxels, num_y_voxels, num_z_voxels);
+      codes[k] = rc;
+      if (rc != VGT_HIP_OK) messages[k] = vgt_hip_last_error();  // the message is the worker thread's own
+    });
+  const int own_rc = vgt_hip_raycast_points_f32(ctx, grids, grid_index, points_xyz_host + 3 * first, count, max_range,
+                                                grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size,
+                                                grid_y_size, grid_z_size, num_x_voxels, num_y_voxels, num_z_voxels);
+  for (std::thread& t : workers) t.join();
+  if (own_rc != VGT_HIP_OK) return own_rc;
+  for (int k = 0; k < helpers; k++)
+    if (codes[k] != VGT_HIP_OK) return FailMulti(codes[k], messages[k]);
+
+  // the sum, onto the caller's grid, on the caller's stream (later calls on `ctx` -- the filter -- see it)
+  const hipStream_t primary_stream = vgt::ContextStream(ctx);
+  const size_t counts = static_cast<size_t>(num_cells) * 2;
+  if (distinct)
+  {
+    const Rccl& rccl = GetRccl();
+    if (!rccl.error.empty()) return FailMulti(VGT_HIP_ERR_UNAVAILABLE, rccl.error);
+    std::vector<int> clique;
+    clique.push_back(primary_device);
+    clique.insert(clique.end(), helper_list.begin(), helper_list.end());
+    std::string comm_error;
+    CommSet* const comms = GetCommSet(rccl, clique, &comm_error);
+    if (!comms) return FailMulti(VGT_HIP_ERR_RUNTIME, comm_error);
+    std::unique_lock<std::mutex> comm_lock(comms->in_use);
+    // held until the streams have drained, whatever happens below
+    struct Drain
+    {
+      RaySet& set;
+      int primary_device;
+      hipStream_t primary_stream;
+      ~Drain()
+      {
+        for (RayHelper& h : set.helpers)
+        {
+          (void)hipSetDevice(h.device);
+          (void)hipStreamSynchronize(h.stream);
+        }
+        (void)hipSetDevice(primary_device);
+        (void)hipStreamSynchronize(primary_stream);
+      }
+    } drain{set, primary_device, primary_stream};
+    VGTX_NCCL(rccl.GroupStart(), "ncclGroupStart");
+    ncclResult_t res = rccl.Reduce(target, target, counts, ncclInt32, ncclSum, 0, comms->comms[0], primary_stream);
+    for (int k = 0; k < helpers && res == ncclSuccess; k++)
+    {
+      RayHelper& h = set.helpers[k];
+      void* const mine = vgt_hip_tracking_grids_dev_ptr(h.grids, 0);
+      res = rccl.Reduce(mine, nullptr, counts, ncclInt32, ncclSum, 0, comms->comms[k + 1], h.stream);
+    }
+    if (res != ncclSuccess)
+    {
+      (void)rccl.GroupEnd();
+      return FailMulti(VGT_HIP_ERR_RUNTIME, std::string("[ncclReduce] RCCL error [") + rccl.GetErrorString(res) + "]");
+    }
+    VGTX_NCCL(rccl.GroupEnd(), "ncclGroupEnd");
+    return VGT_HIP_OK;  // ~Drain waits for the reduction
+  }
+  VGTX_HIP(hipSetDevice(primary_device), "set device");
+  for (int k = 0; k < helpers; k++)
+  {
+    RayHelper& h = set.helpers[k];
+    const auto* mine = static_cast<const int32_t*>(vgt_hip_tracking_grids_dev_ptr(h.grids, 0));
+    if (h.device != primary_device)
+    {
+      VGTX_HIP(hipMemcpyPeerAsync(set.landing, primary_device, mine, h.device, grid_bytes, primary_stream),
+               "copy a share's tracking grid");
+      mine = set.landing;
+    }
+    VGTX_HIP(vgt::LaunchAccumulateCounts(target, mine, static_cast<int64_t>(counts), primary_stream),
+             "add a share's tracking grid");
+  }
+  VGTX_HIP(hipStreamSynchronize(primary_stream), "wait for the sum");
   return VGT_HIP_OK;
 }

@@ -14,6 +14,13 @@ namespace vgt
 // Sets the calling thread's vgt_hip_last_error() message (for translation units other than
 // vgt_hip_capi.hip that implement parts of the C ABI).
 void SetLastError(const std::string& message);
+}  // namespace vgt
+struct vgt_hip_ctx;
+namespace vgt
+{
+// The stream a context enqueues on (vgt_hip_set_stream's, or its own), for translation units that add work
+// which later calls on the context must see (vgt_hipx_multi.hip).
+hipStream_t ContextStream(const vgt_hip_ctx* ctx);
 
 // Intermediate encodings of the signed Euclidean distance transform.
 //  pass 1 (Z scan)  -> int16: +d for a free voxel, -d for a filled voxel, d = distance in
@@ -170,6 +177,8 @@ hipError_t LaunchRaycastF32(const float* points_dev, int64_t num_points, int64_t
 hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const RaycastGridF64& g,
                             int32_t* tracking_dev, int threads_per_block, void* scratch_dev, size_t scratch_bytes,
                             hipStream_t stream);
+// dst[i] += src[i] over `count` int32 counts (both 16-byte aligned): sums the private tracking grids of a split cloud.
+hipError_t LaunchAccumulateCounts(int32_t* dst_dev, const int32_t* src_dev, int64_t count, hipStream_t stream);
 hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
                         double percent_seen_free, int32_t outlier_points_threshold,
                         int32_t num_cameras_seen_free, bool ratio_in_double, float* occupancy_dev,

@@ -572,6 +572,36 @@ hipError_t LaunchRaycastF64(const double* points_dev, int64_t num_points, const 
                                scratch_bytes, stream);
 }
 
+// dst[i] += src[i]: the tracking counts of one share of a point cloud added to another's (the counts are
+// integers, so the sum over shares equals the counts of the whole cloud whatever the split).
+__global__ __launch_bounds__(256) void AccumulateCountsKernel(int32_t* __restrict__ dst,
+                                                              const int32_t* __restrict__ src, int64_t count)
+{
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t quads = count / 4;
+  int4* const dst4 = reinterpret_cast<int4*>(dst);
+  const int4* const src4 = reinterpret_cast<const int4*>(src);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < quads; i += stride)
+  {
+    const int4 a = dst4[i];
+    const int4 b = src4[i];
+    dst4[i] = make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+  for (int64_t i = quads * 4 + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+    dst[i] += src[i];
+}
+
+hipError_t LaunchAccumulateCounts(int32_t* dst_dev, const int32_t* src_dev, int64_t count, hipStream_t stream)
+{
+  if (count <= 0) return hipSuccess;
+  int64_t blocks = (count / 4 + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(AccumulateCountsKernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, dst_dev,
+                     src_dev, count);
+  return hipGetLastError();
+}
+
 hipError_t LaunchFilter(const int32_t* tracking_dev, int64_t num_cells, int32_t num_grids,
                         double percent_seen_free, int32_t outlier_points_threshold,
                         int32_t num_cameras_seen_free, bool ratio_in_double, float* occupancy_dev,

@@ -14,6 +14,13 @@ them to per-line carries for its own slab.  Exact for any slab count: the first 
 nearest-site scan, not a k-voxel halo.
 
 The exchange helpers are plain torch code and run on CPU tensors too (tests/test_multi_gpu_gloo.py).
+
+Raycast voxelization of ONE point cloud over several ranks (RaySplit below): rays are independent but
+scatter into one grid, so every rank casts a contiguous share of the points into a private tracking grid
+and the grids are summed with one int32 all-reduce (or a reduce onto the rank that runs the filter).
+Tracking counts are integers: the sum equals the counts of the whole cloud bit for bit, whatever the split.
+Whole clouds (the reference's own unit of dispatch, S/device_pointcloud_voxelization.cpp:147-149) need no
+collective at all: one cloud per rank, then the filter reads every rank's grid.
 """
 import numpy as np
 
@@ -223,3 +230,53 @@ def sdf_slabs_single_device(ctx, torch, occ, nslabs, resolution, unknown_is_fill
     extrema = np.array(extrema)
     ctx.reset_stream()
     return out, float(extrema[:, 0].min()), float(extrema[:, 1].max())
+
+
+def point_share(num_points, world, rank):
+    """(first, count) of `rank`'s contiguous share of a cloud: the rule of slab_bounds (and of vgt_hipx_point_share)."""
+    first, end = slab_bounds(num_points, world)[rank]
+    return first, end - first
+
+
+def sum_counts(dist, counts, root=None):
+    """Sums the ranks' private tracking counts (int32 tensor, in place): everywhere, or onto `root` only (the other
+    ranks' tensors are then undefined)."""
+    if root is None:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(counts, dst=root, op=dist.ReduceOp.SUM)
+    return counts
+
+
+class _DeviceInts:
+    """int32 device memory owned by the library, described for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def tracking_grid_tensor(torch, grids, index, device):
+    """int32 tensor [2 * cells] aliasing tracking grid `index` of `grids` (seen_free, seen_filled per cell); valid
+    while `grids` is open."""
+    return torch.as_tensor(_DeviceInts(grids.dev_ptr(index), 2 * grids.num_cells), device=device)
+
+
+class RaySplit:
+    """One rank's share of the raycast of ONE point cloud (device-resident points).
+
+    The context must run on torch's current stream (ctx.set_stream(torch.cuda.current_stream().cuda_stream)) so
+    that the raycast kernel and the collective are stream-ordered."""
+
+    def __init__(self, torch, dist, grids, index, device):
+        self.torch, self.dist, self.grids, self.index = torch, dist, grids, index
+        self.counts = tracking_grid_tensor(torch, grids, index, device)
+
+    def run(self, share_points, max_range, xform, voxel_size, inverse_voxel_size, grid_sizes, counts, root=None):
+        """share_points: this rank's point_share of the cloud, float32 [n, 3] on the device.  Afterwards grid `index`
+        holds the counts of the WHOLE cloud on every rank (root=None) or on `root`."""
+        n = int(share_points.shape[0])
+        if n:
+            self.grids.raycast_f32_dev(self.index, share_points.data_ptr(), n, max_range, xform, voxel_size,
+                                       inverse_voxel_size, grid_sizes, counts)
+        return sum_counts(self.dist, self.counts, root)
