@@ -86,7 +86,16 @@ inline uint32_t __float_as_uint(float v)
   return r;
 }
 // one lane per "wave": votes and shuffles see this lane only
-#define __builtin_amdgcn_ballot_w64(pred) (static_cast<unsigned long long>((pred) ? 1ull : 0ull))
+// One lane runs at a time, so a vote holds the lane's own bit -- plus, now and then, the bit of an imaginary other lane:
+// code guarded by a vote must be correct for a lane that did not ask for it.
+inline unsigned long long vgt_emulated_vote(bool pred)
+{
+  static unsigned long long state = 0x9E3779B97F4A7C15ull;
+  state = state * 6364136223846793005ull + 1442695040888963407ull;
+  const bool other = ((state >> 59) == 0);  // 1 in 32
+  return (pred ? 1ull : 0ull) | (other ? 2ull : 0ull);
+}
+#define __builtin_amdgcn_ballot_w64(pred) vgt_emulated_vote(pred)
 #define __builtin_amdgcn_sbfe(value, offset, width) \
   (static_cast<int32_t>(static_cast<uint32_t>(value) << (32 - (offset) - (width))) >> (32 - (width)))
 #define __builtin_amdgcn_alignbit(hi, lo, shift) \

@@ -43,8 +43,8 @@ def test_abi_version_and_workspace_size(lib):
     # 8-byte word record per 32 rows and lane), 256-byte aligned pieces; the same for every EDT variant
     n = 64 * 64 * 64
     slots, words = 64, 2
-    narrow = ((64 + 3 + 7) // 8 + 1) * 64 * 8 * 4
-    wide = ((64 + 3 + 3) // 4 + 1) * 64 * 4 * 8
+    narrow = ((64 + 4 + 7) // 8 + 1) * 64 * 8 * 4
+    wide = ((64 + 4 + 3) // 4 + 1) * 64 * 4 * 8
     scratch = 256 + slots * (max(narrow, wide) + words * 64 * 8) + 256
     assert capi.sdf_workspace_bytes((64, 64, 64)) == n * 2 + n * 4 + 256 + scratch
     assert capi.sdf_workspace_bytes((64, 64, 64), 1) == capi.sdf_workspace_bytes((64, 64, 64))

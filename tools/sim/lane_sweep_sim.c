@@ -125,6 +125,7 @@ int main(int argc, char** argv)
     double sum_depth = 0, sum_finite = 0, sum_anytrans = 0, sum_trans = 0;
     int64_t maxdepth = 0, wave_rows = 0, refill32 = 0, refill16 = 0, deep_rows32 = 0;
     double sum_resid_spread = 0;
+    double sum_look[2] = {0, 0};
 #pragma omp parallel
     {
       Entry* st = malloc(sizeof(Entry) * n * 64);
@@ -133,6 +134,7 @@ int main(int argc, char** argv)
       int32_t* F = malloc(4 * n);
       double l_tests = 0, l_pops = 0, l_push = 0, l_maxtests = 0, l_maxpops = 0, l_anypush = 0, l_evalmax = 0, l_evalpops = 0, l_depth = 0, l_finite = 0, l_anytrans = 0, l_trans = 0;
       int64_t l_maxdepth = 0, l_wave_rows = 0, l_deep32 = 0;
+      double l_look[2] = {0, 0};
 #pragma omp for schedule(dynamic, 4)
       for (int64_t wave = 0; wave < (int64_t)n * n / 64; wave++)
       {
@@ -173,6 +175,23 @@ int main(int argc, char** argv)
           l_depth += depth;
         }
         if ((wave & 7) != 0) continue;  // statistics on every 8th wave
+        // evaluation with look-ahead: a lane evaluates the top K entries of its stack, so it has to pop only when K - 1
+        // advances are pending; when any lane has to, every lane with a pending advance pops along
+        for (int K = 2; K <= 3; K++)
+        {
+          int pending[64] = {0};
+          for (int q = 0; q < n; q++)
+          {
+            int must = 0;
+            for (int lane = 0; lane < 64; lane++) { pending[lane] += evp[lane * n + q]; if (pending[lane] >= K) must = 1; }
+            while (must)
+            {
+              l_look[K - 2] += 1;
+              must = 0;
+              for (int lane = 0; lane < 64; lane++) { if (pending[lane] > 0) pending[lane]--; if (pending[lane] >= K) must = 1; }
+            }
+          }
+        }
         for (int q = 0; q < n; q++)
         {
           int mt = 0, mp = 0, ap = 0, me = 0, at = 0;
@@ -198,6 +217,7 @@ int main(int argc, char** argv)
         sum_anypush += l_anypush; sum_evalmax += l_evalmax; sum_evalpops += l_evalpops; sum_depth += l_depth; sum_finite += l_finite;
         sum_anytrans += l_anytrans; sum_trans += l_trans; deep_rows32 += l_deep32;
         if (l_maxdepth > maxdepth) maxdepth = l_maxdepth;
+        sum_look[0] += l_look[0]; sum_look[1] += l_look[1];
         wave_rows += l_wave_rows;
       }
     }
@@ -206,6 +226,8 @@ int main(int argc, char** argv)
            pass == 0 ? "Y" : "X", sum_finite / lanes, sum_tests / lanes, sum_pops / lanes, sum_push / lanes, sum_evalpops / lanes, sum_trans / lanes,
            sum_maxtests / wave_rows, sum_maxpops / wave_rows, sum_anypush / wave_rows, sum_evalmax / wave_rows, sum_anytrans / wave_rows,
            sum_depth / ((double)n * n), (long long)maxdepth, deep_rows32 / lanes);
+    printf("   evaluation pop iterations per wave-row: one entry evaluated %.3f, two %.3f, three %.3f\n",
+           sum_evalmax / wave_rows, sum_look[0] / wave_rows, sum_look[1] / wave_rows);
     (void)refill32; (void)refill16; (void)sum_resid_spread;
     free(A);
     A = B;

@@ -26,7 +26,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = capi.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        occ = bench.device_occupancy(torch, shape, dist, 42, dev)
+    occ = bench.device_occupancy(torch, shape, dist, 42, dev)
     sdf = torch.empty(shape, dtype=torch.float32, device=dev)
     nbytes = capi.sdf_workspace_bytes(shape)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

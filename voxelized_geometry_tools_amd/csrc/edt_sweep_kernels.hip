@@ -99,7 +99,7 @@ template <>
 struct Codec<true>
 {
   using Entry = uint32_t;
-  static constexpr int32_t kSentinelG = (1 << 22) - 2;  // T0; V0 = kSentinelG + 1; real G and real results below it
+  static constexpr int32_t kSentinelG = (1 << 22) - 3;  // T0; V0, W0 = kSentinelG + 1, + 2; real G and real results below it
   static __device__ __forceinline__ Entry Pack(int32_t G, int row)
   {
     return (static_cast<uint32_t>(G) << 10) | static_cast<uint32_t>(row);
@@ -272,20 +272,22 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // address of entry `depth` and L + lane_chunk the spill address of the chunk that starts at entry `lo`.  Registers
   // hold the top (Gt, rt), the second entry as differences to the top (A = rt - rs >= 0, nB = Gs - Gt) and the third
   // as it came from the ring (e3, decoded when it moves up): a pop is a few additions and only waits for the ring
-  // when it is the second pop in a row. ----
-  uint32_t D = 3u << kShift, L = 0;
+  // when it is the second pop in a row.  Three row-0 sentinels T0 > V0 > W0 (in stack order; G = S, S + 1, S + 2) and
+  // a never-decoded entry 0 keep a fourth entry under every top: sweep 2 looks two entries down. ----
+  uint32_t D = 4u << kShift, L = 0;
   int32_t Gt = C::kSentinelG, nB = 1;
   int rt = 0, A = 0;
-  Entry e3 = C::Pack(0, 0);
+  Entry e3 = C::Pack(C::kSentinelG + 2, 0);
   auto ring_ref = [&](uint32_t scaled_index) -> Entry& {
     return *reinterpret_cast<Entry*>(ring_bytes + ((scaled_index & kRingMask) | lane_entry));
   };
   auto spill_ptr = [&](uint32_t scaled_first) -> Entry* {
     return reinterpret_cast<Entry*>(wave_spill + (scaled_first + lane_chunk));
   };
-  ring_ref(0u << kShift) = C::Pack(0, 0);  // never looked at: keeps "third" inside the stack
-  ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 1, 0);
-  ring_ref(2u << kShift) = C::Pack(C::kSentinelG, 0);
+  ring_ref(0u << kShift) = C::Pack(0, 0);  // never decoded: keeps "fourth" inside the stack
+  ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 2, 0);
+  ring_ref(2u << kShift) = C::Pack(C::kSentinelG + 1, 0);
+  ring_ref(3u << kShift) = C::Pack(C::kSentinelG, 0);
 
   // chunks requested from the spill buffer at the last check (a refill_now of the same chunk drops them)
   Entry pf0[kChunk], pf1[kChunk];
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     }
     pf_count = 0;
   };
-  // top <- second <- third <- ring (two sentinels above entry 0 are never popped, so the third always exists)
+  // top <- second <- third <- ring (the sentinels are never popped, so the third always exists)
   auto pop = [&]() {
 #ifdef VGT_SWEEP_STATS
     {
@@ -524,6 +526,35 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     };
     constexpr int kStep = (kChunk < 8) ? 8 : kChunk;  // rows between two refill steps
 
+    // Sweep 2 looks TWO entries down: a row's value is the better of the top and the second entry, so a lane HAS to
+    // pop only when the third entry has caught up with the second -- and when some lane of the wave has to, every
+    // lane whose second entry is already the better one pops along.  A wave goes through the pop code a quarter as
+    // often as when every lane pops as soon as it can (tools/sim/lane_sweep_sim.c).  Registers: second -> third as
+    // differences (A2 = rs - r3 >= 0, nB2 = G3 - Gs) and the fourth entry as it came from the ring (e4).
+    int A2 = (rt - A) - C::Row(e3);
+    int32_t nB2 = C::G(e3) - (Gt + nB);
+    if (D - 4 * kSlot < L) refill_now();
+    Entry e4 = ring_ref(D - 4 * kSlot);
+    auto pop_down = [&]() {
+#ifdef VGT_SWEEP_STATS
+      {
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+        VGT_SWEEP_COUNT(12, 1);
+        if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
+          VGT_SWEEP_COUNT(8, 1);
+      }
+#endif
+      Gt += nB;
+      rt -= A;
+      A = A2;
+      nB = nB2;
+      A2 = (rt - A) - C::Row(e4);
+      nB2 = C::G(e4) - (Gt + nB);
+      D -= kSlot;
+      if (D - 4 * kSlot < L) refill_now();
+      e4 = ring_ref(D - 4 * kSlot);
+    };
+
     int dn = kFar;             // distance from the row above the current one to the nearest row of the other class above
     uint32_t above_bit0 = 0;   // class of the first row of the word above
     // sign words: this word's and the next lower word's are in registers, the one below that is on its way
@@ -589,19 +620,27 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           {
             const int q = r0 + k;
             const int q2 = 2 * q;
-            // the second member is at least as good at row q: the top owns nothing at or below q
+            // t1 = value of the second entry at row q minus the top's, t2 = the third's minus the second's
             // (rows and row differences are below 2^14: plain unsigned 24-bit multiplies)
-            __builtin_assume(A >= 0 && A < 16384 && rt >= 0 && rt < 16384);
-            if (!(VGT_SWEEP_EXP & 16) && static_cast<int32_t>(__umul24(A, q2)) + nB <= 0)
+            __builtin_assume(A >= 0 && A < 16384 && A2 >= 0 && A2 < 16384 && rt >= 0 && rt < 16384);
+            int32_t t1 = static_cast<int32_t>(__umul24(A, q2)) + nB;
+            int32_t t2 = static_cast<int32_t>(__umul24(A2, q2)) + nB2;
+            if (!(VGT_SWEEP_EXP & 16) && __builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull)
             {
               do
               {
-                pop();
-                __builtin_assume(A >= 0 && A < 16384 && rt >= 0 && rt < 16384);
-              } while (static_cast<int32_t>(__umul24(A, q2)) + nB <= 0);
+                if (t1 <= 0)
+                {
+                  pop_down();
+                  __builtin_assume(A2 >= 0 && A2 < 16384);
+                  t1 = t2;
+                  t2 = static_cast<int32_t>(__umul24(A2, q2)) + nB2;
+                }
+              } while (__builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull);
+              __builtin_assume(rt >= 0 && rt < 16384);
             }
-            // value of the top at q: Gt + q^2 - 2 q rt
-            uint32_t best = static_cast<uint32_t>(Gt + q * q) - __umul24(rt, q2);
+            // the better of the top (Gt + q^2 - 2 q rt) and the second entry at q
+            uint32_t best = static_cast<uint32_t>(Gt + q * q) - __umul24(rt, q2) + static_cast<uint32_t>(min(t1, 0));
             if (classes)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
@@ -687,7 +726,7 @@ constexpr int64_t kSweepSlots = 5120;
 #endif
 constexpr size_t kCounterBytes = 256;  // the work counter, alone on its cache lines
 
-int64_t SpillChunks(int64_t n, int chunk) { return (n + 3 + chunk - 1) / chunk + 1; }
+int64_t SpillChunks(int64_t n, int chunk) { return (n + 4 + chunk - 1) / chunk + 1; }
 
 // Entries of a line of n rows fit 32 bits when every G = F + row^2 stays below the sentinels.
 bool PackedEntries(int64_t n, int64_t max_input)
