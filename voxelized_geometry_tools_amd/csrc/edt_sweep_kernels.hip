@@ -73,7 +73,7 @@ struct RingShape
   static_assert(kBand % kChunk == 0 && kRing >= 4 * kChunk && (kRing & (kRing - 1)) == 0 && kChunk % 4 == 0, "sizes");
 };
 constexpr int kFar = 32768;              // "no row of the other class": kFar^2 is above every real squared distance
-static_assert(kWord % kBand == 0, "sizes");
+static_assert(kWord % kBand == 0 && kBand % 2 == 0, "sizes");
 
 struct SweepGeom
 {
@@ -185,6 +185,19 @@ __device__ __forceinline__ VGT_GLOBAL T* GlobalPointer(T* p)
 #endif
 }
 
+// a * b + c with 24-bit signed a and b, b the same in every lane (a scalar register): one v_mad_i32_i24 (the compiler
+// prefers a 32-bit multiply and an add, or a 64-bit multiply-add that ties up a register pair).
+__device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, int32_t c)
+{
+#ifdef VGT_HOST_EMULATION
+  return a * b_uniform + c;
+#else
+  int32_t d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+  return d;
+#endif
+}
+
 __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
@@ -195,11 +208,15 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 #define VGT_COLD_PATH()
 #define VGT_MIN_F32(acc, v) acc = fminf(acc, v)
 #define VGT_MAX_F32(acc, v) acc = fmaxf(acc, v)
+#define VGT_MIN3_F32(acc, a, b) acc = fminf(acc, fminf(a, b))
+#define VGT_MAX3_F32(acc, a, b) acc = fmaxf(acc, fmaxf(a, b))
 #else
 #define VGT_COLD_PATH() asm volatile("; rare path")
 // plain instructions: no NaN can occur, so no canonicalisation is needed
 #define VGT_MIN_F32(acc, v) asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(v))
 #define VGT_MAX_F32(acc, v) asm("v_max_f32 %0, %0, %1" : "+v"(acc) : "v"(v))
+#define VGT_MIN3_F32(acc, a, b) asm("v_min3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
+#define VGT_MAX3_F32(acc, a, b) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
 #ifdef VGT_SWEEP_STATS
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       int dp[8];
       uint32_t xup = 0;
       if (classes) xup = xup_word >> sub;
+      [[maybe_unused]] float pending_value = 0.0f;
       auto rows = [&](auto guarded) {
         constexpr bool kGuard = decltype(guarded)::value;
 #pragma unroll
@@ -623,8 +641,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             // t1 = value of the second entry at row q minus the top's, t2 = the third's minus the second's
             // (rows and row differences are below 2^14: plain unsigned 24-bit multiplies)
             __builtin_assume(A >= 0 && A < 16384 && A2 >= 0 && A2 < 16384 && rt >= 0 && rt < 16384);
-            int32_t t1 = static_cast<int32_t>(__umul24(A, q2)) + nB;
-            int32_t t2 = static_cast<int32_t>(__umul24(A2, q2)) + nB2;
+            int32_t t1 = Mad24Uniform(A, q2, nB);
+            int32_t t2 = Mad24Uniform(A2, q2, nB2);
             if (!(VGT_SWEEP_EXP & 16) && __builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull)
             {
               do
@@ -634,13 +652,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                   pop_down();
                   __builtin_assume(A2 >= 0 && A2 < 16384);
                   t1 = t2;
-                  t2 = static_cast<int32_t>(__umul24(A2, q2)) + nB2;
+                  t2 = Mad24Uniform(A2, q2, nB2);
                 }
               } while (__builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull);
               __builtin_assume(rt >= 0 && rt < 16384);
             }
             // the better of the top (Gt + q^2 - 2 q rt) and the second entry at q
-            uint32_t best = static_cast<uint32_t>(Gt + q * q) - __umul24(rt, q2) + static_cast<uint32_t>(min(t1, 0));
+            uint32_t best = static_cast<uint32_t>(Mad24Uniform(rt, -q2, Gt) + q * q + min(t1, 0));
             if (classes)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
@@ -674,19 +692,34 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               }
               else
                 dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
-              if (__builtin_amdgcn_ballot_w64(unsure || exact) != 0ull)
+              const bool none = d2 >= static_cast<uint32_t>(kLimit);  // no voxel of the other class anywhere
+              if (__builtin_amdgcn_ballot_w64(unsure || exact || none) != 0ull)
               {
                 VGT_COLD_PATH();  // keeps the block out of the straight-line code
 #ifdef VGT_SWEEP_STATS
                 if (lane == 0) VGT_SWEEP_COUNT(6, 1);
 #endif
                 if (unsure || exact) dist = SqrtTimesResolutionExact(static_cast<int32_t>(d2), g.resolution);
+                if (none) dist = __uint_as_float(0x7f800000u);
               }
-              dist = (d2 >= static_cast<uint32_t>(kLimit)) ? __uint_as_float(0x7f800000u) : dist;
               const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
               row_out[zl] = value;
-              VGT_MIN_F32(lo_value, value);
-              VGT_MAX_F32(hi_value, value);
+              // extrema: two rows per instruction in full bands
+              if constexpr (kGuard)
+              {
+                VGT_MIN_F32(lo_value, value);
+                VGT_MAX_F32(hi_value, value);
+              }
+              else if constexpr (true)
+              {
+                if (k % 2 == 1)
+                  pending_value = value;
+                else
+                {
+                  VGT_MIN3_F32(lo_value, pending_value, value);
+                  VGT_MAX3_F32(hi_value, pending_value, value);
+                }
+              }
             }
             else
             {
