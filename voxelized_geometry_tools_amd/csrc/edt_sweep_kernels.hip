@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     A = rt - C::Row(e3);
     nB = C::G(e3) - Gt;
     D -= kSlot;
-    if (D - 3 * kSlot < L) refill_now();
+    if (__builtin_expect(D - 3 * kSlot < L, 0)) refill_now();
     e3 = ring_ref(D - 3 * kSlot);
   };
   auto commit = [&](const Entry (&buf)[kChunk]) {
@@ -458,12 +458,19 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               int dr = q - rt;
               if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
               {
-                do
+                // (one pop is the common case: it is laid out as straight code, further pops out of line)
+                pop();
+                dG = G - Gt;
+                dr = q - rt;
+                if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
                 {
-                  pop();
-                  dG = G - Gt;
-                  dr = q - rt;
-                } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
+                  do
+                  {
+                    pop();
+                    dG = G - Gt;
+                    dr = q - rt;
+                  } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
+                }
               }
               __builtin_assume(dr > 0 && dr < 16384);
               if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     // differences (A2 = rs - r3 >= 0, nB2 = G3 - Gs) and the fourth entry as it came from the ring (e4).
     int A2 = (rt - A) - C::Row(e3);
     int32_t nB2 = C::G(e3) - (Gt + nB);
-    if (D - 4 * kSlot < L) refill_now();
+    if (__builtin_expect(D - 4 * kSlot < L, 0)) refill_now();
     Entry e4 = ring_ref(D - 4 * kSlot);
     auto pop_down = [&]() {
 #ifdef VGT_SWEEP_STATS
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       A2 = (rt - A) - C::Row(e4);
       nB2 = C::G(e4) - (Gt + nB);
       D -= kSlot;
-      if (D - 4 * kSlot < L) refill_now();
+      if (__builtin_expect(D - 4 * kSlot < L, 0)) refill_now();
       e4 = ring_ref(D - 4 * kSlot);
     };
 
@@ -615,13 +622,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       uint32_t xup = 0;
       if (classes) xup = xup_word >> sub;
       [[maybe_unused]] float pending_value = 0.0f;
-      auto rows = [&](auto guarded) {
+      // (two copies of a full band's code, with and without the class-change candidates: no test per row)
+      auto rows = [&](auto guarded, auto with_classes) {
         constexpr bool kGuard = decltype(guarded)::value;
+        constexpr bool kClasses = decltype(with_classes)::value;
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
           if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4)) refill_step();
-          if (classes && k % 8 == 7)
+          if (kClasses && k % 8 == 7)
           {
             const int first = sub + k - 7;  // position of the group's first row in the word
             const uint32_t below = xdn_word & LowBits(first);
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             __builtin_assume(A >= 0 && A < 16384 && A2 >= 0 && A2 < 16384 && rt >= 0 && rt < 16384);
             int32_t t1 = Mad24Uniform(A, q2, nB);
             int32_t t2 = Mad24Uniform(A2, q2, nB2);
-            if (!(VGT_SWEEP_EXP & 16) && __builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull)
+            if (!(VGT_SWEEP_EXP & 16) && __builtin_expect(__builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull, 0))
             {
               do
               {
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             }
             // the better of the top (Gt + q^2 - 2 q rt) and the second entry at q
             uint32_t best = static_cast<uint32_t>(Mad24Uniform(rt, -q2, Gt) + q * q + min(t1, 0));
-            if (classes)
+            if constexpr (kClasses)
             {
               dn = ((xup >> k) & 1u) ? 1 : dn + 1;
               const uint32_t dm = static_cast<uint32_t>(min(dp[k & 7], dn));
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               else
                 dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
               const bool none = d2 >= static_cast<uint32_t>(kLimit);  // no voxel of the other class anywhere
-              if (__builtin_amdgcn_ballot_w64(unsure || exact || none) != 0ull)
+              if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure || exact || none) != 0ull, 0))
               {
                 VGT_COLD_PATH();  // keeps the block out of the straight-line code
 #ifdef VGT_SWEEP_STATS
@@ -730,10 +739,12 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           }
         }
       };
-      if (r0 + kBand <= n)
-        rows(std::false_type{});
+      if (r0 + kBand > n)
+        rows(std::true_type{}, std::true_type{});  // (the partial band: one copy, the candidates are "far" without classes)
+      else if (classes)
+        rows(std::false_type{}, std::true_type{});
       else
-        rows(std::true_type{});
+        rows(std::false_type{}, std::false_type{});
       if (classes) dn = min(dn, kFar);
     }
   }
