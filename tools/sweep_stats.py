@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Event counts of the sweep passes (the default EDT line passes) from a diagnostic build:
    make -C voxelized_geometry_tools_amd/csrc OBJDIR=sstats OUT=../libvgt_hip_sstats.so HIPFLAGS="... -DVGT_SWEEP_STATS"
+   (event counts; slow) or -DVGT_SWEEP_TIMING (item durations and wave exit times; near full speed)
    VGT_HIP_LIB=.../libvgt_hip_sstats.so python tools/sweep_stats.py [size] [dist]"""
 import ctypes
 import os
@@ -33,12 +34,34 @@ def main():
     mm = torch.empty(2, dtype=torch.float32, device=dev)
     lib = capi.load()
     buf = (ctypes.c_ulonglong * 32)()
-    lib.vgt_hip_debug_sweep_stats(buf, 1)
+    have_counts = hasattr(lib, "vgt_hip_debug_sweep_stats")
+    have_timing = hasattr(lib, "vgt_hip_debug_sweep_items")
+    if have_counts:
+        lib.vgt_hip_debug_sweep_stats(buf, 1)
+    bins = (ctypes.c_ulonglong * 128)()
+    exits = (ctypes.c_ulonglong * 8)()
+    if have_timing:
+        ctx.sdf_dev(occ.data_ptr(), shape, 0.01, sdf.data_ptr(), ws.data_ptr(), nbytes, mm.data_ptr(), True, False)
+        lib.vgt_hip_debug_sweep_items(bins, exits, 1)
     ctx.sdf_dev(occ.data_ptr(), shape, 0.01, sdf.data_ptr(), ws.data_ptr(), nbytes, mm.data_ptr(), True, False)
     torch.cuda.synchronize()
-    lib.vgt_hip_debug_sweep_stats(buf, 1)
+    if have_counts:
+        lib.vgt_hip_debug_sweep_stats(buf, 1)
+    if have_timing:
+        lib.vgt_hip_debug_sweep_items(bins, exits, 1)
+    for p, name in ((0, "Y"), (1, "X")):
+        first, last, total, waves = [exits[p * 4 + i] for i in range(4)]
+        if waves:
+            span = (last - first) / 100.0
+            mean_exit = (total / waves - first) / 100.0
+            print("%s pass: %d waves, first item start to last exit %.1f us, mean exit at %.1f us (%.1f %% of the span idle at the end)"
+                  % (name, waves, span, mean_exit, 100.0 * (span - mean_exit) / span))
+        for c in (0, 1):
+            row = [bins[(p * 2 + c) * 32 + b] for b in range(32)]
+            if sum(row):
+                print("   item durations, %s class changes, 50-us bins from 0: %s" % ("with" if c else "no", " ".join(str(v) for v in row)))
     rows = size * size * size / 64.0
-    for base, name in ((0, "Y"), (16, "X")):
+    for base, name in ((0, "Y"), (16, "X")) if have_counts else ():
         print(name, "pass: wave-rows", rows)
         for i, label in enumerate(NAMES):
             if label != "-":

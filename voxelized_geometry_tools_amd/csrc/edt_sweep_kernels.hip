@@ -226,6 +226,12 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 #define VGT_MAX3_F32(acc, a, b) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
+#ifdef VGT_SWEEP_TIMING
+// diagnostic build (-DVGT_SWEEP_TIMING, tools/sweep_stats.py): item durations in 50-us bins (wall clock, 100 MHz),
+// [pass][class changes in the wave][bin], and when the waves ran out of work
+__device__ unsigned long long g_sweep_item_bins[2][2][32];
+__device__ unsigned long long g_sweep_exit[2][4];  // [pass]: first item start (min), last exit (max), sum of exits, waves
+#endif
 #ifdef VGT_SWEEP_STATS
 // diagnostic build: [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the same in
 // sweep 2, [4] spilled chunks (lanes), [6] exact conversions (wave events), [7] / [8] wave-level pop iterations in
@@ -293,6 +299,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   }
 #endif
   if (item >= g.items) break;
+#ifdef VGT_SWEEP_TIMING
+  const unsigned long long item_begin = wall_clock64();
+  if (lane == 0) atomicMin(&g_sweep_exit[kFinal ? 1 : 0][0], item_begin);
+#endif
   const int outer = item / g.zsegs;
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
@@ -764,7 +774,25 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       if (classes) dn = min(dn, kFar);
     }
   }
+#ifdef VGT_SWEEP_TIMING
+  if (lane == 0)
+  {
+    const unsigned long long ticks = wall_clock64() - item_begin;  // 10 ns each
+    unsigned long long bin = ticks / 5000ull;
+    if (bin > 31ull) bin = 31ull;
+    atomicAdd(&g_sweep_item_bins[kFinal ? 1 : 0][classes ? 1 : 0][bin], 1ull);
+  }
+#endif
   }  // next unit of work
+#ifdef VGT_SWEEP_TIMING
+  if (lane == 0)
+  {
+    const unsigned long long now = wall_clock64();
+    atomicMax(&g_sweep_exit[kFinal ? 1 : 0][1], now);
+    atomicAdd(&g_sweep_exit[kFinal ? 1 : 0][2], now);
+    atomicAdd(&g_sweep_exit[kFinal ? 1 : 0][3], 1ull);
+  }
+#endif
   if constexpr (kFinal)
   {
     uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
@@ -932,6 +960,23 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
   return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
 }
 }  // namespace vgt
+
+#ifdef VGT_SWEEP_TIMING
+extern "C" int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned long long* exit8, int reset)
+{
+  hipError_t err = hipDeviceSynchronize();
+  if (err == hipSuccess) err = hipMemcpyFromSymbol(bins128, HIP_SYMBOL(vgt::g_sweep_item_bins), 128 * sizeof(unsigned long long));
+  if (err == hipSuccess) err = hipMemcpyFromSymbol(exit8, HIP_SYMBOL(vgt::g_sweep_exit), 8 * sizeof(unsigned long long));
+  if (err == hipSuccess && reset)
+  {
+    unsigned long long zeros[128] = {0};
+    err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_item_bins), zeros, sizeof(zeros));
+    unsigned long long init[8] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0};
+    if (err == hipSuccess) err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_exit), init, sizeof(init));
+  }
+  return err == hipSuccess ? 0 : 2;
+}
+#endif
 
 #ifdef VGT_SWEEP_STATS
 extern "C" int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
