@@ -16,6 +16,7 @@ timeout 300 python3 bench.py --dist salt --no-cpu-baseline --no-end-to-end > $OU
 timeout 300 python3 bench.py --dist unknown_mix --no-cpu-baseline --no-end-to-end > $OUT/bench1024_unknown_mix.json 2> /dev/null
 timeout 300 python3 bench.py --size 512 --no-cpu-baseline --no-end-to-end > $OUT/bench512.json 2> /dev/null
 timeout 300 python3 bench.py --workload c5 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_c5_one_gpu.json 2> /dev/null
+python3 -c "import json,sys; p=sys.argv[1]; d=json.load(open(p)); d['commit']=sys.argv[2]; open(p,'w').write(json.dumps(d)+'\n')" $OUT/bench_c5_one_gpu.json $COMMIT
 timeout 300 python3 bench.py --force-slab --steps 3 --warmup 1 > $OUT/bench_config5_one_gpu_slab_path.json 2> /dev/null
 timeout 300 python3 bench.py --variant 2 --no-cpu-baseline --no-end-to-end > $OUT/bench1024_variant2_tiled_envelope.json 2> /dev/null
 timeout 300 python3 bench_raycast.py > $OUT/bench_raycast_config3.json 2> /dev/null
