@@ -267,7 +267,16 @@ __global__ __launch_bounds__(kScanBlock) void ScanZTransitionKernel(
     for (int c = 0; c < NCH; c++)
     {
       const int grp = c * kWave + lane;
-      if (grp * 4 < nz) v[c] = src[grp];
+      if (grp * 4 < nz)
+      {
+        // (the field is read once: a streaming load, which also leaves the caches to the passes that follow)
+        using Raw = InT __attribute__((ext_vector_type(4)));
+        const Raw raw = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(src) + grp);
+        v[c].x = raw.x;
+        v[c].y = raw.y;
+        v[c].z = raw.z;
+        v[c].w = raw.w;
+      }
     }
     bool f[NCH][4];     // class of my four voxels (false beyond the line)
     int first0[NCH];    // class of the first voxel of my quad as an integer, for the lane below me
@@ -354,7 +363,13 @@ __global__ __launch_bounds__(kScanBlock) void ScanZTransitionKernel(
           const int32_t d = min(min(z - below[k], above[k] + 1 - z), static_cast<int32_t>(kInf16));
           r[k] = static_cast<int16_t>(f[c][k] ? -d : d);
         }
-        dst[grp] = make_short4(r[0], r[1], r[2], r[3]);
+        using RawOut = int16_t __attribute__((ext_vector_type(4)));
+        RawOut packed;
+        packed.x = r[0];
+        packed.y = r[1];
+        packed.z = r[2];
+        packed.w = r[3];
+        __builtin_nontemporal_store(packed, reinterpret_cast<RawOut*>(dst) + grp);
       }
     }
     if (summary)

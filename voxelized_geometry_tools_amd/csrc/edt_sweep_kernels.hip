@@ -127,13 +127,60 @@ struct Codec<false>
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e.y); }
 };
 
+#ifndef VGT_SWEEP_NT
+#define VGT_SWEEP_NT 3  // streaming accesses: 1 = row loads, 2 = row stores, 4 = sign words, 8 = spill chunks
+#endif
+// 16-byte and 8-byte scratch accesses, streaming or not
+__device__ __forceinline__ void StoreQuad(uint4* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 8)
+  *p = make_uint4(a, b, c, d);
+#else
+  using Raw = uint32_t __attribute__((ext_vector_type(4)));
+  Raw r;
+  r.x = a; r.y = b; r.z = c; r.w = d;
+  __builtin_nontemporal_store(r, reinterpret_cast<Raw*>(p));
+#endif
+}
+__device__ __forceinline__ uint4 LoadQuad(const uint4* p)
+{
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 8)
+  return *p;
+#else
+  using Raw = uint32_t __attribute__((ext_vector_type(4)));
+  const Raw r = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p));
+  return make_uint4(r.x, r.y, r.z, r.w);
+#endif
+}
+__device__ __forceinline__ void StorePair(uint2* p, uint32_t a, uint32_t b)
+{
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 4)
+  *p = make_uint2(a, b);
+#else
+  using Raw = uint32_t __attribute__((ext_vector_type(2)));
+  Raw r;
+  r.x = a; r.y = b;
+  __builtin_nontemporal_store(r, reinterpret_cast<Raw*>(p));
+#endif
+}
+__device__ __forceinline__ uint2 LoadPair(const uint2* p)
+{
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 4)
+  return *p;
+#else
+  using Raw = uint32_t __attribute__((ext_vector_type(2)));
+  const Raw r = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p));
+  return make_uint2(r.x, r.y);
+#endif
+}
+
 // A chunk of N entries <-> contiguous bytes of the spill buffer, as 16-byte accesses.
 template <int N>
 __device__ __forceinline__ void StoreChunk(uint32_t* dst, const uint32_t (&e)[N])
 {
 #pragma unroll
   for (int j = 0; j < N / 4; j++)
-    reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
+    StoreQuad(reinterpret_cast<uint4*>(dst) + j, e[4 * j], e[4 * j + 1], e[4 * j + 2], e[4 * j + 3]);
 }
 template <int N>
 __device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[N])
@@ -141,7 +188,7 @@ __device__ __forceinline__ void LoadChunk(const uint32_t* src, uint32_t (&e)[N])
 #pragma unroll
   for (int j = 0; j < N / 4; j++)
   {
-    const uint4 a = reinterpret_cast<const uint4*>(src)[j];
+    const uint4 a = LoadQuad(reinterpret_cast<const uint4*>(src) + j);
     e[4 * j] = a.x;
     e[4 * j + 1] = a.y;
     e[4 * j + 2] = a.z;
@@ -153,7 +200,7 @@ __device__ __forceinline__ void StoreChunk(uint2* dst, const uint2 (&e)[N])
 {
 #pragma unroll
   for (int j = 0; j < N / 2; j++)
-    reinterpret_cast<uint4*>(dst)[j] = make_uint4(e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y);
+    StoreQuad(reinterpret_cast<uint4*>(dst) + j, e[2 * j].x, e[2 * j].y, e[2 * j + 1].x, e[2 * j + 1].y);
 }
 template <int N>
 __device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[N])
@@ -161,7 +208,7 @@ __device__ __forceinline__ void LoadChunk(const uint2* src, uint2 (&e)[N])
 #pragma unroll
   for (int j = 0; j < N / 2; j++)
   {
-    const uint4 a = reinterpret_cast<const uint4*>(src)[j];
+    const uint4 a = LoadQuad(reinterpret_cast<const uint4*>(src) + j);
     e[2 * j] = make_uint2(a.x, a.y);
     e[2 * j + 1] = make_uint2(a.z, a.w);
   }
@@ -209,6 +256,18 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
 }
+
+// Rows are read once and written once per pass: streaming accesses (no reuse to protect in the caches).
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 1)
+#define VGT_STREAM_LOAD(p) (*(p))
+#else
+#define VGT_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#if defined(VGT_HOST_EMULATION) || !(VGT_SWEEP_NT & 2)
+#define VGT_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define VGT_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 
 // Host emulation (tests/cpp/sweep_emulation.cc compiles this file with g++ and runs the lanes one by one): no GPU asm.
 #ifdef VGT_HOST_EMULATION
@@ -396,7 +455,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          dst[k] = static_cast<int32_t>(row_in[zl]);
+          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(&row_in[zl]));
           row_in = UniformPointer(row_in + rstride);
         }
       }
@@ -406,7 +465,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          dst[k] = static_cast<int32_t>(row_in[zl]);
+          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(&row_in[zl]));
           if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
         }
       }
@@ -528,7 +587,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         uint32_t xdn = sw ^ ((sw << 1) | prev_bit);  // bit k: row k differs from the row below it (rows past the end: 0)
         xdn &= LowBits(valid);
         if (word_first == 0) xdn &= ~1u;
-        (wave_info + static_cast<int64_t>(word_first / kWord) * kWaveSize)[lane] = make_uint2(sw, static_cast<uint32_t>(din));
+        StorePair(wave_info + static_cast<int64_t>(word_first / kWord) * kWaveSize + lane, sw, static_cast<uint32_t>(din));
         any_transition |= xdn;
         din = xdn ? (valid - (31 - __clz(static_cast<int>(xdn)))) : min(din + valid, kFar);
         prev_bit = (sw >> (valid - 1)) & 1u;
@@ -609,9 +668,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     uint32_t above_bit0 = 0;   // class of the first row of the word above
     // sign words: this word's and the next lower word's are in registers, the one below that is on its way
     const int nwords = g.nwords;
-    uint2 info = (wave_info + static_cast<int64_t>(nwords - 1) * kWaveSize)[lane];
+    uint2 info = LoadPair(wave_info + static_cast<int64_t>(nwords - 1) * kWaveSize + lane);
     uint2 info_below = make_uint2(0u, 0u);
-    if (nwords > 1) info_below = (wave_info + static_cast<int64_t>(nwords - 2) * kWaveSize)[lane];
+    if (nwords > 1) info_below = LoadPair(wave_info + static_cast<int64_t>(nwords - 2) * kWaveSize + lane);
     uint2 info_next = make_uint2(0u, 0u);
     uint32_t xdn_word = 0, xup_word = 0;
     VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));  // row being evaluated
@@ -630,7 +689,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           info = info_below;
           info_below = info_next;
         }
-        if (w > 1) info_next = (wave_info + static_cast<int64_t>(w - 2) * kWaveSize)[lane];
+        if (w > 1) info_next = LoadPair(wave_info + static_cast<int64_t>(w - 2) * kWaveSize + lane);
         if (classes)
         {
           const uint32_t sw = info.x;
@@ -738,7 +797,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                 if (none) dist = __uint_as_float(0x7f800000u);
               }
               const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
-              row_out[zl] = value;
+              VGT_STREAM_STORE(value, &row_out[zl]);
               // extrema: two rows per instruction in full bands
               if constexpr (kGuard)
               {
@@ -759,7 +818,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             else
             {
               const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
-              row_out[zl] = (d2 ^ sign) - sign;
+              VGT_STREAM_STORE(static_cast<OutT>((d2 ^ sign) - sign), &row_out[zl]);
             }
             row_out = UniformPointer(row_out - rstride);
           }
