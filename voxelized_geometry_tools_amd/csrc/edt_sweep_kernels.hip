@@ -347,8 +347,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #else
   // Workgroups with the same blockIdx modulo 8 share an XCD and its L2 (the dispatcher deals them round robin): with
   // g.groups = 8 there is one counter per such group, dealing whole rows of the grid -- the segments of one contiguous
-  // row are then written through one L2 at about the same time instead of through eight.  A speed choice only (the
-  // launcher makes it per pass).
+  // row are then written through one L2 at about the same time instead of through eight.  A speed choice only.
   const int group = static_cast<int>(blockIdx.x) % g.groups;
   if (lane == 0) item = atomicAdd(work_counter + group * kCounterStride, 1);
   item = __builtin_amdgcn_readfirstlane(item);
@@ -904,8 +903,8 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
   g.items = static_cast<int>(items);
   g.outers = static_cast<int>(outer_count);
   const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
-  // (measured: the Y pass gains 2.4 % from the grouping at 1024^3, the X pass nothing, and it loses 4 % at 2048 rows)
-  g.groups = kFinal ? 1 : static_cast<int>(slots < kSweepGroups ? slots : kSweepGroups);
+  // (measured with streaming row accesses: -1.7 % on the Y pass, -0.7 % on the X pass at 1024^3, -1 % at 2048 rows)
+  g.groups = static_cast<int>(slots < kSweepGroups ? slots : kSweepGroups);
   const bool packed = PackedEntries(g.n, max_input);
   const int chunk = packed ? RingShape<true>::kChunk : RingShape<false>::kChunk;
   g.chunks = static_cast<int>(SpillChunks(g.n, chunk));
