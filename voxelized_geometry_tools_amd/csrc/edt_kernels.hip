@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256) void SlabFixupVecKernel(int16_t* __restrict__ 
     const int z0 = static_cast<int>(gidx - line * groups_per_line) * 8 + z_offset;
     const SlabLineCarry c = carries[line];
     uint4* ptr = reinterpret_cast<uint4*>(io) + gidx;
-    uint4 raw = *ptr;
+    using Raw = uint32_t __attribute__((ext_vector_type(4)));
+    const Raw raw = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(ptr));  // read once: streaming
     uint32_t words[4] = {raw.x, raw.y, raw.z, raw.w};
     bool changed = false;
 #pragma unroll
