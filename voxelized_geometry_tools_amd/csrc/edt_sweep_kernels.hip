@@ -868,7 +868,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #ifdef VGT_HOST_EMULATION
 constexpr int64_t kSweepSlots = 3;  // (the CPU test wants slots that are used again and again)
 #else
-constexpr int64_t kSweepSlots = 5120;
+#ifndef VGT_SWEEP_SLOTS
+#define VGT_SWEEP_SLOTS 5120
+#endif
+constexpr int64_t kSweepSlots = VGT_SWEEP_SLOTS;
 #endif
 constexpr size_t kCounterBytes = kSweepGroups * kCounterStride * sizeof(int);  // the work counters, each on its own cache line
 
