@@ -252,6 +252,29 @@ __device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, in
 #endif
 }
 
+// The lane's element of a row of 4-byte values: wave-uniform base + 32-bit byte offset, the scalar-base addressing mode.
+// The empty asm keeps the zero-extension of the offset next to the access: hoisted out of the loop it reaches instruction
+// selection as a 64-bit register, and every access takes a 64-bit vector add and a vector address pair.  (X pass only:
+// the Y pass's 16-bit loads lose their sign extension to a separate instruction this way, and its stores gain nothing.)
+__device__ __forceinline__ uint32_t PinnedOffset(uint32_t byte_offset)
+{
+#ifndef VGT_HOST_EMULATION
+  asm volatile("" : "+v"(byte_offset));
+#endif
+  return byte_offset;
+}
+template <typename T>
+__device__ __forceinline__ const VGT_GLOBAL T* LaneAddress(const VGT_GLOBAL T* row, uint32_t byte_offset)
+{
+  return reinterpret_cast<const VGT_GLOBAL T*>(reinterpret_cast<const VGT_GLOBAL unsigned char*>(row) +
+                                                PinnedOffset(byte_offset));
+}
+template <typename T>
+__device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t byte_offset)
+{
+  return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) + PinnedOffset(byte_offset));
+}
+
 __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(&row_in[zl]));
+          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
           row_in = UniformPointer(row_in + rstride);
         }
       }
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++)
         {
-          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(&row_in[zl]));
+          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
           if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
         }
       }
@@ -599,6 +622,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Sweep 2: evaluate, last row first.
   // =====================================================================================================
   const bool classes = (VGT_SWEEP_EXP & 2) ? false : (__builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull);
+  const bool any_empty = __builtin_amdgcn_ballot_w64(D == (4u << kShift)) != 0ull;  // a line without any site
 #ifdef VGT_SWEEP_STATS
   stat_phase = 2;
   if (lane == 0)
@@ -785,7 +809,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               }
               else
                 dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
-              const bool none = d2 >= static_cast<uint32_t>(kLimit);  // no voxel of the other class anywhere
+              // no voxel of the other class anywhere: only on lines whose stack holds nothing but the sentinels, and
+              // waves with such a line run the copy of the band code that also has the class candidates
+              const bool none = kClasses && d2 >= static_cast<uint32_t>(kLimit);
               if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure || exact || none) != 0ull, 0))
               {
                 VGT_COLD_PATH();  // keeps the block out of the straight-line code
@@ -796,7 +822,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                 if (none) dist = __uint_as_float(0x7f800000u);
               }
               const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
-              VGT_STREAM_STORE(value, &row_out[zl]);
+              VGT_STREAM_STORE(value, LaneAddress(row_out, zl * 4u));
               // extrema: two rows per instruction in full bands
               if constexpr (kGuard)
               {
@@ -825,7 +851,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       };
       if (r0 + kBand > n)
         rows(std::true_type{}, std::true_type{});  // (the partial band: one copy, the candidates are "far" without classes)
-      else if (classes)
+      else if (classes || any_empty)
         rows(std::false_type{}, std::true_type{});
       else
         rows(std::false_type{}, std::false_type{});
