@@ -113,6 +113,9 @@ struct Codec<true>
   }
   static __device__ __forceinline__ int32_t G(Entry e) { return static_cast<int32_t>(e >> 10); }
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e & 1023u); }
+  // "not loaded": no entry looks like it (the largest G belongs to row 0)
+  static __device__ __forceinline__ Entry Unknown() { return ~0u; }
+  static __device__ __forceinline__ bool IsUnknown(Entry e) { return e == ~0u; }
 };
 template <>
 struct Codec<false>
@@ -125,6 +128,8 @@ struct Codec<false>
   }
   static __device__ __forceinline__ int32_t G(Entry e) { return static_cast<int32_t>(e.x); }
   static __device__ __forceinline__ int Row(Entry e) { return static_cast<int>(e.y); }
+  static __device__ __forceinline__ Entry Unknown() { return make_uint2(0u, ~0u); }
+  static __device__ __forceinline__ bool IsUnknown(Entry e) { return e.y == ~0u; }
 };
 
 #ifndef VGT_SWEEP_NT
@@ -448,13 +453,19 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         VGT_SWEEP_COUNT(stat_phase == 0 ? 7 : 8, 1);
     }
 #endif
+    // Most pops of sweep 1 are followed by a push, which sets the third entry itself: the ring is read only when a pop
+    // finds the third entry not loaded (a second pop in a row, or a pop after a row that popped without pushing).
     Gt += nB;
     rt -= A;
+    if (__builtin_expect(C::IsUnknown(e3), 0))
+    {
+      if (__builtin_expect(D - 3 * kSlot < L, 0)) refill_now();
+      e3 = ring_ref(D - 3 * kSlot);
+    }
     A = rt - C::Row(e3);
     nB = C::G(e3) - Gt;
     D -= kSlot;
-    if (__builtin_expect(D - 3 * kSlot < L, 0)) refill_now();
-    e3 = ring_ref(D - 3 * kSlot);
+    e3 = C::Unknown();
   };
   auto commit = [&](const Entry (&buf)[kChunk]) {
     L -= kChunkSlots;
@@ -658,6 +669,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     };
     constexpr int kStep = (kChunk < 8) ? 8 : kChunk;  // rows between two refill steps
 
+    if (C::IsUnknown(e3))  // (sweep 1 loads the third entry lazily)
+    {
+      if (D - 3 * kSlot < L) refill_now();
+      e3 = ring_ref(D - 3 * kSlot);
+    }
     // Sweep 2 looks TWO entries down: a row's value is the better of the top and the second entry, so a lane HAS to
     // pop only when the third entry has caught up with the second -- and when some lane of the wave has to, every
     // lane whose second entry is already the better one pops along.  A wave goes through the pop code a quarter as
