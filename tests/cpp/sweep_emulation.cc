@@ -100,7 +100,9 @@ void CheckY(const Case& c, std::mt19937& rng)
         int64_t want = BruteRow(f, neg, ny, y);
         want = (want == INT64_MAX) ? vgt::kInf32 : want;
         const int64_t signed_want = neg[y] ? -want : want;
-        const int32_t got = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        // the Y sweep hands its result to the X sweep as sign and magnitude (bit 31 = class), not two's complement
+        const int32_t raw = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        const int32_t got = (raw < 0) ? -(raw & 0x7fffffff) : raw;
         if (got != signed_want)
         {
           if (failures++ < 10)
@@ -136,7 +138,9 @@ void CheckX(const Case& c, std::mt19937& rng)
         }
         v = std::min<int64_t>(std::max<int64_t>(v, 1), std::max<int64_t>(max_f, 1));
         if (static_cast<int>(rng() % 100) >= c.p_site) v = vgt::kInf32;
-        in[(static_cast<int64_t>(x) * ny + y) * nz + z] = static_cast<int32_t>(cls ? -v : v);
+        // the X sweep's input format: sign and magnitude (bit 31 = class)
+        in[(static_cast<int64_t>(x) * ny + y) * nz + z] =
+            static_cast<int32_t>(static_cast<uint32_t>(v) | (cls ? 0x80000000u : 0u));
       }
     }
   std::vector<float> out(total, 12345.0f);
@@ -157,7 +161,7 @@ void CheckX(const Case& c, std::mt19937& rng)
       {
         const int32_t v = in[(static_cast<int64_t>(x) * ny + y) * nz + z];
         neg[x] = v < 0;
-        const int64_t a = std::llabs(static_cast<long long>(v));
+        const int64_t a = v & 0x7fffffff;
         f[x] = (a == vgt::kInf32) ? -1 : a;
       }
       for (int x = 0; x < nx; x++)

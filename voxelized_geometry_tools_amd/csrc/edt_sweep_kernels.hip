@@ -566,7 +566,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             const int32_t v = cur[k];
             const int32_t sign = v >> 31;
             bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
-            int32_t f = (v ^ sign) - sign;
+            // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
+            // sign and magnitude (bit 31 = class), which one `and` takes apart
+            int32_t f = (sizeof(InT) == 2) ? (v ^ sign) - sign : (v & 0x7fffffff);
             // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
             if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
             {
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             else
             {
               const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
-              VGT_STREAM_STORE(static_cast<OutT>((d2 ^ sign) - sign), &row_out[zl]);
+              // (sign and magnitude, not two's complement: see sweep 1 of the X pass)
+              VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), &row_out[zl]);
             }
             row_out = UniformPointer(row_out - rstride);
           }

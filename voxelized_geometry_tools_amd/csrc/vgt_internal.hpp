@@ -26,7 +26,9 @@ hipStream_t ContextStream(const vgt_hip_ctx* ctx);
 //  pass 1 (Z scan)  -> int16: +d for a free voxel, -d for a filled voxel, d = distance in
 //                      voxels along Z to the nearest voxel of the OTHER class,
 //                      |value| == kInf16 when the line holds no such voxel.
-//  pass 2 (Y pass)  -> int32: +-(squared distance in the YZ plane), kInf32 when none.
+//  pass 2 (Y pass)  -> int32: +-(squared distance in the YZ plane), kInf32 when none (two's complement between the
+//                      tiled-envelope / brute-force passes, sign and magnitude between the sweep passes: the Y and X
+//                      passes of one extraction are always of the same variant).
 //  pass 3 (X pass)  -> float SDF.
 constexpr int16_t kInf16 = 32767;
 constexpr int32_t kInf32 = 0x7fffffff;
