@@ -61,6 +61,17 @@ struct vgt_hip_ctx
   // struct until the last handle is gone, so handle destructors never touch freed memory.
   std::atomic<int> children{0};
   std::atomic<bool> destroyed{false};
+  // Device buffers of destroyed tracking-grid / filter-grid handles, kept for the next handle of the same size (the
+  // voxelizer allocates both per call, S/cuda_voxelization_helpers.cu:641-658,701-708; a hipMalloc + hipFree pair of
+  // 128 MiB costs more than the raycast it serves).  Guarded by `mutex`; vgt_hip_trim and vgt_hip_destroy free them.
+  struct PooledBuffer
+  {
+    void* ptr;
+    size_t bytes;
+  };
+  std::vector<PooledBuffer> pool;
+  size_t pool_bytes = 0;
+  bool pool_closed = false;  // set by vgt_hip_destroy: handles destroyed later free their buffers themselves
   // Copy streams and events of the pipelined host-pointer SDF extraction (SdfFromHostPipelined)
   hipStream_t copy_in = nullptr;
   hipStream_t copy_out = nullptr;
@@ -150,6 +161,46 @@ void ReleaseChild(vgt_hip_ctx* ctx, int device)
   } while (0)
 
 size_t AlignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Handle buffers come from / go back to the context's pool (at most kPoolLimit bytes are kept).
+constexpr size_t kPoolLimit = size_t{4} << 30;
+hipError_t PoolAllocate(vgt_hip_ctx* ctx, void** ptr, size_t bytes)
+{
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    for (size_t i = 0; i < ctx->pool.size(); i++)
+      if (ctx->pool[i].bytes == bytes)
+      {
+        *ptr = ctx->pool[i].ptr;
+        ctx->pool_bytes -= bytes;
+        ctx->pool.erase(ctx->pool.begin() + static_cast<std::ptrdiff_t>(i));
+        return hipSuccess;
+      }
+  }
+  return hipMalloc(ptr, bytes);
+}
+// (the caller has made sure no work uses the buffer any more)
+void PoolRelease(vgt_hip_ctx* ctx, void* ptr, size_t bytes)
+{
+  if (!ptr) return;
+  if (ctx && !ctx->destroyed.load())
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (!ctx->pool_closed && ctx->pool_bytes + bytes <= kPoolLimit && ctx->pool.size() < 16)
+    {
+      ctx->pool.push_back({ptr, bytes});
+      ctx->pool_bytes += bytes;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+void FreePool(vgt_hip_ctx* ctx)
+{
+  for (const auto& b : ctx->pool) (void)hipFree(b.ptr);
+  ctx->pool.clear();
+  ctx->pool_bytes = 0;
+}
 
 // Grow-only device buffer.
 hipError_t Reserve(void** ptr, size_t* have, size_t need)
@@ -669,6 +720,11 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   FreeUploadLanes(ctx, true);
   if (ctx->minmax_out) (void)hipFree(ctx->minmax_out);
   FreeCachedSdfBuffers(ctx);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    ctx->pool_closed = true;
+    FreePool(ctx);
+  }
   for (hipEvent_t e : ctx->timing_events)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->pipeline_events)
@@ -695,6 +751,7 @@ int vgt_hip_trim(vgt_hip_ctx* ctx)
     VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
     VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "drain stream");
     FreeCachedSdfBuffers(ctx);
+    FreePool(ctx);
   }
   // Lock order: an upload lane's mutex is taken BEFORE the context's (UploadAndRun holds its lane while it
   // records an event under ctx->mutex), so the lanes are released after ctx->mutex has been dropped; a raycast that
@@ -781,7 +838,7 @@ int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t n
   g->num_cells = num_cells;
   g->num_grids = num_grids;
   const size_t bytes = static_cast<size_t>(num_cells) * num_grids * 2 * sizeof(int32_t);
-  hipError_t err = hipMalloc(reinterpret_cast<void**>(&g->dev), bytes);
+  hipError_t err = PoolAllocate(ctx, reinterpret_cast<void**>(&g->dev), bytes);
   if (err == hipSuccess)
   {
     std::lock_guard<std::mutex> lock(ctx->mutex);
@@ -801,8 +858,16 @@ int vgt_hip_tracking_grids_create(vgt_hip_ctx* ctx, int64_t num_cells, int32_t n
 void vgt_hip_tracking_grids_destroy(vgt_hip_grids* grids)
 {
   if (!grids) return;
-  ReleaseChild(grids->ctx, grids->device);
-  if (grids->dev) (void)hipFree(grids->dev);
+  vgt_hip_ctx* const ctx = grids->ctx;
+  const size_t bytes = static_cast<size_t>(grids->num_cells) * grids->num_grids * 2 * sizeof(int32_t);
+  // (the buffer goes back to the pool before the handle's reference, which may be the context's last, is dropped)
+  (void)hipSetDevice(grids->device);
+  if (ctx->destroyed.load())
+    (void)hipDeviceSynchronize();
+  else
+    (void)hipStreamSynchronize(ctx->stream);
+  PoolRelease(ctx, grids->dev, bytes);
+  ReleaseChild(ctx, grids->device);
   delete grids;
 }
 
@@ -1010,9 +1075,11 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
   f->device = ctx->device;
   f->num_cells = num_cells;
   const size_t bytes = static_cast<size_t>(num_cells) * sizeof(float);
-  hipError_t err = hipMalloc(reinterpret_cast<void**>(&f->dev), bytes);
+  hipError_t err = PoolAllocate(ctx, reinterpret_cast<void**>(&f->dev), bytes);
   if (err == hipSuccess)
   {
+    // the caller's array is page-locked for the copy (a pageable 64 MiB copy is staged at a fifth of the link rate)
+    const ScopedHostPin pin(occupancy_host, bytes);
     std::lock_guard<std::mutex> lock(ctx->mutex);
     err = hipMemcpyAsync(f->dev, occupancy_host, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
@@ -1031,8 +1098,14 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
 void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter)
 {
   if (!filter) return;
-  ReleaseChild(filter->ctx, filter->device);
-  if (filter->dev) (void)hipFree(filter->dev);
+  vgt_hip_ctx* const ctx = filter->ctx;
+  (void)hipSetDevice(filter->device);
+  if (ctx->destroyed.load())
+    (void)hipDeviceSynchronize();
+  else
+    (void)hipStreamSynchronize(ctx->stream);
+  PoolRelease(ctx, filter->dev, static_cast<size_t>(filter->num_cells) * sizeof(float));
+  ReleaseChild(ctx, filter->device);
   delete filter;
 }
 
@@ -1101,8 +1174,9 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
   if (!ctx || !filter || !host_out || filter->ctx != ctx)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
-  std::lock_guard<std::mutex> lock(ctx->mutex);
   const size_t bytes = static_cast<size_t>(filter->num_cells) * sizeof(float);
+  const ScopedHostPin pin(host_out, bytes);
+  std::lock_guard<std::mutex> lock(ctx->mutex);
   VGT_TRY_HIP(hipMemcpyAsync(host_out, filter->dev, bytes, hipMemcpyDeviceToHost, ctx->stream),
               "Failed to memcpy the filter grid back to the host");
   VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "retrieve filtered grid");
