@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="cube edge instead of the workload's shape (experiments)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
-    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2 cross-check implementations)")
+    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2 cross-check implementations; 3 split-launch prototype)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")

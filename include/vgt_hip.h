@@ -207,7 +207,8 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
 /* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
  * 0 = default (lane-per-line sweeps: one lane runs the Felzenszwalb-Huttenlocher stack of one line, stack tops in
  * LDS, any extent), 1 = pruned outward search from HBM (any size), 2 = LDS-tiled lower envelope (band hulls + merge;
- * axes up to 2048, longer ones take the pruned search). */
+ * axes up to 2048, longer ones take the pruned search), 3 = the sweeps of 0 launched per half of the Z range on two
+ * streams in vgt_hip_sdf_dev (a measured prototype; the other entry points treat it as 0). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 /* Diagnostic: the final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation
  * with an exact fallback (csrc/edt_device.hpp); this runs both over d2 in

@@ -22,7 +22,7 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 2]  # lane-per-line sweeps (default), pruned search from HBM, LDS-tiled envelope
+VARIANTS = [0, 1, 2, 3]  # lane-per-line sweeps (default), pruned search from HBM, LDS-tiled envelope
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -751,7 +751,7 @@ hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const Sd
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream)
 {
-  if (variant == EdtVariant::kDefault) return LaunchPassYSweep(in16, out32, scratch, p, stream);
+  if (IsSweepVariant(variant)) return LaunchPassYSweep(in16, out32, scratch, p, stream);
   if (variant == EdtVariant::kHull)
   {
     bool handled = false;
@@ -768,7 +768,7 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                                void* scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream)
 {
-  if (variant == EdtVariant::kDefault)
+  if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
   if (variant == EdtVariant::kHull)
   {
@@ -787,7 +787,7 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
 
 bool LinePassesTakeRanges(const SdfParams& p, EdtVariant variant)
 {
-  if (variant == EdtVariant::kDefault) return true;
+  if (IsSweepVariant(variant)) return true;
   return variant == EdtVariant::kHull && HullPassesAreTiled(p);
 }
 
@@ -795,7 +795,7 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
                                     const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
                                     hipStream_t stream)
 {
-  if (variant == EdtVariant::kDefault)
+  if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, outer_begin, outer_count, stream);
   bool handled = false;
   const hipError_t err = LaunchPassXHullFinalizeRange(in32, sdf, minmax_enc, p, outer_begin, outer_count, stream, &handled);

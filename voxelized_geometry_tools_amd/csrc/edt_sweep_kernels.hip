@@ -1065,6 +1065,31 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
 {
   return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
 }
+
+// The passes over the Z positions [z_begin, z_begin + z_count) only (full-grid pointers and extents in `p`; z_begin a
+// multiple of 64).  Lines of different Z never interact in the Y and X passes, so an X launch over a Z range depends
+// only on the Y launch over the same range: EdtVariant::kSplit runs the two halves of the grid on two streams, and
+// the tail of one launch overlaps the head of the next.
+hipError_t LaunchPassYSweepZRange(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+                                  int64_t z_begin, int64_t z_count, hipStream_t stream)
+{
+  int64_t outer_count = 0;
+  SweepGeom g = SweepGeometry(p, 1, &outer_count);
+  g.nz = static_cast<int>(z_count);
+  g.z_offset += static_cast<int>(z_begin);
+  return LaunchSweep<int16_t, int32_t, false>(in16 + z_begin, out32 + z_begin, scratch, nullptr, g, outer_count,
+                                              MaxInputY(p), stream);
+}
+hipError_t LaunchPassXSweepFinalizeZRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                          const SdfParams& p, int64_t z_begin, int64_t z_count, hipStream_t stream)
+{
+  int64_t outer_count = 0;
+  SweepGeom g = SweepGeometry(p, 0, &outer_count);
+  g.nz = static_cast<int>(z_count);
+  g.z_offset += static_cast<int>(z_begin);
+  return LaunchSweep<int32_t, float, true>(in32 + z_begin, sdf + z_begin, scratch, minmax_enc, g, outer_count,
+                                           MaxInputX(p), stream);
+}
 }  // namespace vgt
 
 #ifdef VGT_SWEEP_TIMING

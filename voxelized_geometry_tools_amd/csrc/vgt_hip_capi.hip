@@ -72,6 +72,11 @@ struct vgt_hip_ctx
   std::vector<PooledBuffer> pool;
   size_t pool_bytes = 0;
   bool pool_closed = false;  // set by vgt_hip_destroy: handles destroyed later free their buffers themselves
+  // EdtVariant::kSplit: the second stream, its scratch and the fork / join events
+  hipStream_t split_stream = nullptr;
+  void* split_scratch = nullptr;
+  size_t split_scratch_bytes = 0;
+  hipEvent_t split_fork = nullptr, split_join = nullptr;
   // Copy streams and events of the pipelined host-pointer SDF extraction (SdfFromHostPipelined)
   hipStream_t copy_in = nullptr;
   hipStream_t copy_out = nullptr;
@@ -216,12 +221,12 @@ hipError_t Reserve(void** ptr, size_t* have, size_t need)
 
 void FreeCachedSdfBuffers(vgt_hip_ctx* ctx)
 {
-  for (void** p : {&ctx->sdf_in, &ctx->sdf_out, &ctx->sdf_ws, &ctx->ray_scratch})
+  for (void** p : {&ctx->sdf_in, &ctx->sdf_out, &ctx->sdf_ws, &ctx->ray_scratch, &ctx->split_scratch})
   {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
-  ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = 0;
+  ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = ctx->split_scratch_bytes = 0;
 }
 
 // Page-locks a caller-owned host range for the duration of a call, unless it already is pinned
@@ -355,10 +360,42 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
   else
     VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, nullptr, s), "Z scan");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
-  if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s),
-              "X pass");
+  const int64_t z_segments = (p.nz + 63) / 64;
+  if (ctx->variant == vgt::EdtVariant::kSplit && z_segments >= 2)
+  {
+    // Prototype: the Y and X passes of the lower and of the upper half of the Z range on two streams.  Nothing orders
+    // the halves against each other: the persistent workgroups of whichever launch is ready fill the wave slots the
+    // others give up, so the tail of one launch runs beside the head of the next.  The upper half has its own scratch.
+    const size_t scratch_bytes = vgt::SweepPassScratchBytes(p.nx, p.ny, p.nz);
+    if (!ctx->split_stream)
+    {
+      VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->split_stream, hipStreamNonBlocking), "create stream");
+      VGT_TRY_HIP(hipEventCreateWithFlags(&ctx->split_fork, hipEventDisableTiming), "create event");
+      VGT_TRY_HIP(hipEventCreateWithFlags(&ctx->split_join, hipEventDisableTiming), "create event");
+    }
+    VGT_TRY_HIP(Reserve(&ctx->split_scratch, &ctx->split_scratch_bytes, scratch_bytes), "allocate second scratch");
+    const int64_t z_mid = z_segments / 2 * 64;
+    hipStream_t s2 = ctx->split_stream;
+    VGT_TRY_HIP(hipEventRecord(ctx->split_fork, s), "event record");
+    VGT_TRY_HIP(hipStreamWaitEvent(s2, ctx->split_fork, 0), "fork");
+    VGT_TRY_HIP(vgt::LaunchPassYSweepZRange(ws.t16, ws.t32, ws.sweep_scratch, p, 0, z_mid, s), "Y pass");
+    VGT_TRY_HIP(vgt::LaunchPassYSweepZRange(ws.t16, ws.t32, ctx->split_scratch, p, z_mid, p.nz - z_mid, s2), "Y pass");
+    if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
+    VGT_TRY_HIP(vgt::LaunchPassXSweepFinalizeZRange(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, 0, z_mid, s),
+                "X pass");
+    VGT_TRY_HIP(vgt::LaunchPassXSweepFinalizeZRange(ws.t32, sdf_dev, ws.minmax_enc, ctx->split_scratch, p, z_mid,
+                                                    p.nz - z_mid, s2),
+                "X pass");
+    VGT_TRY_HIP(hipEventRecord(ctx->split_join, s2), "event record");
+    VGT_TRY_HIP(hipStreamWaitEvent(s, ctx->split_join, 0), "join");
+  }
+  else
+  {
+    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
+    if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
+    VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s),
+                "X pass");
+  }
   if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
   return VGT_HIP_OK;
@@ -730,6 +767,14 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   for (hipEvent_t e : ctx->pipeline_events)
     if (e) (void)hipEventDestroy(e);
   ctx->pipeline_events.clear();
+  if (ctx->split_stream)
+  {
+    (void)hipStreamSynchronize(ctx->split_stream);
+    (void)hipStreamDestroy(ctx->split_stream);
+    (void)hipEventDestroy(ctx->split_fork);
+    (void)hipEventDestroy(ctx->split_join);
+    ctx->split_stream = nullptr;
+  }
   if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   ctx->copy_in = nullptr;
@@ -792,7 +837,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 2) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
+  if (!ctx || variant < 0 || variant > 3) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
 }

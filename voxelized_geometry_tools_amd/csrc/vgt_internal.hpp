@@ -78,7 +78,10 @@ struct SlabLineCarry
 // (edt_sweep_kernels.hip; any extent); kBruteForce: pruned outward search straight from HBM; kHull: LDS-tiled
 // lower-envelope passes (band hulls + merge, edt_hull_kernels.hip; axes up to 2048, longer ones fall back to the
 // pruned search).  All exact; 1 and 2 exist for cross-checking.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2 };
+// kSplit: the sweep passes of kDefault, launched per half of the Z range on two streams where the entry point drives the
+// whole pipeline itself (vgt_hip_sdf_dev): a measured prototype of overlapping the passes' tails, see DESIGN.md 4.1.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2, kSplit = 3 };
+inline bool IsSweepVariant(EdtVariant v) { return v == EdtVariant::kDefault || v == EdtVariant::kSplit; }
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -100,6 +103,11 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const
                        EdtVariant variant, hipStream_t stream);
 // X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
 // order-preserving encoding, must be pre-initialised by InitMinMax).
+// The sweep passes over the Z positions [z_begin, z_begin + z_count) only (edt_sweep_kernels.hip).
+hipError_t LaunchPassYSweepZRange(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+                                  int64_t z_begin, int64_t z_count, hipStream_t stream);
+hipError_t LaunchPassXSweepFinalizeZRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+                                          const SdfParams& p, int64_t z_begin, int64_t z_count, hipStream_t stream);
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                void* scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
