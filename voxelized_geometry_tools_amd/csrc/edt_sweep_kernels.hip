@@ -970,21 +970,19 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
   if (err != hipSuccess) return err;
 #endif
   const dim3 grid(static_cast<unsigned>(slots)), block(kWaveSize);
-  // occupancy experiments: extra dynamic LDS per workgroup (bytes)
-  static const int extra_lds = getenv("VGT_SWEEP_EXTRA_LDS") ? atoi(getenv("VGT_SWEEP_EXTRA_LDS")) : 0;
   // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
   const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
   if (packed && general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, extra_lds, stream, in, out,
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, 0, stream, in, out,
                        spill, info, minmax_enc, counter, g);
   else if (packed)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, extra_lds, stream, in, out, spill,
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, 0, stream, in, out, spill,
                        info, minmax_enc, counter, g);
   else if (general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, extra_lds, stream, in, out,
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, 0, stream, in, out,
                        spill, info, minmax_enc, counter, g);
   else
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, extra_lds, stream, in, out, spill,
+    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, 0, stream, in, out, spill,
                        info, minmax_enc, counter, g);
   return hipGetLastError();
 }
