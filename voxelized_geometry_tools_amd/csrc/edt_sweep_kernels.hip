@@ -860,7 +860,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             }
             else
             {
-              const int32_t d2 = (best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
+              // ("no site" only on lines without any: the waves that have one run the band copy with kClasses)
+              const int32_t d2 =
+                  (kClasses && best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
               // (sign and magnitude, not two's complement: see sweep 1 of the X pass)
               VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), &row_out[zl]);
             }
