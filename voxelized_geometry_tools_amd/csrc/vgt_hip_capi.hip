@@ -26,6 +26,12 @@ struct UploadLane
   hipEvent_t after_ctx = nullptr;  // orders the lane behind what the context's stream holds (grid zeroing)
   void* stage = nullptr;
   size_t stage_bytes = 0;
+  // Page-locked host buffer the caller's cloud is copied to first: a 12-MB cloud from pageable memory goes through the
+  // runtime's bounce buffers in 5 - 12 ms, page-locking the caller's buffer per call serialises in the driver when
+  // several clouds arrive at once; a copy into a buffer that is locked once costs about a millisecond, in parallel
+  // across the lanes, and the DMA 0.2 ms.
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
 };
 constexpr int kUploadLanes = 4;
 
@@ -583,6 +589,9 @@ void FreeUploadLanes(vgt_hip_ctx* ctx, bool destroy_streams)
     if (lane.stage) (void)hipFree(lane.stage);
     lane.stage = nullptr;
     lane.stage_bytes = 0;
+    if (lane.pinned) (void)hipHostFree(lane.pinned);
+    lane.pinned = nullptr;
+    lane.pinned_bytes = 0;
     if (destroy_streams)
     {
       if (lane.after_ctx) (void)hipEventDestroy(lane.after_ctx);
@@ -601,8 +610,25 @@ void FreeUploadLanes(vgt_hip_ctx* ctx, bool destroy_streams)
 template <typename Launch>
 int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratch_bytes, Launch launch)
 {
-  UploadLane& lane = ctx->lanes[ctx->next_lane.fetch_add(1) % kUploadLanes];
-  std::lock_guard<std::mutex> lane_lock(lane.mutex);
+  // the first idle lane (a caller that raycasts one cloud after the other keeps using lane 0, whose stream and staging
+  // buffer exist; concurrent callers spread over the lanes), or, when all are busy, the next one in turn
+  UploadLane* chosen = nullptr;
+  std::unique_lock<std::mutex> lane_lock;
+  for (int i = 0; i < kUploadLanes && !chosen; i++)
+  {
+    std::unique_lock<std::mutex> attempt(ctx->lanes[i].mutex, std::try_to_lock);
+    if (attempt.owns_lock())
+    {
+      chosen = &ctx->lanes[i];
+      lane_lock = std::move(attempt);
+    }
+  }
+  if (!chosen)
+  {
+    chosen = &ctx->lanes[ctx->next_lane.fetch_add(1) % kUploadLanes];
+    lane_lock = std::unique_lock<std::mutex>(chosen->mutex);
+  }
+  UploadLane& lane = *chosen;
   if (!lane.stream)
   {
     VGT_TRY_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking), "create upload stream");
@@ -626,7 +652,32 @@ int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratc
     VGT_TRY_HIP(hipEventRecord(lane.after_ctx, ctx->stream), "record event");
   }
   VGT_TRY_HIP(hipStreamWaitEvent(lane.stream, lane.after_ctx, 0), "order upload lane");
-  VGT_TRY_HIP(hipMemcpyAsync(lane.stage, host, bytes, hipMemcpyHostToDevice, lane.stream),
+  const void* source = host;
+  {
+    hipPointerAttribute_t attr{};
+    const bool caller_locked = hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (!caller_locked && bytes >= (size_t{1} << 16))
+    {
+      if (lane.pinned_bytes < bytes)
+      {
+        if (lane.pinned) (void)hipHostFree(lane.pinned);
+        lane.pinned = nullptr;
+        lane.pinned_bytes = 0;
+        const size_t want = AlignUp(bytes + bytes / 4, 1 << 20);
+        if (hipHostMalloc(&lane.pinned, want, hipHostMallocDefault) == hipSuccess)
+          lane.pinned_bytes = want;
+        else
+          (void)hipGetLastError();  // (no page-locked memory to be had: the copy takes the pageable path)
+      }
+      if (lane.pinned_bytes >= bytes)
+      {
+        std::memcpy(lane.pinned, host, bytes);  // (the previous use of the buffer was waited for at the end of its call)
+        source = lane.pinned;
+      }
+    }
+  }
+  VGT_TRY_HIP(hipMemcpyAsync(lane.stage, source, bytes, hipMemcpyHostToDevice, lane.stream),
               "Failed to copy points to the device");
   VGT_TRY_HIP(launch(lane.stage, static_cast<char*>(lane.stage) + scratch_at, lane.stream),
               "Failed to dispatch raycast kernel");
