@@ -399,6 +399,34 @@ def test_pointcloud2_ingestion(ctx, oracle, layout):
             grids.raycast_pointcloud2(0, data, len(pts), point_step, 2, 2.0, xf, vs, ivs, sizes, counts)
 
 
+def test_pooled_handle_buffers_come_back_clean(ctx, oracle):
+    """Tracking-grid / filter-grid buffers of destroyed handles are kept for the next handle of the same size: a reused
+    tracking grid starts from zero counts, a reused filter grid holds the new occupancy, vgt_hip_trim drops the pool."""
+    counts = (48, 48, 48)
+    cells = int(np.prod(counts))
+    vs = np.float32(5.12 / 48)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    pts = synthetic.raycast_cloud(20_000, seed=5)
+    xf = synthetic.translation_xform(2.56, 2.56, 2.56).astype(np.float32)
+    want = oracle.raycast_f32(pts, 3.0, xf, vs, ivs, sizes, counts)
+    first_ptr = None
+    for round_index in range(3):
+        grids = ctx.tracking_grids(cells, 2)
+        if round_index == 0:
+            first_ptr = grids.dev_ptr(0)
+        elif round_index == 1:
+            assert grids.dev_ptr(0) == first_ptr, "the buffer of the destroyed handle was not reused"
+        assert not grids.retrieve(0).any() and not grids.retrieve(1).any()
+        grids.raycast_f32(1, pts, 3.0, xf, vs, ivs, sizes, counts)
+        assert np.array_equal(grids.retrieve(1, counts), want)
+        env = np.full(counts, 0.25 * round_index, dtype=np.float32)
+        fg = ctx.filter_grid(env)
+        assert np.array_equal(fg.retrieve().reshape(counts), env)
+        fg.close()
+        grids.close()
+        if round_index == 1:
+            ctx.trim()
 def test_context_destroyed_before_its_handles():
     """A context destroyed while grids / filter grids / cell grids made from it are still alive (the RAII order
     of a caller that declares the context last) must not be touched after it is freed: the library keeps the
