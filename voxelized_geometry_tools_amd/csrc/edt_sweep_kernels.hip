@@ -52,6 +52,9 @@ namespace
 #ifndef VGT_SWEEP_WAVES
 #define VGT_SWEEP_WAVES 4
 #endif
+#ifndef VGT_SWEEP_GROUP
+#define VGT_SWEEP_GROUP 2  // rows of the X pass's sweep 2 whose final conversions form one block of code (1, 2 or 4)
+#endif
 #ifndef VGT_SWEEP_EXP
 #define VGT_SWEEP_EXP 0
 #endif
@@ -747,11 +750,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       int dp[8];
       uint32_t xup = 0;
       if (classes) xup = xup_word >> sub;
-      [[maybe_unused]] float pending_value = 0.0f;
       // (two copies of a full band's code, with and without the class-change candidates: no test per row)
       auto rows = [&](auto guarded, auto with_classes) {
         constexpr bool kGuard = decltype(guarded)::value;
         constexpr bool kClasses = decltype(with_classes)::value;
+        constexpr int kGroup = kGuard ? 1 : VGT_SWEEP_GROUP;  // rows finished together (X pass)
+        [[maybe_unused]] float& lo_acc = lo_value;  // (named here: the uses below sit in code that depends on kGroup)
+        [[maybe_unused]] float& hi_acc = hi_value;
+        [[maybe_unused]] uint32_t grp_best[kGroup];
+        [[maybe_unused]] int32_t grp_sign[kGroup];
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
@@ -803,58 +810,88 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             const int32_t sign = __builtin_amdgcn_sbfe(static_cast<int32_t>(swb), k, 1);  // -1 on the negative class
             if constexpr (kFinal)
             {
-              uint32_t d2 = best;
-              bool exact = false;
-              if constexpr (!kPlain)
+              // The conversions of kGroup rows run as ONE block of code: each is a chain of a dozen dependent
+              // instructions (reciprocal square root, fp64 steps), and a wave-uniform branch per row would keep the
+              // compiler from overlapping the chains of neighbouring rows.  The rare-path test is taken once per group.
+              grp_best[k % kGroup] = best;
+              grp_sign[k % kGroup] = sign;
+              if (k % kGroup == 0)
               {
-                if (g.add_virtual_border)
+                float dist[kGroup];
+                uint32_t d2s[kGroup];
+                bool redo[kGroup], none[kGroup];
+                bool any_rare = false;
+#pragma unroll
+                for (int j = kGroup - 1; j >= 0; j--)  // row k + j
                 {
-                  const int x = (g.pass_axis == 0) ? q : outer + g.outer_begin;
-                  const int y = (g.pass_axis == 0) ? outer + g.outer_begin : q;
-                  const int32_t site = (d2 >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(d2);
-                  const int32_t clamped = ClampToVirtualBorder(site, x, y, z0 + static_cast<int>(zl) + g.z_offset, g.nx,
-                                                               g.ny, g.nz_global);
-                  d2 = (clamped == kInf32) ? static_cast<uint32_t>(kLimit) : static_cast<uint32_t>(clamped);
+                  uint32_t d2 = grp_best[j];
+                  bool exact = false;
+                  if constexpr (!kPlain)
+                  {
+                    if (g.add_virtual_border)
+                    {
+                      const int qq = q + j;
+                      const int x = (g.pass_axis == 0) ? qq : outer + g.outer_begin;
+                      const int y = (g.pass_axis == 0) ? outer + g.outer_begin : qq;
+                      const int32_t site = (d2 >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(d2);
+                      const int32_t clamped = ClampToVirtualBorder(site, x, y, z0 + static_cast<int>(zl) + g.z_offset, g.nx,
+                                                                   g.ny, g.nz_global);
+                      d2 = (clamped == kInf32) ? static_cast<uint32_t>(kLimit) : static_cast<uint32_t>(clamped);
+                    }
+                    exact = !(g.resolution > 1.0e-30 && g.resolution < 1.0e30);
+                  }
+                  bool unsure;
+                  if (VGT_SWEEP_EXP & 1)
+                  {
+                    unsure = false;
+                    dist[j] = __uint_as_float(d2);
+                  }
+                  else
+                    dist[j] = FastSqrtTimesResolution(d2, g.resolution, unsure);
+                  // no voxel of the other class anywhere: only on lines whose stack holds nothing but the sentinels, and
+                  // waves with such a line run the copy of the band code that also has the class candidates
+                  none[j] = kClasses && d2 >= static_cast<uint32_t>(kLimit);
+                  redo[j] = unsure || exact;
+                  d2s[j] = d2;
+                  any_rare = any_rare || redo[j] || none[j];
                 }
-                exact = !(g.resolution > 1.0e-30 && g.resolution < 1.0e30);
-              }
-              bool unsure;
-              float dist;
-              if (VGT_SWEEP_EXP & 1)
-              {
-                unsure = false;
-                dist = __uint_as_float(d2);
-              }
-              else
-                dist = FastSqrtTimesResolution(d2, g.resolution, unsure);
-              // no voxel of the other class anywhere: only on lines whose stack holds nothing but the sentinels, and
-              // waves with such a line run the copy of the band code that also has the class candidates
-              const bool none = kClasses && d2 >= static_cast<uint32_t>(kLimit);
-              if (__builtin_expect(__builtin_amdgcn_ballot_w64(unsure || exact || none) != 0ull, 0))
-              {
-                VGT_COLD_PATH();  // keeps the block out of the straight-line code
-#ifdef VGT_SWEEP_STATS
-                if (lane == 0) VGT_SWEEP_COUNT(6, 1);
-#endif
-                if (unsure || exact) dist = SqrtTimesResolutionExact(static_cast<int32_t>(d2), g.resolution);
-                if (none) dist = __uint_as_float(0x7f800000u);
-              }
-              const float value = __uint_as_float(__float_as_uint(dist) | (static_cast<uint32_t>(sign) & 0x80000000u));
-              VGT_STREAM_STORE(value, LaneAddress(row_out, zl * 4u));
-              // extrema: two rows per instruction in full bands
-              if constexpr (kGuard)
-              {
-                VGT_MIN_F32(lo_value, value);
-                VGT_MAX_F32(hi_value, value);
-              }
-              else if constexpr (true)
-              {
-                if (k % 2 == 1)
-                  pending_value = value;
-                else
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_rare) != 0ull, 0))
                 {
-                  VGT_MIN3_F32(lo_value, pending_value, value);
-                  VGT_MAX3_F32(hi_value, pending_value, value);
+                  VGT_COLD_PATH();  // keeps the block out of the straight-line code
+#ifdef VGT_SWEEP_STATS
+                  if (lane == 0) VGT_SWEEP_COUNT(6, 1);
+#endif
+#pragma unroll
+                  for (int j = 0; j < kGroup; j++)
+                  {
+                    if (redo[j]) dist[j] = SqrtTimesResolutionExact(static_cast<int32_t>(d2s[j]), g.resolution);
+                    if (none[j]) dist[j] = __uint_as_float(0x7f800000u);
+                  }
+                }
+                float value[kGroup];
+                VGT_GLOBAL OutT* store_at = row_out;  // row k + kGroup - 1
+#pragma unroll
+                for (int j = kGroup - 1; j >= 0; j--)
+                {
+                  value[j] = __uint_as_float(__float_as_uint(dist[j]) | (static_cast<uint32_t>(grp_sign[j]) & 0x80000000u));
+                  VGT_STREAM_STORE(value[j], LaneAddress(store_at, zl * 4u));
+                  store_at = UniformPointer(store_at - rstride);
+                }
+                row_out = store_at;
+                // extrema: two rows per instruction where rows come in pairs
+#pragma unroll
+                for (int j = kGroup - 1; j >= 0; j -= 2)
+                {
+                  if (j >= 1)
+                  {
+                    VGT_MIN3_F32(lo_acc, value[j], value[j - 1]);
+                    VGT_MAX3_F32(hi_acc, value[j], value[j - 1]);
+                  }
+                  else
+                  {
+                    VGT_MIN_F32(lo_acc, value[j]);
+                    VGT_MAX_F32(hi_acc, value[j]);
+                  }
                 }
               }
             }
@@ -865,8 +902,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                   (kClasses && best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
               // (sign and magnitude, not two's complement: see sweep 1 of the X pass)
               VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), &row_out[zl]);
+              row_out = UniformPointer(row_out - rstride);
             }
-            row_out = UniformPointer(row_out - rstride);
           }
         }
       };
