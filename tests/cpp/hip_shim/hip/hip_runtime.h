@@ -4,6 +4,7 @@
 // stack / ring / spill bookkeeping can be checked against a brute-force transform without a GPU.  Test infrastructure,
 // never part of the product.
 #pragma once
+#include <cassert>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -58,7 +59,7 @@ using std::max;
 using std::min;
 
 inline int __mul24(int a, int b) { return static_cast<int>(static_cast<uint32_t>(a) * static_cast<uint32_t>(b)); }
-#define __builtin_assume(cond) ((void)0)
+#define __builtin_assume(cond) assert(cond)  // (the emulation checks every assumption the kernels hand to the optimiser)
 inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz(static_cast<unsigned>(v)); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

@@ -113,6 +113,112 @@ void CheckY(const Case& c, std::mt19937& rng)
     }
 }
 
+// Class records (csrc/vgt_internal.hpp) of a class volume, by the definition: a plain restatement for the test, independent
+// of the device kernel that writes them (csrc/edt_record_kernels.hip, checked on the GPU through the SDF parity tests).
+std::vector<vgt::ClassRecord> RecordsOf(const std::vector<uint8_t>& cls, int nx, int ny, int nz, bool mark_no_site)
+{
+  const int nwords = static_cast<int>(vgt::RecordWords(nz));
+  std::vector<vgt::ClassRecord> rec(static_cast<size_t>(nx) * nwords * ny + 64);
+  for (auto& r : rec) r = vgt::ClassRecord{0xdeadbeefu, 0xdeadbeefu, 12345u, 54321u};  // (padding: never used)
+  for (int x = 0; x < nx; x++)
+    for (int y = 0; y < ny; y++)
+    {
+      const uint8_t* line = &cls[(static_cast<size_t>(x) * ny + y) * nz];
+      bool any = false;
+      for (int z = 0; z + 1 < nz; z++) any = any || line[z] != line[z + 1];
+      for (int w = 0; w < nwords; w++)
+      {
+        vgt::ClassRecord r{0, 0, vgt::kRecordNoneBelow, vgt::kRecordNoneAbove};
+        for (int k = 0; k < 64; k++)
+        {
+          const int z = std::min(64 * w + k, nz - 1);
+          if (line[z]) (k < 32 ? r.mask_lo : r.mask_hi) |= 1u << (k & 31);
+        }
+        for (int t = 64 * w - 1; t >= 0; t--)
+          if (line[t] != line[t + 1])
+          {
+            r.below2 = static_cast<uint32_t>(2 * (t - 64 * w)) + vgt::kRecordBias;
+            break;
+          }
+        for (int t = 64 * w + 63; t + 1 < nz; t++)
+          if (line[t] != line[t + 1])
+          {
+            r.above2 = static_cast<uint32_t>(2 * (t - 64 * w)) + vgt::kRecordBias;
+            break;
+          }
+        if (mark_no_site && !any) r.above2 = vgt::kRecordNoSite;
+        rec[(static_cast<size_t>(x) * nwords + w) * ny + y] = r;
+      }
+    }
+  return rec;
+}
+
+// Y pass of the default pipeline: class records in, int32 out, against the brute-force transform of the distances along Z.
+// c.mode: 0 = independent voxels (p_flip = percent filled), 1 = runs along Z (p_flip = percent chance of a class change per
+// voxel), 2 = runs along Z, and a share of the lines (100 - p_site percent) holds one class only; c.border: records
+// without the one-class marks (what a slab sees before its neighbours' carries).
+void CheckYRecords(const Case& c, std::mt19937& rng)
+{
+  const int nx = c.nx, ny = c.ny, nz = c.nz;
+  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
+  std::vector<uint8_t> cls(total);
+  for (int x = 0; x < nx; x++)
+    for (int y = 0; y < ny; y++)
+    {
+      uint8_t* line = &cls[(static_cast<size_t>(x) * ny + y) * nz];
+      int cur = rng() & 1;
+      const bool flat = c.mode == 2 && static_cast<int>(rng() % 100) >= c.p_site;
+      for (int z = 0; z < nz; z++)
+      {
+        if (c.mode == 0)
+          cur = static_cast<int>(rng() % 100) < c.p_flip;
+        else if (!flat && static_cast<int>(rng() % 100) < c.p_flip)
+          cur ^= 1;
+        line[z] = static_cast<uint8_t>(cur);
+      }
+    }
+  const std::vector<vgt::ClassRecord> rec = RecordsOf(cls, nx, ny, nz, !c.border);
+  std::vector<int32_t> out(total, 12345);
+  vgt::SdfParams p{};
+  p.nx = nx; p.ny = ny; p.nz = nz;
+  p.resolution = 0.01;
+  std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
+  vgt::LaunchPassYSweepRecords(rec.data(), out.data(), scratch.data(), p, nullptr);
+  std::vector<int64_t> f(ny);
+  std::vector<uint8_t> neg(ny);
+  for (int x = 0; x < nx; x++)
+    for (int z = 0; z < nz; z++)
+    {
+      for (int y = 0; y < ny; y++)
+      {
+        const uint8_t* line = &cls[(static_cast<size_t>(x) * ny + y) * nz];
+        neg[y] = line[z];
+        int64_t d = -1;
+        for (int k = 1; k < nz; k++)
+          if ((z - k >= 0 && line[z - k] != line[z]) || (z + k < nz && line[z + k] != line[z]))
+          {
+            d = k;
+            break;
+          }
+        f[y] = d < 0 ? -1 : d * d;
+      }
+      for (int y = 0; y < ny; y++)
+      {
+        int64_t want = BruteRow(f, neg, ny, y);
+        want = (want == INT64_MAX) ? vgt::kInf32 : want;
+        const int64_t signed_want = neg[y] ? -want : want;
+        const int32_t raw = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
+        const int32_t got = (raw < 0) ? -(raw & 0x7fffffff) : raw;
+        if (got != signed_want)
+        {
+          if (failures++ < 10)
+            std::printf("Y (records) MISMATCH shape %dx%dx%d mode %d line (x=%d,z=%d) row %d: got %d want %lld\n", nx, ny, nz,
+                        c.mode, x, z, y, got, static_cast<long long>(signed_want));
+        }
+      }
+    }
+}
+
 // X-pass shaped run: lines along x, int32 input (signed squared YZ distance), float output + extrema.
 void CheckX(const Case& c, std::mt19937& rng)
 {
@@ -214,6 +320,20 @@ int main(int argc, char** argv)
     for (const Case& c : y_cases)
     {
       CheckY(c, rng);
+      cases++;
+    }
+    // {nx, ny, nz, mode, p_site (mode 2: percent of lines with class changes), p_flip, border (no one-class marks)}
+    const Case record_cases[] = {
+        {2, 1, 3, 0, 0, 50, false},      {3, 2, 5, 1, 0, 30, false},     {2, 33, 7, 0, 0, 10, true},
+        {1, 300, 64, 1, 0, 3, false},    {2, 300, 65, 0, 0, 1, false},   {1, 1024, 130, 2, 30, 2, false},
+        {1, 1024, 70, 0, 0, 2, false},   {2, 700, 128, 2, 10, 5, false}, {1, 1500, 3, 1, 0, 20, false},
+        {1, 2050, 2, 0, 0, 50, false},   {3, 97, 66, 1, 0, 40, true},    {2, 64, 64, 2, 0, 5, false},
+        {1, 513, 200, 2, 50, 1, true},   {1, 999, 2, 0, 0, 99, false},   {1, 1030, 257, 1, 0, 1, false},
+        {1, 77, 1, 0, 0, 30, false},     {2, 40, 64, 0, 0, 0, false},    {1, 260, 191, 0, 0, 3, false},
+    };
+    for (const Case& c : record_cases)
+    {
+      CheckYRecords(c, rng);
       cases++;
     }
     const Case x_cases[] = {

@@ -283,6 +283,46 @@ __device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t
   return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) + PinnedOffset(byte_offset));
 }
 
+// A class record (vgt_internal.hpp) through a wave-uniform address: a scalar load (s_load_dwordx4; neighbouring rows merge
+// into wider ones), the record lands in scalar registers.  The records were written by an earlier kernel, so the constant
+// address space is safe.
+__device__ __forceinline__ uint4 LoadRecord(const ClassRecord* base, int index)
+{
+#ifdef VGT_HOST_EMULATION
+  const ClassRecord r = base[index];
+  return make_uint4(r.mask_lo, r.mask_hi, r.below2, r.above2);
+#else
+  using Raw = uint32_t __attribute__((ext_vector_type(4)));
+  using ConstRaw = const __attribute__((address_space(4))) Raw;
+  ConstRaw* p = reinterpret_cast<ConstRaw*>(reinterpret_cast<uint64_t>(base));
+  const Raw r = p[index];
+  return make_uint4(r.x, r.y, r.z, r.w);
+#endif
+}
+// |a - b| + 1 with b the same in every lane: one v_sad_u32 with a scalar operand.
+__device__ __forceinline__ uint32_t AbsDiffPlusOne(uint32_t a, uint32_t b_uniform)
+{
+#ifdef VGT_HOST_EMULATION
+  return (a > b_uniform ? a - b_uniform : b_uniform - a) + 1u;
+#else
+  uint32_t d;
+  asm("v_sad_u32 %0, %1, %2, 1" : "=v"(d) : "v"(a), "s"(b_uniform));
+  return d;
+#endif
+}
+// all ones in the lanes whose bit of a wave-uniform 64-bit mask is set, else zero: one v_cndmask with the mask as the
+// condition (a scalar register pair)
+__device__ __forceinline__ uint32_t SpreadLaneMask(uint64_t mask_uniform, [[maybe_unused]] int lane)
+{
+#ifdef VGT_HOST_EMULATION
+  return ((mask_uniform >> lane) & 1ull) ? ~0u : 0u;
+#else
+  uint32_t d;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(mask_uniform));
+  return d;
+#endif
+}
+
 __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 {
   return (bits >= 32) ? ~0u : ((1u << bits) - 1u);
@@ -344,6 +384,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 {
   using C = Codec<kPacked>;
   using Entry = typename C::Entry;
+  // the Y pass reads class records (the default pipeline) or int16 distances along Z (the cross-check pipelines)
+  constexpr bool kRecords = std::is_same<InT, ClassRecord>::value;
+  static_assert(!(kRecords && kFinal), "records feed the Y pass");
   constexpr int kRing = RingShape<kPacked>::kRing;
   constexpr int kChunk = RingShape<kPacked>::kChunk;
   constexpr int32_t kLimit = C::kSentinelG;  // values at or above: no site
@@ -396,7 +439,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
   const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
-  const InT* const wave_in = in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
+  // (records: [outer][64-voxel segment][row], one per row of this item)
+  const InT* const wave_in = kRecords ? in + static_cast<int64_t>(item) * n
+                                      : in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
   OutT* const wave_out = out + (static_cast<int64_t>(outer) * g.outer_stride + z0);
 
   // ---- stack state.  Entries [0, depth): [0, lo) live in the spill buffer, [lo, depth) in the ring (slot = index
@@ -481,31 +526,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // =====================================================================================================
   uint32_t any_transition = 0;
   {
-    // Rows are loaded through a wave-uniform pointer that steps by the row stride, plus the lane's 32-bit offset: the
-    // address of a row costs two scalar adds and no vector register (the readfirstlane keeps the compiler from folding
-    // the lane offset into a per-lane 64-bit base, which costs a register pair and a 64-bit vector add per row).
-    auto load_band = [&](int32_t (&dst)[kBand], int first_row) {
-      const VGT_GLOBAL InT* row_in = UniformPointer(GlobalPointer(wave_in + static_cast<int64_t>(first_row) * rstride));
-      if (first_row + kBand <= n)
-      {
-#pragma unroll
-        for (int k = 0; k < kBand; k++)
-        {
-          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
-          row_in = UniformPointer(row_in + rstride);
-        }
-      }
-      else
-      {
-        // the last, partial band: rows past the end repeat the last row (not used)
-#pragma unroll
-        for (int k = 0; k < kBand; k++)
-        {
-          dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
-          if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
-        }
-      }
-    };
     // every kChunk rows: the ring must have room for kChunk pushes
     auto check_ring = [&]() {
       // nothing to do while no request is pending, the ring has room and is not about to run dry
@@ -542,79 +562,46 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       }
     };
 
-    int32_t nxt[kBand];
-    load_band(nxt, 0);
     int din = kFar;          // distance from the row below this word to the nearest row of the other class below it
     uint32_t prev_bit = 0;   // class of the row below this word
     uint32_t sw = 0;         // sign bits of the word being swept
     const int32_t n2m = 2 * (n - 1);
-    for (int r0 = 0; r0 < n; r0 += kBand)
-    {
-      __builtin_assume(r0 >= 0 && r0 < 16384);
-      int32_t cur[kBand];
-#pragma unroll
-      for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
-      if (r0 + kBand < n) load_band(nxt, r0 + kBand);
-      uint32_t bits = 0;  // sign bits of this band
-      auto rows = [&](auto guarded) {
-        constexpr bool kGuard = decltype(guarded)::value;
-#pragma unroll
-        for (int k = 0; k < kBand; k++)
+    // a site at row q with cost f (already squared): pops, then the push unless it can never own a row
+    auto site = [&](int q, int32_t f) {
+      const int32_t G = f + q * q;
+      int32_t dG = G - Gt;
+      int dr = q - rt;
+      if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
+      {
+        // (one pop is the common case: it is laid out as straight code, further pops out of line)
+        pop();
+        dG = G - Gt;
+        dr = q - rt;
+        if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
         {
-          if (k % kChunk == 0) check_ring();
-          if (kGuard && r0 + k >= n) bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
-          if (!kGuard || r0 + k < n)
+          do
           {
-            const int q = r0 + k;
-            const int32_t v = cur[k];
-            const int32_t sign = v >> 31;
-            bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
-            // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
-            // sign and magnitude (bit 31 = class), which one `and` takes apart
-            int32_t f = (sizeof(InT) == 2) ? (v ^ sign) - sign : (v & 0x7fffffff);
-            // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
-            if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
-            {
-              if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
-              const int32_t G = f + q * q;
-              int32_t dG = G - Gt;
-              int dr = q - rt;
-              if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
-              {
-                // (one pop is the common case: it is laid out as straight code, further pops out of line)
-                pop();
-                dG = G - Gt;
-                dr = q - rt;
-                if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
-                {
-                  do
-                  {
-                    pop();
-                    dG = G - Gt;
-                    dr = q - rt;
-                  } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
-                }
-              }
-              __builtin_assume(dr > 0 && dr < 16384);
-              if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
-              {
-                VGT_SWEEP_COUNT(13, 1);
-                ring_ref(D) = C::Pack(G, q);
-                e3 = C::Pack(Gt + nB, rt - A);
-                A = dr;
-                nB = -dG;
-                Gt = G;
-                rt = q;
-                D += kSlot;
-              }
-            }
-          }
+            pop();
+            dG = G - Gt;
+            dr = q - rt;
+          } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
         }
-      };
-      if (r0 + kBand <= n)
-        rows(std::false_type{});
-      else
-        rows(std::true_type{});
+      }
+      __builtin_assume(dr >= 0 && dr < 16384);  // (0: a site at row 0 against the row-0 sentinel)
+      if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
+      {
+        VGT_SWEEP_COUNT(13, 1);
+        ring_ref(D) = C::Pack(G, q);
+        e3 = C::Pack(Gt + nB, rt - A);
+        A = dr;
+        nB = -dG;
+        Gt = G;
+        rt = q;
+        D += kSlot;
+      }
+    };
+    // the band [r0, r0 + kBand) has been swept: its sign bits join the word, a complete word goes to the scratch
+    auto band_done = [&](int r0, uint32_t bits) {
       const int sub = r0 & (kWord - 1);
       sw |= (bits >> (32 - kBand)) << sub;
       if (sub + kBand == kWord || r0 + kBand >= n)
@@ -630,6 +617,163 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         din = xdn ? (valid - (31 - __clz(static_cast<int>(xdn)))) : min(din + valid, kFar);
         prev_bit = (sw >> (valid - 1)) & 1u;
         sw = 0;
+      }
+    };
+    if constexpr (kRecords)
+    {
+      // ---- Y pass of the default pipeline: the rows come as class records, one scalar load per row.  A lane's distance
+      // along Z to the other class is the smallest distance across the transitions around it: the two the record names
+      // (nearest below / above the word) and the word's own.  |xq - t2| + 1 is twice that distance for the transition
+      // encoded as t2 on either side (vgt_internal.hpp): one v_sad_u32 per transition, a min3, a shift. ----
+      constexpr int kRows = 4;  // rows per group: records of a group are loaded together, one group ahead
+      static_assert(kBand % kRows == 0 && kChunk % kRows == 0, "sizes");
+      const uint32_t xq = 2u * zl + (kRecordBias - 1u);
+      auto load_group = [&](uint4 (&dst)[kRows], int first_row) {
+        // (a partial last group reads a few records past the line's end: the next line's, or the buffer's padding)
+#pragma unroll
+        for (int k = 0; k < kRows; k++) dst[k] = LoadRecord(wave_in, first_row + k);
+      };
+      auto row = [&](int q, const uint4& rec, uint32_t& bits) {
+        const uint64_t m = (static_cast<uint64_t>(rec.y) << 32) | rec.x;
+        bits = __builtin_amdgcn_alignbit(SpreadLaneMask(m, lane), bits, 1);  // shifted in from the top
+        // the word's own transitions: the first two inline, more (rare) in a loop
+        uint64_t own = (m ^ (m >> 1)) & 0x7fffffffffffffffull;
+        uint32_t t1 = rec.z, t2 = rec.z;
+        if (own)
+        {
+          t1 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
+          own &= own - 1ull;
+        }
+        if (own)
+        {
+          t2 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
+          own &= own - 1ull;
+        }
+        uint32_t f2 = min(min(AbsDiffPlusOne(xq, rec.z), AbsDiffPlusOne(xq, rec.w)),
+                          min(AbsDiffPlusOne(xq, t1), AbsDiffPlusOne(xq, t2)));
+        if (__builtin_expect(own != 0ull, 0))
+        {
+          VGT_COLD_PATH();
+          do
+          {
+            const uint32_t t = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
+            f2 = min(f2, AbsDiffPlusOne(xq, t));
+            own &= own - 1ull;
+          } while (own != 0ull);
+        }
+        if (f2 < 2u * static_cast<uint32_t>(kInf16))
+        {
+          const int32_t f = static_cast<int32_t>(f2 >> 1);
+          site(q, __mul24(f, f));
+        }
+      };
+      // the four rows [q0, q0 + 4) of the band that starts at r0, their records in `cur`; `nxt` receives the next group's
+      // (two buffers that swap roles from group to group: the records stay in the scalar registers they were loaded to)
+      auto group = [&](const uint4 (&cur)[kRows], uint4 (&nxt)[kRows], int q0, bool ring_check, uint32_t& bits) {
+        if (q0 + kRows < n) load_group(nxt, q0 + kRows);
+        if (ring_check) check_ring();
+        // Four rows whose lines hold one class only (marked by pass 1): no lane has a site, and a row's lanes share
+        // their class -- the common case on sparse scenes -- take a handful of scalar instructions and one vector one.
+        if (q0 + kRows <= n && (cur[0].w & cur[1].w & cur[2].w & cur[3].w) == kRecordNoSite)
+        {
+          const uint32_t classes4 = (cur[0].x & 1u) | (cur[1].x & 2u) | (cur[2].x & 4u) | (cur[3].x & 8u);
+          bits = __builtin_amdgcn_alignbit(classes4, bits, kRows);
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < kRows; k++)
+          {
+            if (q0 + k < n)
+              row(q0 + k, cur[k], bits);
+            else
+              bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
+          }
+        }
+      };
+      static_assert((kBand / kRows) % 2 == 0, "the two record buffers swap an even number of times per band");
+      uint4 rec_a[kRows], rec_b[kRows];
+      load_group(rec_a, 0);
+      for (int r0 = 0; r0 < n; r0 += kBand)
+      {
+        __builtin_assume(r0 >= 0 && r0 < 16384);
+        uint32_t bits = 0;  // sign bits of this band
+#pragma unroll
+        for (int k0 = 0; k0 < kBand; k0 += 2 * kRows)
+        {
+          group(rec_a, rec_b, r0 + k0, k0 % kChunk == 0, bits);
+          group(rec_b, rec_a, r0 + k0 + kRows, (k0 + kRows) % kChunk == 0, bits);
+        }
+        band_done(r0, bits);
+      }
+    }
+    else
+    {
+      // Rows are loaded through a wave-uniform pointer that steps by the row stride, plus the lane's 32-bit offset: the
+      // address of a row costs two scalar adds and no vector register (the readfirstlane keeps the compiler from folding
+      // the lane offset into a per-lane 64-bit base, which costs a register pair and a 64-bit vector add per row).
+      auto load_band = [&](int32_t (&dst)[kBand], int first_row) {
+        const VGT_GLOBAL InT* row_in = UniformPointer(GlobalPointer(wave_in + static_cast<int64_t>(first_row) * rstride));
+        if (first_row + kBand <= n)
+        {
+  #pragma unroll
+          for (int k = 0; k < kBand; k++)
+          {
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
+            row_in = UniformPointer(row_in + rstride);
+          }
+        }
+        else
+        {
+          // the last, partial band: rows past the end repeat the last row (not used)
+  #pragma unroll
+          for (int k = 0; k < kBand; k++)
+          {
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
+            if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
+          }
+        }
+      };
+      int32_t nxt[kBand];
+      load_band(nxt, 0);
+      for (int r0 = 0; r0 < n; r0 += kBand)
+      {
+        __builtin_assume(r0 >= 0 && r0 < 16384);
+        int32_t cur[kBand];
+#pragma unroll
+        for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
+        if (r0 + kBand < n) load_band(nxt, r0 + kBand);
+        uint32_t bits = 0;  // sign bits of this band
+        auto rows = [&](auto guarded) {
+          constexpr bool kGuard = decltype(guarded)::value;
+#pragma unroll
+          for (int k = 0; k < kBand; k++)
+          {
+            if (k % kChunk == 0) check_ring();
+            if (kGuard && r0 + k >= n) bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
+            if (!kGuard || r0 + k < n)
+            {
+              const int q = r0 + k;
+              const int32_t v = cur[k];
+              const int32_t sign = v >> 31;
+              bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
+              // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
+              // sign and magnitude (bit 31 = class), which one `and` takes apart
+              int32_t f = (sizeof(InT) == 2) ? (v ^ sign) - sign : (v & 0x7fffffff);
+              // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
+              if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
+              {
+                if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
+                site(q, f);
+              }
+            }
+          }
+        };
+        if (r0 + kBand <= n)
+          rows(std::false_type{});
+        else
+          rows(std::true_type{});
+        band_done(r0, bits);
       }
     }
   }
@@ -1079,6 +1223,15 @@ hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, 
   return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch, nullptr, g, outer_count, MaxInputY(p), stream);
 }
 
+// Y pass of the default pipeline: class records (pass 1, edt_record_kernels.hip) of p.nx slices -> int32.
+hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, void* scratch, const SdfParams& p,
+                                   hipStream_t stream)
+{
+  int64_t outer_count = 0;
+  const SweepGeom g = SweepGeometry(p, 1, &outer_count);
+  return LaunchSweep<ClassRecord, int32_t, false>(records, out32, scratch, nullptr, g, outer_count, MaxInputY(p), stream);
+}
+
 // X pass over the Y positions [outer_begin, outer_begin + outer_count) of the grid (outer_count < 0: all of them):
 // full-grid pointers and extents in `p`.
 hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
@@ -1103,30 +1256,6 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
   return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
 }
 
-// The passes over the Z positions [z_begin, z_begin + z_count) only (full-grid pointers and extents in `p`; z_begin a
-// multiple of 64).  Lines of different Z never interact in the Y and X passes, so an X launch over a Z range depends
-// only on the Y launch over the same range: EdtVariant::kSplit runs the two halves of the grid on two streams, and
-// the tail of one launch overlaps the head of the next.
-hipError_t LaunchPassYSweepZRange(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
-                                  int64_t z_begin, int64_t z_count, hipStream_t stream)
-{
-  int64_t outer_count = 0;
-  SweepGeom g = SweepGeometry(p, 1, &outer_count);
-  g.nz = static_cast<int>(z_count);
-  g.z_offset += static_cast<int>(z_begin);
-  return LaunchSweep<int16_t, int32_t, false>(in16 + z_begin, out32 + z_begin, scratch, nullptr, g, outer_count,
-                                              MaxInputY(p), stream);
-}
-hipError_t LaunchPassXSweepFinalizeZRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
-                                          const SdfParams& p, int64_t z_begin, int64_t z_count, hipStream_t stream)
-{
-  int64_t outer_count = 0;
-  SweepGeom g = SweepGeometry(p, 0, &outer_count);
-  g.nz = static_cast<int>(z_count);
-  g.z_offset += static_cast<int>(z_begin);
-  return LaunchSweep<int32_t, float, true>(in32 + z_begin, sdf + z_begin, scratch, minmax_enc, g, outer_count,
-                                           MaxInputX(p), stream);
-}
 }  // namespace vgt
 
 #ifdef VGT_SWEEP_TIMING

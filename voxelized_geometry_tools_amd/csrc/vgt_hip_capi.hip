@@ -78,11 +78,6 @@ struct vgt_hip_ctx
   std::vector<PooledBuffer> pool;
   size_t pool_bytes = 0;
   bool pool_closed = false;  // set by vgt_hip_destroy: handles destroyed later free their buffers themselves
-  // EdtVariant::kSplit: the second stream, its scratch and the fork / join events
-  hipStream_t split_stream = nullptr;
-  void* split_scratch = nullptr;
-  size_t split_scratch_bytes = 0;
-  hipEvent_t split_fork = nullptr, split_join = nullptr;
   // Copy streams and events of the pipelined host-pointer SDF extraction (SdfFromHostPipelined)
   hipStream_t copy_in = nullptr;
   hipStream_t copy_out = nullptr;
@@ -227,12 +222,12 @@ hipError_t Reserve(void** ptr, size_t* have, size_t need)
 
 void FreeCachedSdfBuffers(vgt_hip_ctx* ctx)
 {
-  for (void** p : {&ctx->sdf_in, &ctx->sdf_out, &ctx->sdf_ws, &ctx->ray_scratch, &ctx->split_scratch})
+  for (void** p : {&ctx->sdf_in, &ctx->sdf_out, &ctx->sdf_ws, &ctx->ray_scratch})
   {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
-  ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = ctx->split_scratch_bytes = 0;
+  ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = 0;
 }
 
 // Page-locks a caller-owned host range for the duration of a call, unless it already is pinned
@@ -307,20 +302,31 @@ private:
 
 struct SdfWorkspace
 {
-  int16_t* t16;
+  vgt::ClassRecord* records;  // pass-1 result of the default pipeline ...
+  int16_t* t16;               // ... or of the cross-check pipelines (one of the two, the other is null)
   int32_t* t32;
   uint32_t* minmax_enc;
   void* sweep_scratch;  // work counter, spilled stack entries and sign words of the line passes
   size_t bytes;
 };
 
-SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, vgt::EdtVariant variant)
 {
   SdfWorkspace ws;
   const size_t n = static_cast<size_t>(nx * ny * nz);
   size_t off = 0;
-  ws.t16 = reinterpret_cast<int16_t*>(static_cast<char*>(base) + off);
-  off = AlignUp(off + n * sizeof(int16_t), 256);
+  ws.records = nullptr;
+  ws.t16 = nullptr;
+  if (variant == vgt::EdtVariant::kDefault)
+  {
+    ws.records = reinterpret_cast<vgt::ClassRecord*>(static_cast<char*>(base) + off);
+    off = AlignUp(off + vgt::ClassRecordBytes(nx, ny, nz), 256);
+  }
+  else
+  {
+    ws.t16 = reinterpret_cast<int16_t*>(static_cast<char*>(base) + off);
+    off = AlignUp(off + n * sizeof(int16_t), 256);
+  }
   ws.t32 = reinterpret_cast<int32_t*>(static_cast<char*>(base) + off);
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
@@ -329,6 +335,36 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz)
   off = AlignUp(off + vgt::SweepPassScratchBytes(nx, ny, nz), 256);
   ws.bytes = off;
   return ws;
+}
+
+// Pass 1 and the Y pass of `slices` X slices that start `first_slice` slices into the grid (the whole grid: 0, p.nx;
+// `p` describes the part: p.nx = slices).  `summary`: per-line slab summaries of the part (multi-GPU) or null.
+template <typename InT>
+hipError_t LaunchPassOne(const InT* input_dev, const SdfWorkspace& ws, const vgt::SdfParams& part, int64_t first_slice,
+                         vgt::SlabLineSummary* summary, hipStream_t s)
+{
+  const int64_t voxel_offset = first_slice * part.ny * part.nz;
+  if (ws.records)
+  {
+    vgt::ClassRecord* records = ws.records + first_slice * vgt::RecordWords(part.nz) * part.ny;
+    if constexpr (std::is_same<InT, float>::value)
+      return vgt::LaunchClassRecordsFromOccupancy(input_dev + voxel_offset, records, part, summary, s);
+    else
+      return vgt::LaunchClassRecordsFromMask(input_dev + voxel_offset, records, part, summary, s);
+  }
+  if constexpr (std::is_same<InT, float>::value)
+    return vgt::LaunchScanZFromOccupancy(input_dev + voxel_offset, ws.t16 + voxel_offset, part, summary, s);
+  else
+    return vgt::LaunchScanZFromMask(input_dev + voxel_offset, ws.t16 + voxel_offset, part, summary, s);
+}
+hipError_t LaunchPassTwo(const SdfWorkspace& ws, const vgt::SdfParams& part, int64_t first_slice, vgt::EdtVariant variant,
+                         hipStream_t s)
+{
+  const int64_t voxel_offset = first_slice * part.ny * part.nz;
+  if (ws.records)
+    return vgt::LaunchPassYSweepRecords(ws.records + first_slice * vgt::RecordWords(part.nz) * part.ny,
+                                        ws.t32 + voxel_offset, ws.sweep_scratch, part, s);
+  return vgt::LaunchPassY(ws.t16 + voxel_offset, ws.t32 + voxel_offset, ws.sweep_scratch, part, variant, s);
 }
 
 int CheckSdfShape(int64_t nx, int64_t ny, int64_t nz, double resolution)
@@ -355,53 +391,17 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
                    void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                    hipEvent_t* events)
 {
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   hipStream_t s = ctx->stream;
   VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
   if (events) VGT_TRY_HIP(hipEventRecord(events[0], s), "event record");
-  if constexpr (std::is_same<InT, float>::value)
-    VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(input_dev, ws.t16, p, nullptr, s), "Z scan");
-  else
-    VGT_TRY_HIP(vgt::LaunchScanZFromMask(input_dev, ws.t16, p, nullptr, s), "Z scan");
+  VGT_TRY_HIP(LaunchPassOne<InT>(input_dev, ws, p, 0, nullptr, s), "pass 1");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
-  const int64_t z_segments = (p.nz + 63) / 64;
-  if (ctx->variant == vgt::EdtVariant::kSplit && z_segments >= 2)
-  {
-    // Prototype: the Y and X passes of the lower and of the upper half of the Z range on two streams.  Nothing orders
-    // the halves against each other: the persistent workgroups of whichever launch is ready fill the wave slots the
-    // others give up, so the tail of one launch runs beside the head of the next.  The upper half has its own scratch.
-    const size_t scratch_bytes = vgt::SweepPassScratchBytes(p.nx, p.ny, p.nz);
-    if (!ctx->split_stream)
-    {
-      VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->split_stream, hipStreamNonBlocking), "create stream");
-      VGT_TRY_HIP(hipEventCreateWithFlags(&ctx->split_fork, hipEventDisableTiming), "create event");
-      VGT_TRY_HIP(hipEventCreateWithFlags(&ctx->split_join, hipEventDisableTiming), "create event");
-    }
-    VGT_TRY_HIP(Reserve(&ctx->split_scratch, &ctx->split_scratch_bytes, scratch_bytes), "allocate second scratch");
-    const int64_t z_mid = z_segments / 2 * 64;
-    hipStream_t s2 = ctx->split_stream;
-    VGT_TRY_HIP(hipEventRecord(ctx->split_fork, s), "event record");
-    VGT_TRY_HIP(hipStreamWaitEvent(s2, ctx->split_fork, 0), "fork");
-    VGT_TRY_HIP(vgt::LaunchPassYSweepZRange(ws.t16, ws.t32, ws.sweep_scratch, p, 0, z_mid, s), "Y pass");
-    VGT_TRY_HIP(vgt::LaunchPassYSweepZRange(ws.t16, ws.t32, ctx->split_scratch, p, z_mid, p.nz - z_mid, s2), "Y pass");
-    if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
-    VGT_TRY_HIP(vgt::LaunchPassXSweepFinalizeZRange(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, 0, z_mid, s),
-                "X pass");
-    VGT_TRY_HIP(vgt::LaunchPassXSweepFinalizeZRange(ws.t32, sdf_dev, ws.minmax_enc, ctx->split_scratch, p, z_mid,
-                                                    p.nz - z_mid, s2),
-                "X pass");
-    VGT_TRY_HIP(hipEventRecord(ctx->split_join, s2), "event record");
-    VGT_TRY_HIP(hipStreamWaitEvent(s, ctx->split_join, 0), "join");
-  }
-  else
-  {
-    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
-    if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
-    VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s),
-                "X pass");
-  }
+  VGT_TRY_HIP(LaunchPassTwo(ws, p, 0, ctx->variant, s), "Y pass");
+  if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
+  VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s), "X pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
   if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
   return VGT_HIP_OK;
@@ -429,7 +429,7 @@ template <typename InT>
 int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, const vgt::SdfParams& p,
                          float* sdf_dev, float* sdf_host)
 {
-  const SdfWorkspace ws = CarveWorkspace(ctx->sdf_ws, p.nx, p.ny, p.nz);
+  const SdfWorkspace ws = CarveWorkspace(ctx->sdf_ws, p.nx, p.ny, p.nz, ctx->variant);
   if (ctx->sdf_ws_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   if (!ctx->copy_in) VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking), "create stream");
   if (!ctx->copy_out) VGT_TRY_HIP(hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking), "create stream");
@@ -463,13 +463,9 @@ int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, c
   {
     vgt::SdfParams part = p;
     part.nx = x_begin(c + 1) - x_begin(c);
-    const int64_t off = x_begin(c) * plane;
     VGT_TRY_HIP(hipStreamWaitEvent(s, uploaded[c], 0), "wait for a chunk of the upload");
-    if constexpr (std::is_same<InT, float>::value)
-      VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
-    else
-      VGT_TRY_HIP(vgt::LaunchScanZFromMask(in_dev + off, ws.t16 + off, part, nullptr, s), "Z scan");
-    VGT_TRY_HIP(vgt::LaunchPassY(ws.t16 + off, ws.t32 + off, ws.sweep_scratch, part, ctx->variant, s), "Y pass");
+    VGT_TRY_HIP(LaunchPassOne<InT>(in_dev, ws, part, x_begin(c), nullptr, s), "pass 1");
+    VGT_TRY_HIP(LaunchPassTwo(ws, part, x_begin(c), ctx->variant, s), "Y pass");
   }
   const size_t pitch = static_cast<size_t>(plane) * sizeof(float);
   for (int c = 0; c < kPipelineChunks; c++)
@@ -498,7 +494,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   if (rc != VGT_HIP_OK) return rc;
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
-  const size_t ws_bytes = vgt_hip_sdf_workspace_bytes(p.nx, p.ny, p.nz);
+  const size_t ws_bytes = CarveWorkspace(nullptr, p.nx, p.ny, p.nz, ctx->variant).bytes;
   const ScopedHostPin pin_in(input_host, nvox * sizeof(InT));
   const ScopedHostPin pin_out(sdf_host, nvox * sizeof(float));
   std::lock_guard<std::mutex> lock(ctx->mutex);
@@ -818,14 +814,6 @@ void vgt_hip_destroy(vgt_hip_ctx* ctx)
   for (hipEvent_t e : ctx->pipeline_events)
     if (e) (void)hipEventDestroy(e);
   ctx->pipeline_events.clear();
-  if (ctx->split_stream)
-  {
-    (void)hipStreamSynchronize(ctx->split_stream);
-    (void)hipStreamDestroy(ctx->split_stream);
-    (void)hipEventDestroy(ctx->split_fork);
-    (void)hipEventDestroy(ctx->split_join);
-    ctx->split_stream = nullptr;
-  }
   if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   ctx->copy_in = nullptr;
@@ -1284,14 +1272,13 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  return CarveWorkspace(nullptr, nx, ny, nz).bytes;
+  return CarveWorkspace(nullptr, nx, ny, nz, vgt::EdtVariant::kDefault).bytes;
 }
 
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
 {
-  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
-  (void)variant;  // every variant runs in the same workspace
-  return CarveWorkspace(nullptr, nx, ny, nz).bytes;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || variant < 0 || variant > 3) return 0;
+  return CarveWorkspace(nullptr, nx, ny, nz, static_cast<vgt::EdtVariant>(variant)).bytes;
 }
 
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host, int64_t nx,
@@ -1405,6 +1392,13 @@ int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, c
               "cell predicate");
   vgt::SdfParams mask_params = p;
   mask_params.unknown_is_filled = 0;
+  // (the workspace was sized for the default pipeline: a cross-check variant set later needs more)
+  const size_t need = CarveWorkspace(nullptr, c->nx, c->ny, c->nz, ctx->variant).bytes;
+  if (need > c->workspace_bytes)
+  {
+    VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "synchronize");
+    VGT_TRY_HIP(Reserve(&c->workspace, &c->workspace_bytes, need), "allocate SDF workspace");
+  }
   return RunSdfPipeline<uint8_t>(ctx, c->mask, mask_params, sdf_dev, c->workspace, c->workspace_bytes,
                                  ctx->minmax_out, nullptr);
 }
@@ -1627,7 +1621,7 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
   if (rc == VGT_HIP_OK) rc = RunCellsSdf(ctx, cells, 2, 0, p, cells->sdf_named);  // cells of named objects only
   if (rc == VGT_HIP_OK)
   {
-    uint32_t* enc = CarveWorkspace(cells->workspace, cells->nx, cells->ny, cells->nz).minmax_enc;
+    uint32_t* enc = CarveWorkspace(cells->workspace, cells->nx, cells->ny, cells->nz, ctx->variant).minmax_enc;
     hipError_t err = vgt::LaunchInitMinMax(enc, ctx->stream);
     if (err == hipSuccess)
       err = vgt::LaunchCombineFreeAndNamed(cells->sdf, cells->sdf_named, n, cells->sdf, enc, ctx->stream);
@@ -1928,7 +1922,7 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   vgt::SdfParams p{nx, ny, nz_local, 1.0, unknown_is_filled ? 1 : 0, 0};
   p.z_offset = z_offset;
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local, ctx->variant);
   if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   StageTimer timer;
   const int trc = timer.Init(kernel_ms != nullptr, 1);
@@ -1937,10 +1931,8 @@ int vgt_hip_sdf_slab_begin_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int
   hipEvent_t* slot = kernel_ms ? nullptr : TimingSlot(ctx);
   VGT_TRY_HIP(timer.Mark(0, ctx->stream), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[0], ctx->stream), "event record");
-  VGT_TRY_HIP(vgt::LaunchScanZFromOccupancy(occupancy_dev, ws.t16, p,
-                                            static_cast<vgt::SlabLineSummary*>(summary_dev),
-                                            ctx->stream),
-              "Z scan");
+  VGT_TRY_HIP(LaunchPassOne<float>(occupancy_dev, ws, p, 0, static_cast<vgt::SlabLineSummary*>(summary_dev), ctx->stream),
+              "pass 1");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[1], ctx->stream), "event record");
   VGT_TRY_HIP(timer.Mark(1, ctx->stream), "event record");
   return timer.Finish(ctx->stream, kernel_ms, 1);
@@ -1993,7 +1985,7 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   vgt::SdfParams p{nx, ny, nz_local, resolution, 0, add_virtual_border ? 1 : 0};
   p.z_offset = z_offset;
   p.nz_global = nz_global;
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local);
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, nx, ny, nz_local, ctx->variant);
   if (workspace_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   StageTimer timer;
   const int trc = timer.Init(kernel_ms != nullptr, 3);
@@ -2004,11 +1996,14 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
   VGT_TRY_HIP(timer.Mark(0, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[4], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
-              "slab fix-up");
+  if (ws.records)
+    VGT_TRY_HIP(vgt::LaunchSlabRecordFixup(ws.records, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
+                "slab fix-up");
+  else
+    VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s), "slab fix-up");
   VGT_TRY_HIP(timer.Mark(1, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[5], s), "event record");
-  VGT_TRY_HIP(vgt::LaunchPassY(ws.t16, ws.t32, ws.sweep_scratch, p, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(LaunchPassTwo(ws, p, 0, ctx->variant, s), "Y pass");
   VGT_TRY_HIP(timer.Mark(2, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[6], s), "event record");
   VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s), "X pass");

@@ -48,6 +48,34 @@ struct SdfParams
   int64_t nz_global = 0;
 };
 
+// Pass 1 of the default pipeline (edt_record_kernels.hip): the binarised grid as CLASS RECORDS, one 16-byte record per
+// 64-voxel word of a Z line, laid out [x][word][y] so that the records a Y-pass wave walks through (one x, one word,
+// every y) are contiguous.  A record holds the classes of its 64 voxels and where the nearest class change outside the
+// word is; the Y pass derives every voxel's distance along Z from it (0.25 B per voxel instead of a 2-byte distance).
+// A class change ("transition") at position t means class(t) != class(t + 1): for every voxel above t (up to the next
+// transition) the nearest voxel of the other class below is t, for every voxel at or below t the nearest one above is t + 1.
+//   mask:    bit k = voxel 64 w + k is filled; bits past the end of the line repeat the line's last voxel
+//   below2:  last transition below the word (t < 64 w), as 2 (t - 64 w) + kRecordBias; kRecordNoneBelow when none
+//   above2:  first transition at or after the word's last voxel (t >= 64 w + 63), same encoding; kRecordNoneAbove when
+//            none; kRecordNoSite when the whole line -- all slabs of it -- holds one class only (below2 is then
+//            kRecordNoneBelow and the word has no transition of its own): no voxel of the word has a distance along Z
+// With xq = 2 lane - 1 + kRecordBias, |xq - t2| + 1 is TWICE the distance from voxel `lane` to the other class across
+// the transition encoded as t2, whichever side it lies on (one v_sad_u32); the "none" encodings give >= 2 kInf16.
+struct ClassRecord
+{
+  uint32_t mask_lo, mask_hi, below2, above2;
+};
+constexpr uint32_t kRecordBias = 1u << 17;
+constexpr uint32_t kRecordNoneBelow = 0u;
+constexpr uint32_t kRecordNoneAbove = 2u * kRecordBias;
+constexpr uint32_t kRecordNoSite = 0xfffffff0u;
+inline int64_t RecordWords(int64_t nz) { return (nz + 63) / 64; }
+// records of a grid (+ one band of padding: the Y pass prefetches a few records past the end of its last line)
+inline size_t ClassRecordBytes(int64_t nx, int64_t ny, int64_t nz)
+{
+  return (static_cast<size_t>(nx) * static_cast<size_t>(RecordWords(nz)) * static_cast<size_t>(ny) + 64) * sizeof(ClassRecord);
+}
+
 // Per-line summary of a Z slab, exchanged between devices: 4 bytes.  A slab's first voxel is filled or free, so of
 // "first filled" and "first free" one is the slab's first voxel; the record keeps the class of the first voxel and the
 // position of the first voxel of the OTHER class (the same for the last voxel):
@@ -74,14 +102,13 @@ struct SlabLineCarry
   int16_t prev_filled, next_filled, prev_free, next_free;
 };
 
-// kDefault: lane-per-line sweep passes, Felzenszwalb-Huttenlocher stacks with their tops in LDS
-// (edt_sweep_kernels.hip; any extent); kBruteForce: pruned outward search straight from HBM; kHull: LDS-tiled
-// lower-envelope passes (band hulls + merge, edt_hull_kernels.hip; axes up to 2048, longer ones fall back to the
-// pruned search).  All exact; 1 and 2 exist for cross-checking.
-// kSplit: the sweep passes of kDefault, launched per half of the Z range on two streams where the entry point drives the
-// whole pipeline itself (vgt_hip_sdf_dev): a measured prototype of overlapping the passes' tails, see DESIGN.md 4.1.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2, kSplit = 3 };
-inline bool IsSweepVariant(EdtVariant v) { return v == EdtVariant::kDefault || v == EdtVariant::kSplit; }
+// kDefault: class records (pass 1, edt_record_kernels.hip) + lane-per-line sweep passes, Felzenszwalb-Huttenlocher
+// stacks with their tops in LDS (edt_sweep_kernels.hip; any extent).  The others exist for cross-checking and share the
+// Z scan to an int16 distance field (edt_kernels.hip): kBruteForce: pruned outward search straight from HBM; kHull:
+// LDS-tiled lower-envelope passes (band hulls + merge, edt_hull_kernels.hip; axes up to 2048, longer ones fall back to
+// the pruned search); kDistanceField: the sweep passes fed by the int16 field (the default of earlier versions).  All exact.
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2, kDistanceField = 3 };
+inline bool IsSweepVariant(EdtVariant v) { return v == EdtVariant::kDefault || v == EdtVariant::kDistanceField; }
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -97,17 +124,24 @@ hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int ra
                              SlabLineCarry* carries, hipStream_t stream);
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream);
+// Pass 1 of the default pipeline (edt_record_kernels.hip): occupancy (float) or mask (u8) -> class records
+// (ClassRecordBytes bytes).  `summary` (optional, multi-GPU) receives one SlabLineSummary per (x, y) line; lines that
+// hold one class are then marked by LaunchSlabRecordFixup, which folds the other slabs' carries into the records.
+hipError_t LaunchClassRecordsFromOccupancy(const float* occupancy, ClassRecord* records, const SdfParams& p,
+                                           SlabLineSummary* summary, hipStream_t stream);
+hipError_t LaunchClassRecordsFromMask(const uint8_t* mask, ClassRecord* records, const SdfParams& p,
+                                      SlabLineSummary* summary, hipStream_t stream);
+hipError_t LaunchSlabRecordFixup(ClassRecord* records, const SlabLineCarry* carries, const SdfParams& p,
+                                 hipStream_t stream);
+// Y pass of the default pipeline: class records -> int32 signed squared distance (edt_sweep_kernels.hip).
+hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, void* scratch, const SdfParams& p,
+                                   hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.
 // `scratch`: SweepPassScratchBytes bytes (part of the SDF workspace).
 hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream);
 // X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
 // order-preserving encoding, must be pre-initialised by InitMinMax).
-// The sweep passes over the Z positions [z_begin, z_begin + z_count) only (edt_sweep_kernels.hip).
-hipError_t LaunchPassYSweepZRange(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
-                                  int64_t z_begin, int64_t z_count, hipStream_t stream);
-hipError_t LaunchPassXSweepFinalizeZRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
-                                          const SdfParams& p, int64_t z_begin, int64_t z_count, hipStream_t stream);
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                void* scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
