@@ -118,7 +118,7 @@ void CheckY(const Case& c, std::mt19937& rng)
 std::vector<vgt::ClassRecord> RecordsOf(const std::vector<uint8_t>& cls, int nx, int ny, int nz, bool mark_no_site)
 {
   const int nwords = static_cast<int>(vgt::RecordWords(nz));
-  std::vector<vgt::ClassRecord> rec(static_cast<size_t>(nx) * nwords * ny + 64);
+  std::vector<vgt::ClassRecord> rec(static_cast<size_t>(nx) * nwords * ny + vgt::kRecordPadding);
   for (auto& r : rec) r = vgt::ClassRecord{0xdeadbeefu, 0xdeadbeefu, 12345u, 54321u};  // (padding: never used)
   for (int x = 0; x < nx; x++)
     for (int y = 0; y < ny; y++)

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_workspace_size(lib):
     assert lib.vgt_hip_abi_version() == 1
-    # class records (16 bytes per 64-voxel word of a Z line, plus 64 records of padding) + the int32 intermediate, a
+    # class records (16 bytes per 64-voxel word of a Z line, plus 256 records of padding) + the int32 intermediate, a
     # small min/max block and the line passes' scratch (8 work counters + per slot: the larger of the spill areas of the
     # two entry kinds -- chunks of 8 x 4-byte or 4 x 8-byte entries per lane -- and one 8-byte word record per 32 rows
     # and lane), 256-byte aligned pieces; the cross-check variants keep an int16 distance field instead of the records
@@ -47,7 +47,7 @@ def test_abi_version_and_workspace_size(lib):
     narrow = ((64 + 4 + 7) // 8 + 1) * 64 * 8 * 4
     wide = ((64 + 4 + 3) // 4 + 1) * 64 * 4 * 8
     scratch = 1024 + slots * (max(narrow, wide) + words * 64 * 8) + 256
-    records = (64 * 1 * 64 + 64) * 16
+    records = (64 * 1 * 64 + 256) * 16
     assert capi.sdf_workspace_bytes((64, 64, 64)) == records + n * 4 + 256 + scratch
     for variant in (1, 2, 3):
         assert capi.sdf_workspace_bytes((64, 64, 64), variant) == n * 2 + n * 4 + 256 + scratch

@@ -17,6 +17,9 @@
 // Lines longer than 4096 voxels take a slower one-line-per-wave path with the same result.
 #include "edt_device.hpp"
 
+#ifndef VGT_REC_EXP
+#define VGT_REC_EXP 0
+#endif
 namespace vgt
 {
 namespace
@@ -41,7 +44,9 @@ __device__ __forceinline__ bool IsFilledCell(uint8_t mask)
 // value[lane `target`] = a wave-uniform word (v_writelane_b32 with a constant lane; this compiler has no builtin for it)
 __device__ __forceinline__ void WriteLane(uint32_t& value, uint32_t word_uniform, int target)
 {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(value) : "s"(word_uniform), "n"(target));
+  // (the word comes straight from a vector compare: the wait states between a vector instruction's scalar result and
+  // its use by another vector instruction are the compiler's job everywhere else, inside an asm statement they are ours)
+  asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(value) : "s"(word_uniform), "n"(target));
 }
 
 __device__ __forceinline__ uint32_t EncodeBelow(int t, int word_begin)
@@ -89,7 +94,11 @@ __global__ __launch_bounds__(kRecordBlock) void ClassRecordKernel(const InT* __r
       for (int c = 0; c < W; c++)
       {
         const int z = min(min(c, nwords - 1) * kWaveSize + lane, nz - 1);
+#if VGT_REC_EXP & 2
+        v[jj][c] = line_in[z];
+#else
         v[jj][c] = __builtin_nontemporal_load(line_in + z);
+#endif
       }
     }
     // ---- votes: word (jj, c) goes to lane jj * W + c ----
@@ -155,6 +164,9 @@ __global__ __launch_bounds__(kRecordBlock) void ClassRecordKernel(const InT* __r
       raw.y = r.mask_hi;
       raw.z = r.below2;
       raw.w = r.above2;
+#if VGT_REC_EXP & 1
+      if (raw.x == 0x12345u)
+#endif
       *reinterpret_cast<Raw*>(records + ((x * nwords + w) * ny + y)) = raw;
     }
     if (summary)

@@ -626,10 +626,26 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       // (nearest below / above the word) and the word's own.  |xq - t2| + 1 is twice that distance for the transition
       // encoded as t2 on either side (vgt_internal.hpp): one v_sad_u32 per transition, a min3, a shift. ----
       constexpr int kRows = 4;  // rows per group: records of a group are loaded together, one group ahead
+      // Rows without a site go by in a few nanoseconds, far faster than a record arrives from memory, and a scalar load
+      // cannot be left in flight across the next wait.  So the wave also reads the records as plain vector loads, 64 rows
+      // (1 KiB) at a time and kTouchAhead rows ahead of the row at work, and does nothing with them but fold them into
+      // a word nobody looks at: that brings the lines into L2, where the scalar loads find them.
+      constexpr int kTouchRows = 64, kTouchAhead = 128;
+      static_assert(kTouchRows % kBand == 0 && kTouchAhead % kTouchRows == 0, "sizes");
+      [[maybe_unused]] uint4 ahead = make_uint4(0u, 0u, 0u, 0u);
+      [[maybe_unused]] uint32_t folded = 0;
+      [[maybe_unused]] auto touch = [&](int first_row) {
+#ifndef VGT_HOST_EMULATION
+        folded ^= ahead.x ^ ahead.y ^ ahead.z ^ ahead.w;
+        using Raw = uint32_t __attribute__((ext_vector_type(4)));
+        const Raw r = *(reinterpret_cast<const Raw*>(wave_in + first_row) + lane);
+        ahead = make_uint4(r.x, r.y, r.z, r.w);
+#endif
+      };
       static_assert(kBand % kRows == 0 && kChunk % kRows == 0, "sizes");
       const uint32_t xq = 2u * zl + (kRecordBias - 1u);
       auto load_group = [&](uint4 (&dst)[kRows], int first_row) {
-        // (a partial last group reads a few records past the line's end: the next line's, or the buffer's padding)
+        // (the groups at and after the line's end read a few records past it: the next line's, or the buffer's padding)
 #pragma unroll
         for (int k = 0; k < kRows; k++) dst[k] = LoadRecord(wave_in, first_row + k);
       };
@@ -670,11 +686,19 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       // the four rows [q0, q0 + 4) of the band that starts at r0, their records in `cur`; `nxt` receives the next group's
       // (two buffers that swap roles from group to group: the records stay in the scalar registers they were loaded to)
       auto group = [&](const uint4 (&cur)[kRows], uint4 (&nxt)[kRows], int q0, bool ring_check, uint32_t& bits) {
-        if (q0 + kRows < n) load_group(nxt, q0 + kRows);
+        // Scalar loads return out of order, so a wait for this group's records is a wait for every scalar load in
+        // flight: the first look at the records comes BEFORE the next group's load is issued (the empty asm ties the
+        // load's address to that look, or the compiler would hoist the load), which then has the whole group to land.
+        const uint32_t marks = cur[0].w & cur[1].w & cur[2].w & cur[3].w;
+        int next_first = q0 + kRows;
+#ifndef VGT_HOST_EMULATION
+        asm volatile("" : "+s"(next_first) : "s"(marks));
+#endif
+        load_group(nxt, next_first);  // (unconditional: past the last row it reads padding, see load_group)
         if (ring_check) check_ring();
         // Four rows whose lines hold one class only (marked by pass 1): no lane has a site, and a row's lanes share
         // their class -- the common case on sparse scenes -- take a handful of scalar instructions and one vector one.
-        if (q0 + kRows <= n && (cur[0].w & cur[1].w & cur[2].w & cur[3].w) == kRecordNoSite)
+        if (q0 + kRows <= n && marks == kRecordNoSite)
         {
           const uint32_t classes4 = (cur[0].x & 1u) | (cur[1].x & 2u) | (cur[2].x & 4u) | (cur[3].x & 8u);
           bits = __builtin_amdgcn_alignbit(classes4, bits, kRows);
@@ -692,11 +716,14 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         }
       };
       static_assert((kBand / kRows) % 2 == 0, "the two record buffers swap an even number of times per band");
+      static_assert(kTouchAhead + kTouchRows <= kRecordPadding, "reads past the end stay inside the padding");
       uint4 rec_a[kRows], rec_b[kRows];
       load_group(rec_a, 0);
+      touch(kTouchRows);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
+        if ((r0 & (kTouchRows - 1)) == 0) touch(r0 + kTouchAhead);
         uint32_t bits = 0;  // sign bits of this band
 #pragma unroll
         for (int k0 = 0; k0 < kBand; k0 += 2 * kRows)
@@ -706,6 +733,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         }
         band_done(r0, bits);
       }
+#ifndef VGT_HOST_EMULATION
+      asm volatile("" : : "v"(folded ^ ahead.x ^ ahead.y ^ ahead.z ^ ahead.w));
+#endif
     }
     else
     {

@@ -70,10 +70,12 @@ constexpr uint32_t kRecordNoneBelow = 0u;
 constexpr uint32_t kRecordNoneAbove = 2u * kRecordBias;
 constexpr uint32_t kRecordNoSite = 0xfffffff0u;
 inline int64_t RecordWords(int64_t nz) { return (nz + 63) / 64; }
-// records of a grid (+ one band of padding: the Y pass prefetches a few records past the end of its last line)
+// records of a grid (+ padding: the Y pass fetches records up to 136 rows past the end of the line it works on)
+constexpr int kRecordPadding = 256;
 inline size_t ClassRecordBytes(int64_t nx, int64_t ny, int64_t nz)
 {
-  return (static_cast<size_t>(nx) * static_cast<size_t>(RecordWords(nz)) * static_cast<size_t>(ny) + 64) * sizeof(ClassRecord);
+  return (static_cast<size_t>(nx) * static_cast<size_t>(RecordWords(nz)) * static_cast<size_t>(ny) + kRecordPadding) *
+         sizeof(ClassRecord);
 }
 
 // Per-line summary of a Z slab, exchanged between devices: 4 bytes.  A slab's first voxel is filled or free, so of
