@@ -283,22 +283,6 @@ __device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t
   return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) + PinnedOffset(byte_offset));
 }
 
-// A class record (vgt_internal.hpp) through a wave-uniform address: a scalar load (s_load_dwordx4; neighbouring rows merge
-// into wider ones), the record lands in scalar registers.  The records were written by an earlier kernel, so the constant
-// address space is safe.
-__device__ __forceinline__ uint4 LoadRecord(const ClassRecord* base, int index)
-{
-#ifdef VGT_HOST_EMULATION
-  const ClassRecord r = base[index];
-  return make_uint4(r.mask_lo, r.mask_hi, r.below2, r.above2);
-#else
-  using Raw = uint32_t __attribute__((ext_vector_type(4)));
-  using ConstRaw = const __attribute__((address_space(4))) Raw;
-  ConstRaw* p = reinterpret_cast<ConstRaw*>(reinterpret_cast<uint64_t>(base));
-  const Raw r = p[index];
-  return make_uint4(r.x, r.y, r.z, r.w);
-#endif
-}
 // |a - b| + 1 with b the same in every lane: one v_sad_u32 with a scalar operand.
 __device__ __forceinline__ uint32_t AbsDiffPlusOne(uint32_t a, uint32_t b_uniform)
 {
@@ -625,29 +609,50 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       // along Z to the other class is the smallest distance across the transitions around it: the two the record names
       // (nearest below / above the word) and the word's own.  |xq - t2| + 1 is twice that distance for the transition
       // encoded as t2 on either side (vgt_internal.hpp): one v_sad_u32 per transition, a min3, a shift. ----
-      constexpr int kRows = 4;  // rows per group: records of a group are loaded together, one group ahead
-      // Rows without a site go by in a few nanoseconds, far faster than a record arrives from memory, and a scalar load
-      // cannot be left in flight across the next wait.  So the wave also reads the records as plain vector loads, 64 rows
-      // (1 KiB) at a time and kTouchAhead rows ahead of the row at work, and does nothing with them but fold them into
-      // a word nobody looks at: that brings the lines into L2, where the scalar loads find them.
-      constexpr int kTouchRows = 64, kTouchAhead = 128;
-      static_assert(kTouchRows % kBand == 0 && kTouchAhead % kTouchRows == 0, "sizes");
-      [[maybe_unused]] uint4 ahead = make_uint4(0u, 0u, 0u, 0u);
-      [[maybe_unused]] uint32_t folded = 0;
-      [[maybe_unused]] auto touch = [&](int first_row) {
-#ifndef VGT_HOST_EMULATION
-        folded ^= ahead.x ^ ahead.y ^ ahead.z ^ ahead.w;
+      // The records of 64 rows are ONE vector load (16 bytes per lane: lane l holds the record of row b + l), two blocks
+      // ahead of the block at work, so nothing of the record stream is ever waited for and the scalar unit's loads --
+      // which can only be waited for all at once, together with the LDS -- stay out of the loop.  A block's "no voxel
+      // of these 64 has a site" marks and, for those rows, classes are two votes; a row that does have sites gets its
+      // record into scalar registers with four v_readlane.
+      constexpr int kRows = 4;     // rows per group: the unit of the "no site" short cut inside a band
+      constexpr int kBlock = 64;   // rows per record block
+      static_assert(kBand % kRows == 0 && kChunk % kRows == 0 && kBlock % kBand == 0, "sizes");
+      static_assert(3 * kBlock <= kRecordPadding, "reads past the end stay inside the padding");
+      const uint32_t xq = 2u * zl + (kRecordBias - 1u);
+      [[maybe_unused]] auto load_block = [&](int first_row) -> uint4 {
+#ifdef VGT_HOST_EMULATION
+        return make_uint4(0u, 0u, 0u, 0u);
+#else
         using Raw = uint32_t __attribute__((ext_vector_type(4)));
         const Raw r = *(reinterpret_cast<const Raw*>(wave_in + first_row) + lane);
-        ahead = make_uint4(r.x, r.y, r.z, r.w);
+        return make_uint4(r.x, r.y, r.z, r.w);
 #endif
       };
-      static_assert(kBand % kRows == 0 && kChunk % kRows == 0, "sizes");
-      const uint32_t xq = 2u * zl + (kRecordBias - 1u);
-      auto load_group = [&](uint4 (&dst)[kRows], int first_row) {
-        // (the groups at and after the line's end read a few records past it: the next line's, or the buffer's padding)
-#pragma unroll
-        for (int k = 0; k < kRows; k++) dst[k] = LoadRecord(wave_in, first_row + k);
+      // bit l: row first_row + l of the block carries the one-class mark / is of the filled class (meaningful with the mark)
+      auto block_marks = [&]([[maybe_unused]] const uint4& blk, [[maybe_unused]] int first_row, uint64_t& marks,
+                             uint64_t& filled) {
+#ifdef VGT_HOST_EMULATION
+        marks = filled = 0;
+        for (int l = 0; l < kBlock; l++)
+        {
+          // (rows past the line's end: whatever the padding holds, never used)
+          const ClassRecord r = wave_in[first_row + l];
+          if (r.above2 == kRecordNoSite) marks |= 1ull << l;
+          if (r.mask_lo & 1u) filled |= 1ull << l;
+        }
+#else
+        marks = __builtin_amdgcn_ballot_w64(blk.w == kRecordNoSite);
+        filled = __builtin_amdgcn_ballot_w64((blk.x & 1u) != 0u);
+#endif
+      };
+      auto record_of = [&]([[maybe_unused]] const uint4& blk, [[maybe_unused]] int first_row, int index) -> uint4 {
+#ifdef VGT_HOST_EMULATION
+        const ClassRecord r = wave_in[first_row + index];
+        return make_uint4(r.mask_lo, r.mask_hi, r.below2, r.above2);
+#else
+        return make_uint4(__builtin_amdgcn_readlane(blk.x, index), __builtin_amdgcn_readlane(blk.y, index),
+                          __builtin_amdgcn_readlane(blk.z, index), __builtin_amdgcn_readlane(blk.w, index));
+#endif
       };
       auto row = [&](int q, const uint4& rec, uint32_t& bits) {
         const uint64_t m = (static_cast<uint64_t>(rec.y) << 32) | rec.x;
@@ -683,59 +688,58 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           site(q, __mul24(f, f));
         }
       };
-      // the four rows [q0, q0 + 4) of the band that starts at r0, their records in `cur`; `nxt` receives the next group's
-      // (two buffers that swap roles from group to group: the records stay in the scalar registers they were loaded to)
-      auto group = [&](const uint4 (&cur)[kRows], uint4 (&nxt)[kRows], int q0, bool ring_check, uint32_t& bits) {
-        // Scalar loads return out of order, so a wait for this group's records is a wait for every scalar load in
-        // flight: the first look at the records comes BEFORE the next group's load is issued (the empty asm ties the
-        // load's address to that look, or the compiler would hoist the load), which then has the whole group to land.
-        const uint32_t marks = cur[0].w & cur[1].w & cur[2].w & cur[3].w;
-        int next_first = q0 + kRows;
-#ifndef VGT_HOST_EMULATION
-        asm volatile("" : "+s"(next_first) : "s"(marks));
-#endif
-        load_group(nxt, next_first);  // (unconditional: past the last row it reads padding, see load_group)
-        if (ring_check) check_ring();
-        // Four rows whose lines hold one class only (marked by pass 1): no lane has a site, and a row's lanes share
-        // their class -- the common case on sparse scenes -- take a handful of scalar instructions and one vector one.
-        if (q0 + kRows <= n && marks == kRecordNoSite)
-        {
-          const uint32_t classes4 = (cur[0].x & 1u) | (cur[1].x & 2u) | (cur[2].x & 4u) | (cur[3].x & 8u);
-          bits = __builtin_amdgcn_alignbit(classes4, bits, kRows);
-        }
-        else
-        {
-#pragma unroll
-          for (int k = 0; k < kRows; k++)
-          {
-            if (q0 + k < n)
-              row(q0 + k, cur[k], bits);
-            else
-              bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
-          }
-        }
-      };
-      static_assert((kBand / kRows) % 2 == 0, "the two record buffers swap an even number of times per band");
-      static_assert(kTouchAhead + kTouchRows <= kRecordPadding, "reads past the end stay inside the padding");
-      uint4 rec_a[kRows], rec_b[kRows];
-      load_group(rec_a, 0);
-      touch(kTouchRows);
+      uint4 blk0 = load_block(0), blk1 = load_block(kBlock), blk2 = load_block(2 * kBlock);
+      uint64_t marks = 0, filled = 0;
+      constexpr uint32_t kBandMask = kBand >= 32 ? ~0u : ((1u << (kBand % 32)) - 1u);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
-        if ((r0 & (kTouchRows - 1)) == 0) touch(r0 + kTouchAhead);
-        uint32_t bits = 0;  // sign bits of this band
-#pragma unroll
-        for (int k0 = 0; k0 < kBand; k0 += 2 * kRows)
+        const int in_block = r0 & (kBlock - 1);
+        const int block_first = r0 - in_block;
+        if (in_block == 0)
         {
-          group(rec_a, rec_b, r0 + k0, k0 % kChunk == 0, bits);
-          group(rec_b, rec_a, r0 + k0 + kRows, (k0 + kRows) % kChunk == 0, bits);
+          if (r0 != 0)
+          {
+            blk0 = blk1;
+            blk1 = blk2;
+            blk2 = load_block(r0 + 2 * kBlock);
+          }
+          block_marks(blk0, r0, marks, filled);
+        }
+        const uint32_t band_marks = static_cast<uint32_t>(marks >> in_block) & kBandMask;
+        const uint32_t band_filled = static_cast<uint32_t>(filled >> in_block) & kBandMask;
+        uint32_t bits;  // sign bits of this band, in the top kBand bits
+        if (band_marks == kBandMask && r0 + kBand <= n)
+        {
+          // A band whose lines hold one class only (marked by pass 1): no lane has a site and a row's lanes share their
+          // class -- most bands of a sparse scene -- costs a few scalar instructions.
+          bits = band_filled << (32 - kBand);
+        }
+        else
+        {
+          bits = 0;
+#pragma unroll
+          for (int k0 = 0; k0 < kBand; k0 += kRows)
+          {
+            const int q0 = r0 + k0;
+            if (k0 % kChunk == 0) check_ring();
+            if (((band_marks >> k0) & 0xfu) == 0xfu && q0 + kRows <= n)
+              bits = __builtin_amdgcn_alignbit((band_filled >> k0) & 0xfu, bits, kRows);
+            else
+            {
+#pragma unroll
+              for (int k = 0; k < kRows; k++)
+              {
+                if (q0 + k < n)
+                  row(q0 + k, record_of(blk0, block_first, in_block + k0 + k), bits);
+                else
+                  bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
+              }
+            }
+          }
         }
         band_done(r0, bits);
       }
-#ifndef VGT_HOST_EMULATION
-      asm volatile("" : : "v"(folded ^ ahead.x ^ ahead.y ^ ahead.z ^ ahead.w));
-#endif
     }
     else
     {
