@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL_PASS = 8.0  # 3 passes x (4 B read + 4 B write) = 24 B/voxel
-KERNEL_NAMES = ["ScanZ", "PassY", "PassXFinalize"]
+KERNEL_NAMES = ["PassZClassRecords", "PassY", "PassXFinalize"]  # (variants 1-3: pass 1 is the int16 Z scan)
 
 
 def parse_args():
@@ -45,13 +45,14 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="cube edge instead of the workload's shape (experiments)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
-    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2 cross-check implementations; 3 split-launch prototype)")
+    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2, 3 cross-check implementations; 3 = the int16 distance field + sweeps of round 3)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--no-raycast", action="store_true", help="skip the raycast voxelizer section (BASELINE config 3)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary SDF workloads (salt, unknown mix, 512^3, 64^3)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -303,6 +304,53 @@ def multi_host_path(torch, shape, res):
                     "whole call from pageable host arrays (page-locked per call), device state kept from the first call"}
 
 
+def secondary_workloads(ctx, torch, capi, device, res, steps=3, warmup=1):
+    """SURVEY 8d's secondary numbers in the driver-run line: the other distributions at the headline size and D1 at the
+    smaller sizes, device-resident like the headline, `steps` timed steps each OUTSIDE the headline's timed region.
+    ms = wall clock per step around the timed steps (fence on both sides); kernel_ms / whole_sdf_frac from the library's
+    kernel events (24 B/voxel credited, as for the headline)."""
+    out = {}
+    cases = [("1024^3 D2 salt p=0.01", (1024,) * 3, "salt"), ("1024^3 D3 unknown mix", (1024,) * 3, "unknown_mix"),
+             ("512^3 D1 spheres", (512,) * 3, "spheres"), ("64^3 D1 spheres", (64,) * 3, "spheres")]
+    for name, shape, dist_name in cases:
+        try:
+            occ = device_occupancy(torch, shape, dist_name, 42, device)
+            sdf = torch.empty(shape, dtype=torch.float32, device=device)
+            ws_bytes = capi.sdf_workspace_bytes(shape, 0)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            minmax = torch.zeros(2, dtype=torch.float32, device=device)
+
+            def step():
+                ctx.sdf_dev(occ.data_ptr(), shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes, minmax.data_ptr())
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            ctx.timing_start(steps)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            wall_ms = (time.perf_counter() - t0) / steps * 1e3
+            per_step = ctx.timing_stop().astype(np.float64)
+            avg = per_step.mean(axis=0) if len(per_step) else np.zeros(3)
+            vox = float(np.prod(shape))
+            dom = int(np.argmax(avg))
+            out[name] = {
+                "ms": round(wall_ms, 4), "Mvoxels_per_s": round(vox / (wall_ms * 1e-3) / 1e6, 1),
+                "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNEL_NAMES, avg)},
+                "whole_sdf_frac": round(3 * ALG_BYTES_PER_VOXEL_PASS * vox / (avg.sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                if avg.sum() > 0 else None,
+                "whole_sdf_frac_wall_clock": round(3 * ALG_BYTES_PER_VOXEL_PASS * vox / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "dominant_kernel": KERNEL_NAMES[dom],
+                "dominant_frac": round(ALG_BYTES_PER_VOXEL_PASS * vox / (avg[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                if avg[dom] > 0 else None}
+            del occ, sdf, ws, minmax
+        except Exception as exc:
+            out[name] = {"error": repr(exc)}
+    return out
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: run this script under torch.distributed.run with N ranks.
     Nothing in this (parent) process has initialised the GPU; the child is a subprocess, not an exec."""
@@ -476,6 +524,12 @@ def main():
                                 "bytes_received_per_rank": runner.exchange_bytes_received}
             if not args.size:
                 line["same_workload_one_gpu"] = one_gpu_reference(workload_key)
+        if headline and not args.no_secondary:
+            del occ, sdf, ws  # (8 + 7.4 GB: the secondary workloads allocate their own)
+            occ = sdf = ws = None
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_workloads(ctx, torch, capi, device, res)
+            occ = device_occupancy(torch, local_shape, args.dist, 42, device, z_offset, full_shape, args.salt_p)
         if headline and not args.no_raycast:
             try:
                 line["raycast"] = raycast_section()

@@ -283,16 +283,12 @@ __device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t
   return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) + PinnedOffset(byte_offset));
 }
 
-// |a - b| + 1 with b the same in every lane: one v_sad_u32 with a scalar operand.
+// |a - b| + 1 with b the same in every lane.  Written so that the compiler selects ONE v_sad_u32 with a scalar operand
+// (max - min + c is its pattern for that instruction) and, unlike with an asm statement, keeps the wait states between a
+// vector instruction that writes a scalar register (v_readlane) and a vector instruction that reads it.
 __device__ __forceinline__ uint32_t AbsDiffPlusOne(uint32_t a, uint32_t b_uniform)
 {
-#ifdef VGT_HOST_EMULATION
-  return (a > b_uniform ? a - b_uniform : b_uniform - a) + 1u;
-#else
-  uint32_t d;
-  asm("v_sad_u32 %0, %1, %2, 1" : "=v"(d) : "v"(a), "s"(b_uniform));
-  return d;
-#endif
+  return (max(a, b_uniform) - min(a, b_uniform)) + 1u;
 }
 // all ones in the lanes whose bit of a wave-uniform 64-bit mask is set, else zero: one v_cndmask with the mask as the
 // condition (a scalar register pair)
@@ -301,9 +297,7 @@ __device__ __forceinline__ uint32_t SpreadLaneMask(uint64_t mask_uniform, [[mayb
 #ifdef VGT_HOST_EMULATION
   return ((mask_uniform >> lane) & 1ull) ? ~0u : 0u;
 #else
-  uint32_t d;
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(mask_uniform));
-  return d;
+  return __builtin_amdgcn_inverse_ballot_w64(mask_uniform) ? ~0u : 0u;
 #endif
 }
 
@@ -550,30 +544,34 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     uint32_t prev_bit = 0;   // class of the row below this word
     uint32_t sw = 0;         // sign bits of the word being swept
     const int32_t n2m = 2 * (n - 1);
-    // a site at row q with cost f (already squared): pops, then the push unless it can never own a row
+    // A site at row q with cost f (already squared).  It is pushed when it beats the top before the last row
+    // (G - Gt < 2 (n - 1) (q - rt)); a site that does not cannot pop the top either (the top beat ITS predecessor before
+    // the last row when it was pushed, so its interval ends before the new site's would begin), and a site that pops
+    // the top beats the entry below it even earlier: the one comparison against the top decides the push, and the pop
+    // tests -- two 64-bit multiply-adds and a 64-bit compare each -- are only paid by sites that will be pushed.
     auto site = [&](int q, int32_t f) {
       const int32_t G = f + q * q;
       int32_t dG = G - Gt;
       int dr = q - rt;
-      if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
-      {
-        // (one pop is the common case: it is laid out as straight code, further pops out of line)
-        pop();
-        dG = G - Gt;
-        dr = q - rt;
-        if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
-        {
-          do
-          {
-            pop();
-            dG = G - Gt;
-            dr = q - rt;
-          } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
-        }
-      }
       __builtin_assume(dr >= 0 && dr < 16384);  // (0: a site at row 0 against the row-0 sentinel)
       if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
       {
+        if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
+        {
+          // (one pop is the common case: it is laid out as straight code, further pops out of line)
+          pop();
+          dG = G - Gt;
+          dr = q - rt;
+          if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
+          {
+            do
+            {
+              pop();
+              dG = G - Gt;
+              dr = q - rt;
+            } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
+          }
+        }
         VGT_SWEEP_COUNT(13, 1);
         ring_ref(D) = C::Pack(G, q);
         e3 = C::Pack(Gt + nB, rt - A);
