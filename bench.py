@@ -426,7 +426,8 @@ def main():
     ws_bytes = capi.sdf_workspace_bytes(local_shape, args.variant)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     minmax = torch.zeros(2, dtype=torch.float32, device=device)
-    ctx = capi.Context(local_rank)
+    # (the cross-check variants exist in the testing library only; the headline runs the product library)
+    ctx = capi.Context(local_rank, testing=args.variant != 0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_edt_variant(args.variant)
     if dist_on:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VGT_HIP_ABI_VERSION 1
+#define VGT_HIP_ABI_VERSION 2
 
 typedef struct vgt_hip_ctx vgt_hip_ctx;       /* one context <-> one device + one stream */
 typedef struct vgt_hip_grids vgt_hip_grids;   /* tracking grids (TrackingGridsHandle)    */
@@ -189,10 +189,12 @@ int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, 
  * in HBM, the caller provides the scratch workspace.  minmax_dev, if non-NULL, receives
  * {min, max} as two floats on the device after the call (stream-ordered). */
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
-/* As above for a context set to EDT variant `variant` (kept for callers of earlier versions: every variant runs in
- * the workspace of vgt_hip_sdf_workspace_bytes).  The workspace holds the two intermediate fields (2 + 4 bytes per
- * voxel) and the line passes' scratch, which grows with the axis lengths, not with the volume (the spilled stack
- * entries and sign words of the at most 5120 waves in flight: 2.8 GB for a 1024^3 grid, 5.5 GB at 2048 x 2048 x 1024). */
+/* As above for a context set to EDT variant `variant` (0 = the default pipeline = vgt_hip_sdf_workspace_bytes; the
+ * cross-check variants 1-3 exist in testing builds only, the product library returns 0 for them).  The default
+ * workspace holds the class records of pass 1 (0.25 bytes per voxel), the int32 intermediate field (4 bytes per voxel)
+ * and the line passes' scratch, which grows with the axis lengths, not with the volume (the spilled stack entries and
+ * sign words of the at most 4096 waves in flight: 1.1 GB for a 1024^3 grid, 4.4 GB at 2048 x 2048 x 1024; the launches
+ * use as many workgroups as the scratch they are given holds).  5.7 GB in all at 1024^3. */
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant);
 int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                     int64_t nz, double resolution, int unknown_is_filled,
@@ -204,19 +206,25 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
-/* Selects the EDT line-pass implementation (all exact; testing / cross-check knob):
- * 0 = default (lane-per-line sweeps: one lane runs the Felzenszwalb-Huttenlocher stack of one line, stack tops in
- * LDS, any extent), 1 = pruned outward search from HBM (any size), 2 = LDS-tiled lower envelope (band hulls + merge;
- * axes up to 2048, longer ones take the pruned search), 3 = the sweeps of 0 launched per half of the Z range on two
- * streams in vgt_hip_sdf_dev (a measured prototype; the other entry points treat it as 0). */
+#ifdef VGT_HIP_TESTING
+/* ---- Testing builds only: libvgt_hip_testing.so (make -C voxelized_geometry_tools_amd/csrc testing), which the parity
+ * tests load next to the product library.  The product library exports none of these and contains none of the
+ * cross-check implementations. ----
+ * Selects the EDT pipeline (all exact): 0 = default (pass 1 writes class records, lane-per-line sweeps: one lane runs
+ * the Felzenszwalb-Huttenlocher stack of one line, stack tops in LDS, any extent); the others share an int16 distance
+ * field along Z as pass 1: 1 = pruned outward search from HBM (any size), 2 = LDS-tiled lower envelope (band hulls +
+ * merge; axes up to 2048, longer ones take the pruned search), 3 = the sweeps of 0 fed by the int16 field. */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
-/* Diagnostic: the final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation
- * with an exact fallback (csrc/edt_device.hpp); this runs both over d2 in
- * [first_d2, first_d2 + count) on the device and reports how many results differ (must be 0)
- * and the first differing d2 (UINT64_MAX if none). */
+/* The final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation with an exact fallback
+ * (csrc/edt_device.hpp); this runs both over d2 in [first_d2, first_d2 + count) on the device and reports how many
+ * results differ (must be 0) and the first differing d2 (UINT64_MAX if none). */
 int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t count,
                                  double resolution, uint64_t* mismatches,
                                  uint64_t* first_mismatch);
+/* Smallest grid (voxels) that the host-pointer SDF entry points pipeline (upload / kernels / download overlapped);
+ * default 2^27, negative = never.  Lets the tests run that path on small grids. */
+int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels);
+#endif /* VGT_HIP_TESTING */
 
 /* ---- SDFs of the map types whose cells carry more than an occupancy ----
  * Replaces the per-voxel `is_filled_fn` + EDT of
@@ -337,7 +345,10 @@ int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, in
  *      (4 x int16: prev_filled, next_filled, prev_free, next_free as global z, -1 when absent)
  *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
  * The slabs must be the ranges of vgt_hip_sdf_slab_range (equal shares of nz_global, earlier slabs take the
- * remainder): the carries are decoded with them.
+ * remainder): the carries are decoded with them, and vgt_hip_sdf_slab_finish_dev rejects carries that
+ * vgt_hip_sdf_slab_carries_dev computed for another (z_offset, nz_local, nz_global) than the one it is given
+ * (VGT_HIP_ERR_INVALID_ARGUMENT; ABI version 2.  Version 1 exchanged 8-byte records with absolute positions and
+ * accepted any partition).
  * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
  * in both calls.  kernel_ms (optional): begin -> [scan]; finish -> [fix-up, Y pass, X pass];
  * when given, the call blocks until the work has finished.
@@ -393,7 +404,7 @@ int vgt_hipx_last_timing(float* ms5);
  *      bit, whatever the split; counts already in the grid are kept.  Blocking; the sum is ordered on ctx's
  *      stream, so the filter that follows sees it.  Helper contexts and grids are kept for the next call with
  *      the same (device, helper list, cell count); vgt_hipx_release frees them.  num_helpers = 0 is the plain call. */
-void vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count);
+int vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count);
 int vgt_hipx_raycast_points_split(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,
                                   const int* helper_devices, int num_helpers, const float* points_xyz_host,
                                   int64_t num_points, float max_range, const float* grid_pointcloud_transform,

@@ -82,7 +82,7 @@ void CheckY(const Case& c, std::mt19937& rng)
   p.nz = nz;
   p.resolution = 0.01;
   std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
-  vgt::LaunchPassYSweep(in.data(), out.data(), scratch.data(), p, nullptr);
+  vgt::LaunchPassYSweep(in.data(), out.data(), vgt::SweepScratch{scratch.data(), scratch.size()}, p, nullptr);
   std::vector<int64_t> f(ny);
   std::vector<uint8_t> neg(ny);
   for (int x = 0; x < nx; x++)
@@ -182,8 +182,10 @@ void CheckYRecords(const Case& c, std::mt19937& rng)
   vgt::SdfParams p{};
   p.nx = nx; p.ny = ny; p.nz = nz;
   p.resolution = 0.01;
-  std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
-  vgt::LaunchPassYSweepRecords(rec.data(), out.data(), scratch.data(), p, nullptr);
+  // (c.border also: a scratch that holds ONE workgroup's slot -- the launch must make do with what it is given)
+  std::vector<unsigned char> scratch(c.border ? vgt::SweepPassScratchBytes(1, ny, std::min(nz, 64))
+                                              : vgt::SweepPassScratchBytes(nx, ny, nz));
+  vgt::LaunchPassYSweepRecords(rec.data(), out.data(), vgt::SweepScratch{scratch.data(), scratch.size()}, p, nullptr);
   std::vector<int64_t> f(ny);
   std::vector<uint8_t> neg(ny);
   for (int x = 0; x < nx; x++)
@@ -256,7 +258,7 @@ void CheckX(const Case& c, std::mt19937& rng)
   p.add_virtual_border = c.border ? 1 : 0;
   std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
   uint32_t minmax[2] = {0xffffffffu, 0u};
-  vgt::LaunchPassXSweepFinalize(in.data(), out.data(), minmax, scratch.data(), p, nullptr);
+  vgt::LaunchPassXSweepFinalize(in.data(), out.data(), minmax, vgt::SweepScratch{scratch.data(), scratch.size()}, p, nullptr);
   std::vector<int64_t> f(nx);
   std::vector<uint8_t> neg(nx);
   float lo = INFINITY, hi = -INFINITY;

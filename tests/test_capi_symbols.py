@@ -10,9 +10,13 @@ from conftest import ROOT
 from voxelized_geometry_tools_amd import capi
 
 
-def _declared_symbols():
+def _declared_symbols(testing=False):
+    """Functions include/vgt_hip.h declares: outside (product) or inside (testing=True) its VGT_HIP_TESTING section."""
     text = open(os.path.join(ROOT, "include", "vgt_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    section = re.search(r"#ifdef VGT_HIP_TESTING(.*?)#endif", text, flags=re.S)
+    assert section, "the header has a VGT_HIP_TESTING section"
+    text = section.group(1) if testing else text.replace(section.group(0), "")
     return sorted(set(re.findall(r"\b(vgt_hipx?_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -36,24 +40,41 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(raw, name), name
 
 
+def test_testing_hooks_live_in_the_testing_library_only(lib):
+    """The cross-check EDT variants and the debug / tuning hooks are declared under VGT_HIP_TESTING, bound separately and
+    exported by libvgt_hip_testing.so -- which also exports the whole product ABI -- and by nothing else."""
+    hooks = _declared_symbols(testing=True)
+    assert sorted(capi.TESTING_SIGNATURES) == hooks and len(hooks) >= 3
+    product = ctypes.CDLL(capi.LIB_PATH)
+    testing = ctypes.CDLL(capi.TESTING_LIB_PATH)
+    for name in hooks:
+        assert hasattr(testing, name), name
+        assert not hasattr(product, name), name
+    for name in _declared_symbols():
+        assert hasattr(testing, name), name
+    # no environment knobs in the product library
+    with open(capi.LIB_PATH, "rb") as fh:
+        assert b"VGT_HIP_HOST_PIPELINE" not in fh.read()
+
+
 def test_abi_version_and_workspace_size(lib):
-    assert lib.vgt_hip_abi_version() == 1
+    assert lib.vgt_hip_abi_version() == 2
     # class records (16 bytes per 64-voxel word of a Z line, plus 256 records of padding) + the int32 intermediate, a
-    # small min/max block and the line passes' scratch (8 work counters + per slot: the larger of the spill areas of the
-    # two entry kinds -- chunks of 8 x 4-byte or 4 x 8-byte entries per lane -- and one 8-byte word record per 32 rows
-    # and lane), 256-byte aligned pieces; the cross-check variants keep an int16 distance field instead of the records
+    # small min/max block and the line passes' scratch (8 work counters + per workgroup in flight -- at most 4096 -- the
+    # spill area of a full-depth stack per lane, chunks of 8 x 4-byte entries where the extents allow packed entries,
+    # and one 8-byte word record per 32 rows and lane), 256-byte aligned pieces; the cross-check variants keep an int16
+    # distance field instead of the records
     n = 64 * 64 * 64
     slots, words = 64, 2
     narrow = ((64 + 4 + 7) // 8 + 1) * 64 * 8 * 4
-    wide = ((64 + 4 + 3) // 4 + 1) * 64 * 4 * 8
-    scratch = 1024 + slots * (max(narrow, wide) + words * 64 * 8) + 256
+    scratch = 1024 + slots * (narrow + words * 64 * 8) + 256
     records = (64 * 1 * 64 + 256) * 16
     assert capi.sdf_workspace_bytes((64, 64, 64)) == records + n * 4 + 256 + scratch
     for variant in (1, 2, 3):
         assert capi.sdf_workspace_bytes((64, 64, 64), variant) == n * 2 + n * 4 + 256 + scratch
     # the scratch grows with the axis lengths, not with the volume: at most 5120 workgroups are in flight
     big = capi.sdf_workspace_bytes((1024, 1024, 1024))
-    assert big - 4 * 2 ** 30 - 2 ** 28 - 256 < 3 * 2 ** 30
+    assert big - 4 * 2 ** 30 - 2 ** 28 - 256 < 1.25 * 2 ** 30
     assert capi.sdf_workspace_bytes((0, 4, 4)) == 0
 
 

@@ -22,13 +22,34 @@ def oracle():
     return O
 
 
-VARIANTS = [0, 1, 2, 3]  # lane-per-line sweeps (default), pruned search from HBM, LDS-tiled envelope
+@pytest.fixture(scope="module")
+def vctx():
+    """A context of libvgt_hip_testing.so: the product's code plus the cross-check pipelines (EDT variants 1-3) and the
+    testing hooks.  The product library (the `ctx` fixture, what every other test runs) contains none of them."""
+    c = capi.Context(0, testing=True)
+    yield c
+    c.set_edt_variant(0)
+    c.close()
+
+
+# 0 = the default pipeline (class records + lane-per-line sweeps; run on the PRODUCT library), and the cross-check
+# pipelines of the testing library, which share an int16 distance field along Z as pass 1: 1 = pruned search from HBM,
+# 2 = LDS-tiled envelope, 3 = the sweeps fed by the int16 field
+VARIANTS = [0, 1, 2, 3]
+
+
+def context_for(variant, ctx, vctx):
+    if variant == 0:
+        return ctx
+    vctx.set_edt_variant(variant)
+    return vctx
+
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_reference_known_answers(ctx, sdf_kats, variant):
+def test_reference_known_answers(ctx, vctx, sdf_kats, variant):
     """test/sdf_generation_test.cpp extrema + exact cases through the HIP path."""
-    ctx.set_edt_variant(variant)
+    ctx = context_for(variant, ctx, vctx)
     tol = sdf_kats["extrema_tolerance"]
     for case in sdf_kats["extrema_cases"]:
         occ = kat_occupancy(case)
@@ -43,12 +64,11 @@ def test_reference_known_answers(ctx, sdf_kats, variant):
         sq = np.array(case["expected_sq"], dtype=np.float32)
         expected = (np.sign(sq) * np.sqrt(np.abs(sq))).astype(np.float32).reshape(case["shape"])
         assert bits_equal(sdf, expected), case["name"]
-    ctx.set_edt_variant(0)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_independent_edt_fixtures(ctx, sdf_scipy_cases, variant):
-    ctx.set_edt_variant(variant)
+def test_independent_edt_fixtures(ctx, vctx, sdf_scipy_cases, variant):
+    ctx = context_for(variant, ctx, vctx)
     for name, c in sdf_scipy_cases.items():
         sdf, lo, hi = ctx.sdf_from_occupancy(c["occ"], float(c["res"]), bool(c["uif"]), False)
         assert bits_equal(sdf, c["sdf"]), name
@@ -56,7 +76,6 @@ def test_independent_edt_fixtures(ctx, sdf_scipy_cases, variant):
         vb, lo, hi = ctx.sdf_from_occupancy(c["occ"], float(c["res"]), bool(c["uif"]), True)
         assert bits_equal(vb, c["sdf_vb"]), name + " (virtual border)"
         assert lo == c["sdf_vb"].min() and hi == c["sdf_vb"].max(), name
-    ctx.set_edt_variant(0)
 
 
 SHAPES = [(1, 1, 1), (1, 1, 2), (2, 1, 1), (1, 70, 1), (3, 5, 64), (3, 5, 65), (7, 9, 130),
@@ -90,16 +109,18 @@ def test_degenerate_grids(ctx, oracle):
     assert np.all(np.isneginf(got)) and np.isneginf(lo) and np.isneginf(hi)
 
 
-def test_variants_agree_on_synthetic_distributions(ctx, oracle):
+def test_variants_agree_on_synthetic_distributions(ctx, vctx, oracle):
     shape = (72, 96, 160)
     for dist in ("spheres", "salt", "unknown_mix"):
         occ = synthetic.make_occupancy(shape, dist, seed=42)
         want, _, _ = oracle.sdf_from_occupancy(occ, 0.01)
         for variant in VARIANTS:
-            ctx.set_edt_variant(variant)
-            got, _, _ = ctx.sdf_from_occupancy(occ, 0.01)
+            got, _, _ = context_for(variant, ctx, vctx).sdf_from_occupancy(occ, 0.01)
             assert bits_equal(got, want), (dist, variant)
-    ctx.set_edt_variant(0)
+        # the testing library's own build of the default pipeline, too
+        vctx.set_edt_variant(0)
+        got, _, _ = vctx.sdf_from_occupancy(occ, 0.01)
+        assert bits_equal(got, want), (dist, "testing library, default")
 
 
 def test_mask_entry_point(ctx, oracle):
@@ -119,12 +140,23 @@ def test_mask_entry_point(ctx, oracle):
         assert lo == want.min() and hi == want.max()
 
 
-def test_pipelined_host_entry_point(ctx, oracle, monkeypatch):
+def test_pipelined_host_entry_point(vctx, oracle):
     """Large grids through the host-pointer entry points are uploaded in X chunks, scanned and swept along Y chunk
     by chunk, swept along X in ranges of Y and downloaded range by range on separate streams.  The size threshold
     is lowered so that small grids take that path: ragged chunk sizes, the virtual border (whose Y coordinate is
-    the range's offset + the tile's), masks, and a grid just below the minimum extents (falls back)."""
-    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "1")
+    the range's offset + the tile's), masks, and a grid just below the minimum extents (falls back).  The threshold is
+    a hook of the testing library (the product pipelines from 2^27 voxels: bench.py's host_path runs that at 1024^3 and
+    checks that pageable and pinned calls give the same field)."""
+    ctx = vctx
+    ctx.set_edt_variant(0)
+    ctx.set_host_pipeline_min_voxels(1)
+    try:
+        _pipelined_host_cases(ctx, oracle)
+    finally:
+        ctx.set_host_pipeline_min_voxels(2 ** 27)
+
+
+def _pipelined_host_cases(ctx, oracle):
     rng = np.random.default_rng(77)
     for shape in ((32, 32, 8), (33, 47, 20), (100, 61, 36), (70, 130, 17), (31, 64, 12), (64, 600, 8), (1030, 40, 8)):
         occ = (rng.random(shape) < 0.03).astype(np.float32)
@@ -140,10 +172,10 @@ def test_pipelined_host_entry_point(ctx, oracle, monkeypatch):
         assert bits_equal(got, want), shape
         assert lo == want.min() and hi == want.max()
     # the same call with the pipeline turned off gives the same field
-    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "-1")
+    ctx.set_host_pipeline_min_voxels(-1)
     occ = (rng.random((100, 61, 36)) < 0.03).astype(np.float32)
     plain = ctx.sdf_from_occupancy(occ, 0.07, True, True)
-    monkeypatch.setenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS", "1")
+    ctx.set_host_pipeline_min_voxels(1)
     piped = ctx.sdf_from_occupancy(occ, 0.07, True, True)
     assert bits_equal(plain[0], piped[0]) and plain[1:] == piped[1:]
 
@@ -243,8 +275,8 @@ def test_headline_config_bit_exact_vs_oracle(ctx, oracle, dist):
 
 @pytest.mark.parametrize("shape,nslabs", [((1100, 600, 384), 3), ((600, 1300, 96), 2), ((2048, 520, 64), 4)])
 def test_z_slab_pipeline_long_axes(ctx, oracle, shape, nslabs):
-    """The slab pipeline on axes that use the wide-line tiles of the envelope passes (rows > 512 and > 1024),
-    all slabs on this device, against the oracle."""
+    """The slab pipeline on long axes (lines of more than 1024 rows: 64-bit stack entries in the sweep passes; a global Z
+    extent that decides the entry kind where the slab's own would not), all slabs on this device, against the oracle."""
     import torch
     from voxelized_geometry_tools_amd import multi_gpu
     if not _host_ram_ok(float(np.prod(shape))):
@@ -281,15 +313,15 @@ def test_multi_device_argument_errors():
         capi.sdf_multi([0, 4096], occ, 0.1)
 
 
-@pytest.mark.parametrize("shape", [(40, 33, 2048), (40, 33, 2049), (3, 1024, 2048), (1024, 3, 2048), (1024, 64, 2048),
-                                   (1024, 65, 2048), (3, 2048, 1449), (3, 2048, 1450), (2048, 3, 1449),
-                                   (2048, 30, 1449)])
-def test_packed_owner_limits(ctx, oracle, shape):
-    """The line passes keep (owner row, magnitude) in one 32-bit LDS word while every input magnitude is below
-    2^22 and the line has at most 1024 rows (2^21 and 2048 rows), and fall back to the member-mask iterator
-    beyond that: shapes on both sides of the limits (2047^2 < 2^22 <= 2048^2; 2047^2 + 63^2 < 2^22 <=
-    2047^2 + 64^2; 1448^2 < 2^21 <= 1449^2; 1448^2 + 2^2 < 2^21 <= 1448^2 + 29^2), with fields
-    whose distances reach the largest magnitudes (a single site in a corner) and dense ones."""
+@pytest.mark.parametrize("shape", [(40, 33, 2048), (40, 33, 2049), (3, 1024, 1775), (3, 1024, 1776), (1024, 3, 1775),
+                                   (1024, 3, 1776), (1024, 64, 1774), (1024, 65, 1774), (3, 1025, 40), (1025, 3, 40),
+                                   (3, 2048, 1449), (2048, 30, 1449)])
+def test_packed_entry_limits(ctx, oracle, shape):
+    """The sweep passes keep a stack entry (G = F + row^2, row) in one 32-bit word (22 + 10 bits) while the line has at
+    most 1024 rows and every G stays below 2^22 - 3, i.e. max input + (n - 1)^2 < 4194301 with max input = (nz - 1)^2 in
+    the Y pass and (nz - 1)^2 + (ny - 1)^2 in the X pass, and 64-bit entries beyond: shapes on both sides of the limits
+    (1023^2 + 1774^2 < 4194301 <= 1023^2 + 1775^2; 1023^2 + 1773^2 + 63^2 < 4194301 <= 1023^2 + 1773^2 + 64^2; 1024
+    and 1025 rows), with fields whose distances reach the largest magnitudes (a single site in a corner) and dense ones."""
     rng = np.random.default_rng(sum(shape))
     fields = []
     occ = np.zeros(shape, dtype=np.float32)
@@ -309,26 +341,25 @@ def test_packed_owner_limits(ctx, oracle, shape):
 
 @pytest.mark.parametrize("shape", [(1100, 6, 40), (5, 1500, 33), (2048, 4, 16), (3, 2049, 20),
                                    (2100, 3, 8), (4, 5, 1100), (2, 3, 2500)])
-def test_long_axes(ctx, oracle, shape):
-    """Axes in (1024, 2048] use the 16-line tiles (64 mask words per line); longer ones fall back
-    to the pruned search; Z lines beyond 1024 use the generic scan."""
+def test_long_axes(ctx, vctx, oracle, shape):
+    """Long axes in every pipeline.  Default: lines of more than 1024 rows take 64-bit stack entries, Z lines of more
+    than 1024 voxels the 32- and 64-word record kernels.  Cross-checks: axes in (1024, 2048] use the tiled envelope's
+    16-line tiles, longer ones fall back to the pruned search, Z lines beyond 1024 use the generic int16 scan."""
     rng = np.random.default_rng(sum(shape))
     occ = (rng.random(shape) < 0.01).astype(np.float32)
     occ[rng.random(shape) < 0.005] = 0.5
     want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.05)
     for variant in VARIANTS:
-        ctx.set_edt_variant(variant)
-        got, lo, hi = ctx.sdf_from_occupancy(occ, 0.05)
+        got, lo, hi = context_for(variant, ctx, vctx).sdf_from_occupancy(occ, 0.05)
         assert bits_equal(got, want), (shape, variant)
         assert (lo, hi) == (wlo, whi)
-    ctx.set_edt_variant(0)
 
 
 @pytest.mark.parametrize("resolution", [0.01, 0.25, 1.0, 1.0 / 3.0, 0.1, 0.05, 2.5e-3, 7.0, 1.0e-20, 3.0e25, 1.0e-42])
-def test_fast_finalize_matches_exact_for_every_d2(ctx, resolution):
+def test_fast_finalize_matches_exact_for_every_d2(vctx, resolution):
     """The final conversion float(sqrt(double(d2)) * res) (signed_distance_field_generation.hpp:98-105) has a
     fast evaluation with an exact fallback; both are run on the device for EVERY d2 in [0, 2^31)."""
-    bad, first = ctx.debug_finalize_check(0, 2 ** 31, resolution)
+    bad, first = vctx.debug_finalize_check(0, 2 ** 31, resolution)  # (a hook of the testing library)
     assert bad == 0, "first mismatch at d2 = %s" % first
 
 
@@ -473,5 +504,36 @@ def test_slab_carry_kernel_matches_torch_reduction(ctx):
             ctx.sdf_slab_carries(gathered.data_ptr(), world, rank, nx, ny, nz, got.data_ptr())
             torch.cuda.synchronize()
             assert torch.equal(got, want), rank
+    finally:
+        ctx.reset_stream()
+
+
+def test_slab_finish_rejects_carries_of_another_slab(ctx):
+    """The carries are decoded with the slab ranges of vgt_hip_sdf_slab_range: finishing a slab that is not the one the
+    carries were computed for (a custom or uneven split) is an argument error, not a silently wrong field."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    nx, ny, nz, world = 6, 7, 40, 3
+    occ = torch.zeros((nx, ny, nz), dtype=torch.float32, device="cuda")
+    occ[2, 3, 17] = 1.0
+    ctx.set_stream(None)
+    try:
+        gathered = torch.empty((world, nx * ny, 2), dtype=torch.int16, device="cuda")
+        slabs = []
+        for r in range(world):
+            local_shape, z0 = multi_gpu.slab_of((nx, ny, nz), r, world)
+            local = occ[:, :, z0:z0 + local_shape[2]].contiguous()
+            nbytes = capi.sdf_workspace_bytes(local_shape)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            ctx.sdf_slab_begin(local.data_ptr(), local_shape, z0, ws.data_ptr(), nbytes, gathered[r].data_ptr(), True)
+            slabs.append((local_shape, z0, ws, nbytes))
+        carries = torch.empty((nx * ny, 4), dtype=torch.int16, device="cuda")
+        ctx.sdf_slab_carries(gathered.data_ptr(), world, 1, nx, ny, nz, carries.data_ptr())
+        local_shape, z0, ws, nbytes = slabs[1]
+        sdf = torch.empty(local_shape, dtype=torch.float32, device="cuda")
+        with pytest.raises(ValueError, match="another slab"):  # the carries of rank 1 for a slab that starts elsewhere
+            ctx.sdf_slab_finish(local_shape, z0 + 1, nz, 0.1, carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), nbytes)
+        ctx.sdf_slab_finish(local_shape, z0, nz, 0.1, carries.data_ptr(), sdf.data_ptr(), ws.data_ptr(), nbytes)
+        torch.cuda.synchronize()
     finally:
         ctx.reset_stream()

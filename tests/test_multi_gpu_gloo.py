@@ -207,3 +207,7 @@ def test_point_share_matches_library():
         assert shares == [capi.point_share(n, world, r) for r in range(world)]
         assert sum(c for _, c in shares) == n
         assert all(shares[r][0] + shares[r][1] == shares[r + 1][0] for r in range(world - 1))
+    # invalid shares are argument errors (a share count of zero used to divide by zero inside the library)
+    for n, world, r in ((10, 0, 0), (10, 3, 3), (10, 3, -1), (-1, 2, 0)):
+        with pytest.raises(ValueError):
+            capi.point_share(n, world, r)

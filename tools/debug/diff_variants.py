@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from voxelized_geometry_tools_amd import capi
 
 rng = np.random.default_rng(5)
-with capi.Context(0) as ctx:
+with capi.Context(0, testing=True) as ctx:
     for shape in [(1, 1, 12), (1, 2, 12), (4, 8, 12), (2, 3, 64), (2, 3, 65), (3, 5, 130), (2, 70, 200), (1, 1, 1100), (5, 4, 5000)]:
         occ = (rng.random(shape) < 0.3).astype(np.float32)
         ctx.set_edt_variant(3)

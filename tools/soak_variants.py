@@ -36,7 +36,7 @@ def extract(ctx, occ, shape, variant, vb):
 def main():
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dev = torch.device("cuda", 0)
-    ctx = capi.Context(0)
+    ctx = capi.Context(0, testing=True)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     bad = 0
     for shape in SHAPES:

@@ -5,6 +5,7 @@ include/vgt_hip/.  There is no CPU fallback here -- if the library is missing, o
 device is usable, the calls raise.
 """
 import ctypes
+import threading
 import weakref
 import os
 
@@ -12,6 +13,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VGT_HIP_LIB") or os.path.join(_HERE, "libvgt_hip.so")  # override: diagnostic builds
+# The product library plus the cross-check EDT implementations and the testing hooks (-DVGT_HIP_TESTING): what the
+# parity tests load NEXT TO the product library (Context(testing=True)) to check the default pipeline against
+# independent implementations.  Nothing in the product path uses it.
+TESTING_LIB_PATH = os.environ.get("VGT_HIP_TESTING_LIB") or os.path.join(_HERE, "libvgt_hip_testing.so")
 _LIB = None
 
 _i64 = ctypes.c_int64
@@ -70,12 +75,11 @@ SIGNATURES = {
     "vgt_hipx_sdf_multi": (_int, [_p, _int, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hipx_release": (None, []),
     "vgt_hipx_last_timing": (_int, [_p]),
-    "vgt_hipx_point_share": (None, [_i64, _i32, _i32, _p, _p]),
+    "vgt_hipx_point_share": (_int, [_i64, _i32, _i32, _p, _p]),
     "vgt_hipx_raycast_points_split": (_int, [_p, _p, _sz, _p, _int, _p, _i64, _f32, _p, _f32, _f32, _f32, _f32,
                                              _f32, _i32, _i32, _i32]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
-    "vgt_hip_set_edt_variant": (_int, [_p, _int]),
     "vgt_hip_cells_create": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                    ctypes.c_int32, _p]),
     "vgt_hip_cells_destroy": (None, [_p]),
@@ -90,13 +94,20 @@ SIGNATURES = {
                                             ctypes.c_int64, _p]),
     "vgt_hip_timing_start": (_int, [_p, ctypes.c_int32]),
     "vgt_hip_timing_stop": (_int, [_p, _p, _p]),
-    "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_sdf_slab_summary_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_carries_bytes": (_sz, [_i64, _i64]),
     "vgt_hip_sdf_slab_range": (_int, [_i64, ctypes.c_int32, ctypes.c_int32, _p, _p]),
     "vgt_hip_sdf_slab_begin_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p, _sz, _p, _p]),
     "vgt_hip_sdf_slab_finish_dev": (_int, [_p, _i64, _i64, _i64, _i64, _i64, _f64, _int, _p, _p, _p,
                                            _sz, _p, _p]),
+}
+
+
+# exported by libvgt_hip_testing.so only (include/vgt_hip.h under VGT_HIP_TESTING)
+TESTING_SIGNATURES = {
+    "vgt_hip_set_edt_variant": (_int, [_p, _int]),
+    "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
+    "vgt_hip_testing_set_host_pipeline_min_voxels": (_int, [ctypes.c_int64]),
 }
 
 
@@ -108,32 +119,58 @@ class VgtHipUnavailable(VgtHipError):
     """No usable device (helper->IsAvailable() == false in the C++ glue)."""
 
 
-def load():
-    """Loads libvgt_hip.so once.  Raises if it has not been built (no fallback)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise VgtHipError(
-            "libvgt_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
-            "g.build()'` or `make -C voxelized_geometry_tools_amd/csrc`" % LIB_PATH)
+_TESTING_LIB = None
+_ERRORS = threading.local()
+
+
+def _bind(path, signatures):
     try:
         # One HIP runtime per process: if torch is around, let it load its bundled
         # libamdhip64 (same SONAME) first so the dynamic linker reuses it for us.
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C ABI
         pass
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
-    for name, (restype, argtypes) in SIGNATURES.items():
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+
+    def remember_error(result, func, args):
+        # error messages are thread-local PER LIBRARY: fetch the message from the library that failed
+        if isinstance(result, int) and result != 0:
+            _ERRORS.message = lib.vgt_hip_last_error().decode("utf-8", "replace")
+        return result
+
+    for name, (restype, argtypes) in signatures.items():
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    _LIB = lib
+        if restype is _int and name != "vgt_hip_abi_version":
+            fn.errcheck = remember_error
     return lib
 
 
+def load(testing=False):
+    """Loads libvgt_hip.so (or, testing=True, libvgt_hip_testing.so) once.  Raises if it has not been built (no fallback)."""
+    global _LIB, _TESTING_LIB
+    if testing:
+        if _TESTING_LIB is None:
+            if not os.path.exists(TESTING_LIB_PATH):
+                raise VgtHipError("libvgt_hip_testing.so is not built (%s); run `make -C voxelized_geometry_tools_amd/csrc`"
+                                  % TESTING_LIB_PATH)
+            _TESTING_LIB = _bind(TESTING_LIB_PATH, dict(SIGNATURES, **TESTING_SIGNATURES))
+        return _TESTING_LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise VgtHipError(
+            "libvgt_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C voxelized_geometry_tools_amd/csrc`" % LIB_PATH)
+    _LIB = _bind(LIB_PATH, SIGNATURES)
+    return _LIB
+
+
 def last_error():
-    return load().vgt_hip_last_error().decode("utf-8", "replace")
+    """Message of the last failed call of this thread (whichever of the two libraries it went to)."""
+    message = getattr(_ERRORS, "message", None)
+    return message if message is not None else load().vgt_hip_last_error().decode("utf-8", "replace")
 
 
 def check(rc):
@@ -170,8 +207,11 @@ def device_name(device):
 class Context:
     """One device + one stream (vgt_hip_ctx)."""
 
-    def __init__(self, device=0, threads_per_block=-1):
-        self._lib = load()
+    def __init__(self, device=0, threads_per_block=-1, testing=False):
+        """testing=True: a context of libvgt_hip_testing.so (set_edt_variant, debug_finalize_check,
+        set_host_pipeline_min_voxels exist there only)."""
+        self._lib = load(testing)
+        self.testing = bool(testing)
         h = _p()
         check(self._lib.vgt_hip_create(device, threads_per_block, ctypes.byref(h)))
         self.handle = h
@@ -259,7 +299,16 @@ class Context:
         return out[:n.value].copy()
 
     def set_edt_variant(self, variant):
+        """Testing library only: 0 default, 1 / 2 / 3 the cross-check pipelines."""
+        if not self.testing:
+            if int(variant) == 0:
+                return
+            raise VgtHipError("EDT variants other than 0 exist in libvgt_hip_testing.so only: Context(testing=True)")
         check(self._lib.vgt_hip_set_edt_variant(self.handle, int(variant)))
+
+    def set_host_pipeline_min_voxels(self, min_voxels):
+        """Testing library only (process-wide there): smallest grid the host-pointer SDF entry points pipeline."""
+        check(self._lib.vgt_hip_testing_set_host_pipeline_min_voxels(int(min_voxels)))
 
     def debug_finalize_check(self, first_d2, count, resolution):
         """(mismatches, first mismatching d2 or None) of the fast vs exact final conversion."""
@@ -375,7 +424,7 @@ def sdf_multi(devices, occupancy, resolution, unknown_is_filled=True, add_virtua
 def point_share(num_points, shares, share):
     """vgt_hipx_point_share -> (first, count) of `share` among `shares` contiguous shares of a cloud."""
     first, count = ctypes.c_int64(0), ctypes.c_int64(0)
-    load().vgt_hipx_point_share(int(num_points), int(shares), int(share), ctypes.byref(first), ctypes.byref(count))
+    check(load().vgt_hipx_point_share(int(num_points), int(shares), int(share), ctypes.byref(first), ctypes.byref(count)))
     return first.value, count.value
 
 
@@ -392,8 +441,9 @@ def sdf_multi_last_timing():
 
 
 def sdf_workspace_bytes(shape, variant=0):
-    """Workspace of the device-resident SDF entry points (the same for every EDT variant)."""
-    return int(load().vgt_hip_sdf_workspace_bytes_for_variant(*[int(s) for s in shape], int(variant)))
+    """Workspace of the device-resident SDF entry points (variant != 0: a cross-check pipeline of the testing library)."""
+    lib = load(testing=int(variant) != 0)
+    return int(lib.vgt_hip_sdf_workspace_bytes_for_variant(*[int(s) for s in shape], int(variant)))
 
 
 class TrackingGrids:

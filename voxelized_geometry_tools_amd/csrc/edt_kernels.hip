@@ -15,16 +15,18 @@
 //     pass 2  Y: lower envelope of parabolas over the squared pass-1 distances
 //     pass 3  X: same, fused with sqrt / resolution / sign / virtual border / min-max.
 //
-// This file holds the Z scan and the simple pruned-search line pass (EdtVariant::kBruteForce,
-// exact for any size, the fallback for axes longer than the tiled kernels support).  The
-// default line passes live in edt_sweep_kernels.hip (lane-per-line sweeps), the LDS-tiled
-// lower-envelope passes (cross-check variant 2) in edt_hull_kernels.hip.
+// The default pipeline is pass 1 = class records (edt_record_kernels.hip), passes 2 and 3 = lane-per-line sweeps
+// (edt_sweep_kernels.hip).  This file holds what the pipelines share (extrema, slab carries, the dispatch by variant)
+// and, in VGT_HIP_TESTING builds only (libvgt_hip_testing.so, used by the parity tests to cross-check the default
+// against independent implementations), the int16 Z scan and the pruned-search line passes (EdtVariant::kBruteForce);
+// the LDS-tiled lower-envelope passes (variant 2) live in edt_hull_kernels.hip, also a testing-only file.
 #include "edt_device.hpp"
 
 namespace vgt
 {
 namespace
 {
+#ifdef VGT_HIP_TESTING
 constexpr int kWave = kWaveSize;
 constexpr int kScanBlock = 256;
 constexpr int kScanWaves = kScanBlock / kWave;
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(256) void SlabFixupKernel(int16_t* __restrict__ io,
   }
 }
 
+#endif  // VGT_HIP_TESTING
 // Multi-GPU: per-line carries of slab `rank` from the gathered summaries of all slabs
 // (summaries[slab][line], 4 bytes each, see vgt_internal.hpp): nearest filled / free voxel below = the last such
 // voxel of the nearest lower slab that has one, above = the first such voxel of the nearest upper slab (-1 when
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256) void SlabCarriesKernel(const SlabLineSummary* 
   }
 }
 
+#ifdef VGT_HIP_TESTING
 // Same, eight consecutive voxels of one line per thread (nz % 8 == 0): one 16-byte load, one
 // carry record, and a store only when a distance actually shrank.
 __global__ __launch_bounds__(256) void SlabFixupVecKernel(int16_t* __restrict__ io,
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(256) void PassXBruteFinalizeKernel(
   BlockMinMax(lo, hi, minmax_enc);
 }
 
+#endif  // VGT_HIP_TESTING
 __global__ void InitMinMaxKernel(uint32_t* minmax_enc)
 {
   minmax_enc[0] = 0xffffffffu;
@@ -615,11 +620,14 @@ int GridFor(int64_t work_items, int block)
 }  // namespace
 
 // Defined in edt_sweep_kernels.hip / edt_hull_kernels.hip.
-hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+#ifdef VGT_HIP_TESTING
+hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                             hipStream_t stream);
-hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+#endif  // VGT_HIP_TESTING
+hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, SweepScratch scratch,
                                          const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
                                          hipStream_t stream);
+#ifdef VGT_HIP_TESTING
 hipError_t LaunchPassYHull(const int16_t* in16, int32_t* out32, const SdfParams& p,
                            hipStream_t stream, bool* handled);
 hipError_t LaunchPassXHullFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
@@ -629,6 +637,8 @@ hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_
                                         const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
                                         hipStream_t stream, bool* handled);
 
+#endif  // VGT_HIP_TESTING
+#ifdef VGT_HIP_TESTING
 namespace
 {
 template <typename InT>
@@ -724,6 +734,7 @@ hipError_t LaunchFinalizeCheck(int64_t first, int64_t count, double resolution,
   return hipGetLastError();
 }
 
+#endif  // VGT_HIP_TESTING
 hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int rank, int64_t lines, int64_t nz_global,
                              SlabLineCarry* carries, hipStream_t stream)
 {
@@ -732,6 +743,7 @@ hipError_t LaunchSlabCarries(const SlabLineSummary* summaries, int world, int ra
   return hipGetLastError();
 }
 
+#ifdef VGT_HIP_TESTING
 hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const SdfParams& p,
                            hipStream_t stream)
 {
@@ -748,7 +760,7 @@ hipError_t LaunchSlabFixup(int16_t* io16, const SlabLineCarry* carries, const Sd
   return hipGetLastError();
 }
 
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream)
 {
   if (IsSweepVariant(variant)) return LaunchPassYSweep(in16, out32, scratch, p, stream);
@@ -764,12 +776,14 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const
   return hipGetLastError();
 }
 
+#endif  // VGT_HIP_TESTING
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               void* scratch, const SdfParams& p, EdtVariant variant,
+                               SweepScratch scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream)
 {
   if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
+#ifdef VGT_HIP_TESTING
   if (variant == EdtVariant::kHull)
   {
     bool handled = false;
@@ -783,24 +797,36 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                      static_cast<int>(p.z_offset),
                      static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz));
   return hipGetLastError();
+#else
+  return hipErrorInvalidValue;  // (the cross-check variants are not part of this build)
+#endif
 }
 
 bool LinePassesTakeRanges(const SdfParams& p, EdtVariant variant)
 {
   if (IsSweepVariant(variant)) return true;
+#ifdef VGT_HIP_TESTING
   return variant == EdtVariant::kHull && HullPassesAreTiled(p);
+#else
+  (void)p;
+  return false;
+#endif
 }
 
-hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, SweepScratch scratch,
                                     const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
                                     hipStream_t stream)
 {
   if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, outer_begin, outer_count, stream);
+#ifdef VGT_HIP_TESTING
   bool handled = false;
   const hipError_t err = LaunchPassXHullFinalizeRange(in32, sdf, minmax_enc, p, outer_begin, outer_count, stream, &handled);
   if (err != hipSuccess) return err;
   return handled ? hipSuccess : hipErrorInvalidValue;
+#else
+  return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream)

@@ -1123,13 +1123,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   }
 }
 
-// Workgroups per launch = slots of the scratch buffer.  More than the 256 CUs x 16 waves of an MI355X hold at four
-// waves per SIMD, so the chip is always full; extra workgroups find the work counter exhausted and leave.
+// Workgroups per launch = slots of the scratch buffer: what the 256 CUs x 16 waves of an MI355X hold at four waves per
+// SIMD (more workgroups than that find nothing different to do: 4096, 5120 and 6144 measured the same).
 #ifdef VGT_HOST_EMULATION
 constexpr int64_t kSweepSlots = 3;  // (the CPU test wants slots that are used again and again)
 #else
 #ifndef VGT_SWEEP_SLOTS
-#define VGT_SWEEP_SLOTS 5120
+#define VGT_SWEEP_SLOTS 4096
 #endif
 constexpr int64_t kSweepSlots = VGT_SWEEP_SLOTS;
 #endif
@@ -1143,20 +1143,30 @@ bool PackedEntries(int64_t n, int64_t max_input)
   return n <= 1024 && max_input + (n - 1) * (n - 1) < Codec<true>::kSentinelG;
 }
 
-// Scratch of one pass: work counter, spill chunks and sign words of `slots` workgroups.  Sized for 64-bit entries
-// whatever the launch will use, so that the size depends on the extents only.
-size_t PassScratchBytes(int64_t n, int64_t items)
+// Scratch of one slot: the spill chunks of its 64 lines (every entry of a full-depth stack) and one (sign word, carry) pair
+// per 32 rows and lane.
+size_t SlotScratchBytes(int64_t n, bool packed)
+{
+  const int64_t nwords = (n + kWord - 1) / kWord;
+  const size_t spill = packed ? SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t)
+                              : SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
+  return spill + static_cast<size_t>(nwords) * kWaveSize * sizeof(uint2);
+}
+
+// Scratch of one pass: the work counters and the slots of the workgroups in flight, for the entry kind the extents call
+// for.  The size only decides how many workgroups a launch can use (LaunchSweep fits its slots into what it is given): a
+// slab whose global Z extent needs 64-bit entries where the local extents promised 32-bit ones runs with fewer slots.
+size_t PassScratchBytes(int64_t n, int64_t items, int64_t max_input)
 {
   const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
-  const int64_t nwords = (n + kWord - 1) / kWord;
-  const size_t narrow = SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t);
-  const size_t wide = SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
-  return kCounterBytes + static_cast<size_t>(slots) * ((narrow > wide ? narrow : wide) + nwords * kWaveSize * sizeof(uint2));
+  const size_t planned = static_cast<size_t>(slots) * SlotScratchBytes(n, PackedEntries(n, max_input));
+  const size_t one_wide = SlotScratchBytes(n, false);
+  return kCounterBytes + (planned > one_wide ? planned : one_wide);
 }
 
 template <typename InT, typename OutT, bool kFinal>
-hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax_enc, SweepGeom g, int64_t outer_count,
-                       int64_t max_input, hipStream_t stream)
+hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_bytes, uint32_t* minmax_enc, SweepGeom g,
+                       int64_t outer_count, int64_t max_input, hipStream_t stream)
 {
   g.zsegs = (g.nz + kWaveSize - 1) / kWaveSize;
   g.nwords = (g.n + kWord - 1) / kWord;
@@ -1165,10 +1175,17 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, uint32_t* minmax
   if (items > 0x7fffffffLL) return hipErrorInvalidValue;
   g.items = static_cast<int>(items);
   g.outers = static_cast<int>(outer_count);
-  const int64_t slots = items < kSweepSlots ? items : kSweepSlots;
+  const bool packed = PackedEntries(g.n, max_input);
+  int64_t slots = items < kSweepSlots ? items : kSweepSlots;
+  {
+    // as many slots as the scratch holds (see PassScratchBytes)
+    const size_t per_slot = SlotScratchBytes(g.n, packed);
+    const int64_t fit = scratch_bytes > kCounterBytes ? static_cast<int64_t>((scratch_bytes - kCounterBytes) / per_slot) : 0;
+    if (fit < 1) return hipErrorInvalidValue;
+    if (fit < slots) slots = fit;
+  }
   // (measured with streaming row accesses: -1.7 % on the Y pass, -0.7 % on the X pass at 1024^3, -1 % at 2048 rows)
   g.groups = static_cast<int>(slots < kSweepGroups ? slots : kSweepGroups);
-  const bool packed = PackedEntries(g.n, max_input);
   const int chunk = packed ? RingShape<true>::kChunk : RingShape<false>::kChunk;
   g.chunks = static_cast<int>(SpillChunks(g.n, chunk));
   // scratch: work counter | spill chunks of every slot | one (sign word, carry) pair per 32 rows, lane and slot
@@ -1244,29 +1261,36 @@ int64_t MaxInputX(const SdfParams& p) { return MaxInputY(p) + (p.ny - 1) * (p.ny
 size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz)
 {
   const int64_t zsegs = (nz + kWaveSize - 1) / kWaveSize;
-  const size_t y = PassScratchBytes(ny, nx * zsegs), x = PassScratchBytes(nx, ny * zsegs);
+  const int64_t max_y = (nz - 1) * (nz - 1), max_x = max_y + (ny - 1) * (ny - 1);
+  const size_t y = PassScratchBytes(ny, nx * zsegs, max_y), x = PassScratchBytes(nx, ny * zsegs, max_x);
   return (y > x ? y : x) + 256;
 }
 
-hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p, hipStream_t stream)
+#if defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION)
+// Y pass fed by the int16 distance field of the cross-check pipelines (EdtVariant::kDistanceField).
+hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch scratch, const SdfParams& p,
+                            hipStream_t stream)
 {
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);
-  return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch, nullptr, g, outer_count, MaxInputY(p), stream);
+  return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch.ptr, scratch.bytes, nullptr, g, outer_count,
+                                              MaxInputY(p), stream);
 }
+#endif
 
 // Y pass of the default pipeline: class records (pass 1, edt_record_kernels.hip) of p.nx slices -> int32.
-hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, void* scratch, const SdfParams& p,
+hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                                    hipStream_t stream)
 {
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);
-  return LaunchSweep<ClassRecord, int32_t, false>(records, out32, scratch, nullptr, g, outer_count, MaxInputY(p), stream);
+  return LaunchSweep<ClassRecord, int32_t, false>(records, out32, scratch.ptr, scratch.bytes, nullptr, g, outer_count,
+                                                  MaxInputY(p), stream);
 }
 
 // X pass over the Y positions [outer_begin, outer_begin + outer_count) of the grid (outer_count < 0: all of them):
 // full-grid pointers and extents in `p`.
-hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, SweepScratch scratch,
                                          const SdfParams& p, int64_t outer_begin, int64_t outer_count_or_all,
                                          hipStream_t stream)
 {
@@ -1279,10 +1303,11 @@ hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32
     g.outer_begin = static_cast<int>(outer_begin);
     outer_count = outer_count_or_all;
   }
-  return LaunchSweep<int32_t, float, true>(in32, sdf, scratch, minmax_enc, g, outer_count, MaxInputX(p), stream);
+  return LaunchSweep<int32_t, float, true>(in32, sdf, scratch.ptr, scratch.bytes, minmax_enc, g, outer_count,
+                                           MaxInputX(p), stream);
 }
 
-hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc, SweepScratch scratch,
                                     const SdfParams& p, hipStream_t stream)
 {
   return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);

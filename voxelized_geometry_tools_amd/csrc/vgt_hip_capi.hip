@@ -78,6 +78,14 @@ struct vgt_hip_ctx
   std::vector<PooledBuffer> pool;
   size_t pool_bytes = 0;
   bool pool_closed = false;  // set by vgt_hip_destroy: handles destroyed later free their buffers themselves
+  // Z-slab calls: which slab a carries buffer was computed for (vgt_hip_sdf_slab_carries_dev decodes the gathered
+  // summaries with the slab ranges of vgt_hip_sdf_slab_range; vgt_hip_sdf_slab_finish_dev refuses carries that were
+  // made for another slab than the one it is given).  Guarded by `mutex`.
+  struct SlabNote
+  {
+    int64_t z_offset, nz_local, nz_global;
+  };
+  std::map<const void*, SlabNote> slab_notes;
   // Copy streams and events of the pipelined host-pointer SDF extraction (SdfFromHostPipelined)
   hipStream_t copy_in = nullptr;
   hipStream_t copy_out = nullptr;
@@ -306,7 +314,7 @@ struct SdfWorkspace
   int16_t* t16;               // ... or of the cross-check pipelines (one of the two, the other is null)
   int32_t* t32;
   uint32_t* minmax_enc;
-  void* sweep_scratch;  // work counter, spilled stack entries and sign words of the line passes
+  vgt::SweepScratch sweep_scratch;  // work counters, spilled stack entries and sign words of the line passes
   size_t bytes;
 };
 
@@ -331,8 +339,9 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, vgt:
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
   off += 256;
-  ws.sweep_scratch = static_cast<char*>(base) + off;
-  off = AlignUp(off + vgt::SweepPassScratchBytes(nx, ny, nz), 256);
+  ws.sweep_scratch.ptr = static_cast<char*>(base) + off;
+  ws.sweep_scratch.bytes = vgt::SweepPassScratchBytes(nx, ny, nz);
+  off = AlignUp(off + ws.sweep_scratch.bytes, 256);
   ws.bytes = off;
   return ws;
 }
@@ -352,10 +361,14 @@ hipError_t LaunchPassOne(const InT* input_dev, const SdfWorkspace& ws, const vgt
     else
       return vgt::LaunchClassRecordsFromMask(input_dev + voxel_offset, records, part, summary, s);
   }
+#ifdef VGT_HIP_TESTING
   if constexpr (std::is_same<InT, float>::value)
     return vgt::LaunchScanZFromOccupancy(input_dev + voxel_offset, ws.t16 + voxel_offset, part, summary, s);
   else
     return vgt::LaunchScanZFromMask(input_dev + voxel_offset, ws.t16 + voxel_offset, part, summary, s);
+#else
+  return hipErrorInvalidValue;  // (no records: a cross-check variant, not part of this build)
+#endif
 }
 hipError_t LaunchPassTwo(const SdfWorkspace& ws, const vgt::SdfParams& part, int64_t first_slice, vgt::EdtVariant variant,
                          hipStream_t s)
@@ -364,7 +377,12 @@ hipError_t LaunchPassTwo(const SdfWorkspace& ws, const vgt::SdfParams& part, int
   if (ws.records)
     return vgt::LaunchPassYSweepRecords(ws.records + first_slice * vgt::RecordWords(part.nz) * part.ny,
                                         ws.t32 + voxel_offset, ws.sweep_scratch, part, s);
+#ifdef VGT_HIP_TESTING
   return vgt::LaunchPassY(ws.t16 + voxel_offset, ws.t32 + voxel_offset, ws.sweep_scratch, part, variant, s);
+#else
+  (void)variant;
+  return hipErrorInvalidValue;
+#endif
 }
 
 int CheckSdfShape(int64_t nx, int64_t ny, int64_t nz, double resolution)
@@ -413,14 +431,14 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
 // (nx pieces of ny_range * nz floats) goes back on a second copy stream while the next range is computed.  Only
 // with the tiled line passes (the others need whole axes per launch).  The caller holds ctx->mutex.
 constexpr int kPipelineChunks = 8;
+std::atomic<int64_t> g_host_pipeline_min_voxels{int64_t{1} << 27};
 
 template <typename InT>
 bool CanPipelineFromHost(const vgt_hip_ctx* ctx, const vgt::SdfParams& p)
 {
-  // VGT_HIP_HOST_PIPELINE_MIN_VOXELS: smallest grid that is pipelined (default 2^27; tests lower it, a negative
-  // value turns the pipeline off)
-  int64_t min_voxels = int64_t{1} << 27;
-  if (const char* text = getenv("VGT_HIP_HOST_PIPELINE_MIN_VOXELS")) min_voxels = atoll(text);
+  // smallest grid that is pipelined: 2^27 voxels (testing builds: vgt_hip_testing_set_host_pipeline_min_voxels lowers
+  // it so that small grids take this path, a negative value turns the pipeline off)
+  const int64_t min_voxels = g_host_pipeline_min_voxels.load();
   if (min_voxels < 0 || !vgt::LinePassesTakeRanges(p, ctx->variant)) return false;
   return p.nx >= 4 * kPipelineChunks && p.ny >= 4 * kPipelineChunks && p.nx * p.ny * p.nz >= min_voxels;
 }
@@ -874,6 +892,8 @@ int vgt_hip_synchronize(vgt_hip_ctx* ctx)
 
 int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 
+#ifdef VGT_HIP_TESTING
+/* Testing builds only (libvgt_hip_testing.so; declared in vgt_hip.h under VGT_HIP_TESTING). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
   if (!ctx || variant < 0 || variant > 3) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
@@ -903,6 +923,13 @@ int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t cou
   *first_mismatch = host[1];
   return VGT_HIP_OK;
 }
+
+int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels)
+{
+  g_host_pipeline_min_voxels.store(min_voxels);
+  return VGT_HIP_OK;
+}
+#endif  // VGT_HIP_TESTING
 
 /* ------------------------------ tracking grids ------------------------------ */
 
@@ -1278,6 +1305,9 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0 || variant < 0 || variant > 3) return 0;
+#ifndef VGT_HIP_TESTING
+  if (variant != 0) return 0;  // the cross-check variants are not part of this build
+#endif
   return CarveWorkspace(nullptr, nx, ny, nz, static_cast<vgt::EdtVariant>(variant)).bytes;
 }
 
@@ -1966,6 +1996,11 @@ int vgt_hip_sdf_slab_carries_dev(vgt_hip_ctx* ctx, const void* gathered_summarie
   VGT_TRY_HIP(vgt::LaunchSlabCarries(static_cast<const vgt::SlabLineSummary*>(gathered_summaries_dev), world, rank,
                                      nx * ny, nz_global, static_cast<vgt::SlabLineCarry*>(carries_dev), ctx->stream),
               "slab carries");
+  // the carries hold for the slab that vgt_hip_sdf_slab_range gives this rank, and for no other
+  vgt_hip_ctx::SlabNote note{0, 0, nz_global};
+  vgt::SlabRange(nz_global, world, rank, &note.z_offset, &note.nz_local);
+  if (ctx->slab_notes.size() > 64) ctx->slab_notes.clear();
+  ctx->slab_notes[carries_dev] = note;
   return VGT_HIP_OK;
 }
 
@@ -1991,6 +2026,13 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   const int trc = timer.Init(kernel_ms != nullptr, 3);
   if (trc != VGT_HIP_OK) return trc;
   std::lock_guard<std::mutex> lock(ctx->mutex);
+  {
+    const auto note = ctx->slab_notes.find(carries_dev);
+    if (note != ctx->slab_notes.end() && (note->second.z_offset != z_offset || note->second.nz_local != nz_local ||
+                                          note->second.nz_global != nz_global))
+      return Fail(VGT_HIP_ERR_INVALID_ARGUMENT,
+                  "the carries were computed for another slab: slabs must be the ranges of vgt_hip_sdf_slab_range");
+  }
   hipStream_t s = ctx->stream;
   hipEvent_t* slot = kernel_ms ? nullptr : TimingSlot(ctx);
   VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
@@ -1999,8 +2041,10 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   if (ws.records)
     VGT_TRY_HIP(vgt::LaunchSlabRecordFixup(ws.records, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s),
                 "slab fix-up");
+#ifdef VGT_HIP_TESTING
   else
     VGT_TRY_HIP(vgt::LaunchSlabFixup(ws.t16, static_cast<const vgt::SlabLineCarry*>(carries_dev), p, s), "slab fix-up");
+#endif
   VGT_TRY_HIP(timer.Mark(1, s), "event record");
   if (slot) VGT_TRY_HIP(hipEventRecord(slot[5], s), "event record");
   VGT_TRY_HIP(LaunchPassTwo(ws, p, 0, ctx->variant, s), "Y pass");

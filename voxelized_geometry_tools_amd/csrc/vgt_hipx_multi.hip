@@ -382,9 +382,10 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   (void)hipGetLastError();
   // the output array is not needed before the first download: it is page-locked by a helper thread while the
   // uploads run (joined before the first download is enqueued)
-  bool registered_out = false;
-  std::thread pin_out([&registered_out, sdf_host, total_bytes] {
-    registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
+  // (the thread writes the call state itself: whichever way this function returns, the joiner below joins the thread
+  // before the state's destructor looks at the flag and unlocks the pages)
+  std::thread pin_out([&st, sdf_host, total_bytes] {
+    st.registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
   });
   struct Joiner
   {
@@ -459,7 +460,6 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
 
   // per slab: carries, fix-up, Y and X passes, download
   pin_out.join();
-  st.registered_out = registered_out;
   (void)hipGetLastError();
   for (int r = 0; r < world; r++)
   {
@@ -501,10 +501,15 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   return VGT_HIP_OK;
 }
 
-extern "C" void vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count)
+extern "C" int vgt_hipx_point_share(int64_t num_points, int32_t shares, int32_t share, int64_t* first, int64_t* count)
 {
+  if (!first || !count) return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *first = *count = 0;
+  if (num_points < 0 || shares <= 0 || share < 0 || share >= shares)
+    return FailMulti(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid share of a point cloud");
   // equal shares, earlier shares take the remainder (the rule of vgt_hip_sdf_slab_range)
   vgt::SlabRange(num_points, shares, share, first, count);
+  return VGT_HIP_OK;
 }
 
 extern "C" int vgt_hipx_raycast_points_split(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t grid_index,

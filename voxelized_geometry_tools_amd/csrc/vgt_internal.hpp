@@ -135,23 +135,30 @@ hipError_t LaunchClassRecordsFromMask(const uint8_t* mask, ClassRecord* records,
                                       SlabLineSummary* summary, hipStream_t stream);
 hipError_t LaunchSlabRecordFixup(ClassRecord* records, const SlabLineCarry* carries, const SdfParams& p,
                                  hipStream_t stream);
+// Scratch of the sweep passes (work counters, spilled stack entries and sign words of the workgroups in flight): the
+// launchers use as many workgroups as its size allows, see SweepPassScratchBytes.
+struct SweepScratch
+{
+  void* ptr;
+  size_t bytes;
+};
 // Y pass of the default pipeline: class records -> int32 signed squared distance (edt_sweep_kernels.hip).
-hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, void* scratch, const SdfParams& p,
+hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                                    hipStream_t stream);
 // Y pass: int16 -> int32 signed squared distance.
 // `scratch`: SweepPassScratchBytes bytes (part of the SDF workspace).
-hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, void* scratch, const SdfParams& p,
+hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                        EdtVariant variant, hipStream_t stream);
 // X pass + finalize: int32 -> float SDF, min/max folded into minmax_enc (2 x uint32,
 // order-preserving encoding, must be pre-initialised by InitMinMax).
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
-                               void* scratch, const SdfParams& p, EdtVariant variant,
+                               SweepScratch scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
 // For callers that pipeline parts of a grid: the Y pass treats X slices independently (call LaunchPassY with nx =
 // slices of a contiguous part), and the X pass can be launched over a range of Y positions (full-grid pointers and
 // extents in `p`; outer_count < 0: the whole axis).  LinePassesTakeRanges: whether `variant` supports that for `p`.
 bool LinePassesTakeRanges(const SdfParams& p, EdtVariant variant);
-hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, void* scratch,
+hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, SweepScratch scratch,
                                     const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
                                     hipStream_t stream);
 // Scratch for the lane-per-line sweep passes (edt_sweep_kernels.hip): work counter, spilled stack entries and sign
