@@ -20,6 +20,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells):
+    """The raycaster against the bound it has (atomic throughput, not streaming HBM): atomic requests that
+    reach the L2 per launch (committed rocprofv3 --pmc TCC_ATOMIC pass, profiles/raycast_atomic_current.json, reported only
+    while the kernel timed here is within 5 % of the duration it was collected at) over the chip's scattered-atomic rate
+    from the committed micro-benchmark (tools/microbench/scattered_atomics.hip), and the floor: one atomic per distinct
+    cell a cloud touches.  Counters cannot be read from inside this process."""
+    out = {"visits": int(visits), "distinct_cells_touched": int(distinct_cells),
+           "note": "floor = one global atomic per distinct (cell, counter) touched; the workgroups' LDS tables merge visits of "
+                   "the SAME workgroup only, so cells shared by several workgroups cost one atomic each"}
+    path = os.path.join(ROOT, "profiles", "raycast_atomic_current.json")
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+        entry = doc["clouds"][cloud_key]
+        rate = float(doc["scattered_atomic_rate_G_per_s"])
+        recorded_ms = float(entry["raycast_kernel_ms"])
+        out["scattered_atomic_rate_G_per_s"] = rate
+        out["rate_source"] = doc.get("rate_source")
+        if recorded_ms > 0 and abs(raycast_ms - recorded_ms) <= 0.05 * recorded_ms:
+            atomics = float(entry["l2_atomics_per_launch"])
+            out.update({"l2_atomics_per_launch": int(atomics), "atomics_per_visit": round(atomics / max(visits, 1), 4),
+                        "atomics_per_distinct_cell": round(atomics / max(distinct_cells, 1), 3),
+                        "achieved_G_atomics_per_s": round(atomics / (raycast_ms * 1e-3) / 1e9, 2),
+                        "frac_of_scattered_atomic_rate": round(atomics / (raycast_ms * 1e-3) / 1e9 / rate, 3),
+                        "counters_source": "profiles/raycast_atomic_current.json (commit %s, kernel %.3f ms)" % (
+                            doc.get("commit", "?"), recorded_ms)})
+        else:
+            out["counters_source"] = "profiles/raycast_atomic_current.json is for a %.3f ms kernel (commit %s): not this build" % (
+                recorded_ms, doc.get("commit", "?"))
+    except (OSError, KeyError, ValueError, TypeError):
+        out["counters_source"] = None
+    return out
+
+
 def measure(points=1_000_000, grid=256, steps=10, warmup=3, check=True, threads_per_block=-1, ctx=None):
     """-> {"A_inside": {...}, "B_outside": {...}}: per cloud the raycast time (points resident in HBM), visits, rates and,
     with `check`, whether every tracking count equals the CPU oracle's."""
@@ -60,6 +94,7 @@ def measure(points=1_000_000, grid=256, steps=10, warmup=3, check=True, threads_
         single_ms = ev0.elapsed_time(ev1)
         got = grids.retrieve(0, counts)
         visits = int(got.sum())
+        distinct = int(np.count_nonzero(got))
         grids.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -79,6 +114,8 @@ def measure(points=1_000_000, grid=256, steps=10, warmup=3, check=True, threads_
                  "filter_ms": round(filter_ms, 4),
                  # algorithmic bytes: 12 B/point + 8 B/visit (4-byte atomic RMW), SURVEY.md 8d
                  "achieved_GBps": round((12.0 * points + 8.0 * visits) / (ms * 1e-3) / 1e9, 1)}
+        if points == 1_000_000 and grid == 256:
+            entry["atomic_roofline"] = atomic_roofline(name, ms, visits, distinct)
         if check:
             from oracle import oracle as O
             t0 = time.perf_counter()

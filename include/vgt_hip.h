@@ -137,6 +137,13 @@ int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
  * device copy of the static environment's float occupancy. */
 int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells,
                                const float* occupancy_host, vgt_hip_filter** out_filter);
+/* The same without waiting for the copy: the upload runs on a copy stream beside whatever the context does next (the
+ * raycasts of HipPointCloudVoxelizer, which prepares the filter grid first), and the calls that use the grid --
+ * filter, retrieve, destroy -- are ordered behind it.  `occupancy_host` must stay valid and unchanged until one of
+ * vgt_hip_retrieve_filtered_grid / vgt_hip_filter_grid_destroy has returned for this grid (it is page-locked by the
+ * library for that time). */
+int vgt_hip_filter_grid_create_deferred(vgt_hip_ctx* ctx, int64_t num_cells,
+                                        const float* occupancy_host, vgt_hip_filter** out_filter);
 void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter);
 int64_t vgt_hip_filter_grid_num_cells(const vgt_hip_filter* filter);
 void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter);

@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,19 @@ namespace vgt_hip
 {
 using voxelized_geometry_tools::pointcloud_voxelization::DeviceVoxelizationHelperInterface;
 using voxelized_geometry_tools::pointcloud_voxelization::LoggingFunction;
+
+// Host-clock phases of one VoxelizePointClouds call (seconds), for benchmarks: what VoxelizerRuntime's two numbers are made of.
+struct VoxelizePhases
+{
+  double prepare_tracking_grids_s = 0;       // device buffer (pooled) + zeroing enqueued
+  double filter_grid_enqueue_s = 0;          // page-locking the static environment + enqueueing its upload (not waited for)
+  double raycast_s = 0;                      // per-cloud upload + raycast kernels, all clouds, dispatch threads joined
+  double filter_grid_blocking_upload_s = 0;  // only with helpers that cannot defer the upload
+  double filter_enqueue_s = 0;               // filter kernel enqueued
+  double filter_and_download_s = 0;          // rest of the upload, filter kernel, download of the filtered grid (blocking)
+  double release_s = 0;                      // device buffers back to the pool
+  double total_s = 0;
+};
 
 class HipPointCloudVoxelizer
 {
@@ -48,11 +62,20 @@ public:
       const std::vector<PointCloudWrapperSharedPtr>& pointclouds,
       OccupancyMap& output_environment) const;
 
+  // Phases of the most recent call that finished on this object (any thread).
+  VoxelizePhases LastPhases() const
+  {
+    std::lock_guard<std::mutex> lock(phases_mutex_);
+    return last_phases_;
+  }
+
 private:
   void EnforceAvailable() const;
   std::unique_ptr<DeviceVoxelizationHelperInterface> helper_interface_;
   std::string device_name_ = "HipPointCloudVoxelizer";
   int dispatch_threads_ = 1;
+  mutable std::mutex phases_mutex_;
+  mutable VoxelizePhases last_phases_;
 };
 
 // OccupancyMap::ExtractSignedDistanceField<float>.  Throws std::invalid_argument for grids the

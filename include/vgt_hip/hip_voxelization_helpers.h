@@ -41,6 +41,17 @@ public:
       TrackingGridsHandle& tracking_grids, size_t tracking_grid_index) = 0;
 };
 
+// Extension of the plugin interface implemented by the HIP helper: PrepareFilterGrid without waiting for the copy.
+// The upload of the static environment (64 MiB at 256^3) then runs beside the raycasts instead of after them;
+// FilterTrackingGrids / RetrieveFilteredGrid are ordered behind it.  `host_data_ptr` must stay valid and unchanged until
+// RetrieveFilteredGrid has returned or the handle is destroyed.  Callers discover it with dynamic_cast on the helper.
+class DeferredFilterGridInterface
+{
+public:
+  virtual ~DeferredFilterGridInterface() {}
+  virtual std::unique_ptr<FilterGridHandle> PrepareFilterGridDeferred(int64_t num_cells, const void* host_data_ptr) = 0;
+};
+
 std::vector<AvailableDevice> GetAvailableDevices();
 
 std::unique_ptr<DeviceVoxelizationHelperInterface> MakeHipVoxelizationHelper(

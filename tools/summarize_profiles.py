@@ -7,21 +7,22 @@ import json
 import os
 import sys
 
-KERNELS = (("ScanZ", "ScanZ"), ("PassY", "false"), ("PassXFinalize", "true"))
-EXPECTED = {"ScanZ": "4 GiB read (float occupancy) + 2 GiB write (int16)",
-            "PassY": "2 GiB read (int16) + 4 GiB write (int32)",
+EXPECTED = {"PassZClassRecords": "4 GiB read (float occupancy) + 0.25 GiB write (class records)",
+            "PassY": "0.25 GiB read (class records) + 4 GiB write (int32)",
             "PassXFinalize": "4 GiB read (int32) + 4 GiB write (float)"}
 
 
 def classify(name):
     if "vgt::" not in name:
         return None
+    if "ClassRecord" in name and "SweepPassKernel" not in name:
+        return "PassZClassRecords"
     if "ScanZ" in name:
-        return "ScanZ"
+        return "PassZClassRecords"  # (cross-check builds: the int16 scan is their pass 1)
     if "SweepPassKernel" in name:
         # SweepPassKernel<InT, OutT, kFinal, ...>: the X pass writes floats
         args = name.split("SweepPassKernel", 1)[1]
-        return "PassXFinalize" if ("float" in args[:24] or "IifL" in args[:8]) else "PassY"
+        return "PassXFinalize" if ("float" in args[:40] or "IifL" in args[:8]) else "PassY"
     if "PassKernel" in name or "Brute" in name:
         # the bool template argument kFinal tells the X pass from the Y pass
         return "PassXFinalize" if ("true" in name or "b1" in name or "Finalize" in name) else "PassY"
@@ -40,9 +41,10 @@ def main():
                "commit": commit,
                "note": "MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a "
                        "coalesced streaming read (128-B requests tallied at 64 B), WRITE_SIZE is exact.  "
-                       "'fetch_bytes_corrected' doubles the raw value: the Z scan reads 16 B per lane, the sweep passes "
-                       "one 128-B (int16) or 256-B (int32) row segment per wave instruction, which the L2 fetches as "
-                       "whole 128-B requests.  kernel_ns / kernel_name: the kernel these bytes belong to (rocprofv3 "
+                       "'fetch_bytes_corrected' doubles the raw value: pass 1 and the X pass read one 256-B row segment "
+                       "per wave instruction, the Y pass its records 1 KiB per wave instruction, the spill refills 32 B per "
+                       "lane -- all whole 128-B requests at the L2 (check: pass 1's corrected fetch is the 4 GiB of the "
+                       "occupancy grid).  kernel_ns / kernel_name: the kernel these bytes belong to (rocprofv3 "
                        "--kernel-trace --stats of the same build, AverageNs); bench.py reports the traffic only when "
                        "the kernel it times agrees within 5 %.",
                "kernels": {}}
@@ -107,6 +109,38 @@ def main():
                 short = next((k for k in ("RaycastKernel", "DirectionBinKernel", "BinOffsetsKernel", "ScatterOrderKernel",
                                           "FilterKernel") if k in name), "other")
                 atomic[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if atomic and "RaycastKernel" in atomic:
+        # the bench line's atomic_roofline reads this (bench_raycast.atomic_roofline): clouds alternate A, B per launch
+        counts = next(iter(atomic["RaycastKernel"].values()))
+        half = len(counts) // 2
+        durations = {}
+        for f in rstats:
+            for row in csv.DictReader(open(f)):
+                if "RaycastKernel" in row["Name"]:
+                    durations = {"avg_ms": float(row["AverageNs"]) * 1e-6}
+        micro = {}
+        try:
+            micro = json.load(open(os.path.join(out, "microbench_scattered_atomics.json")))
+        except (OSError, ValueError):
+            pass
+        bench = {}
+        try:
+            bench = json.load(open(os.path.join(out, "bench_raycast_config3.json")))["results"]
+        except (OSError, ValueError, KeyError):
+            pass
+        current = {"commit": commit,
+                   "command": "rocprofv3 --pmc TCC_ATOMIC(_sum) --kernel-trace -- python3 bench_raycast.py --no-check; "
+                              "tools/microbench/scattered_atomics",
+                   "scattered_atomic_rate_G_per_s": micro.get("scattered_G_atomics_per_s"),
+                   "rate_source": "tools/microbench/scattered_atomics.hip on the same box: uniformly random cells of an "
+                                  "int32[2 x 256^3] grid, one atomic per lane",
+                   "microbench": micro,
+                   "clouds": {}}
+        for key, values in (("A_inside", counts[:half]), ("B_outside", counts[half:])):
+            if values and key in bench:
+                current["clouds"][key] = {"l2_atomics_per_launch": sum(values) / len(values),
+                                          "raycast_kernel_ms": bench[key]["raycast_ms"]}
+        json.dump(current, open(os.path.join(out, "raycast_atomic_current.json"), "w"), indent=1)
     if atomic:
         json.dump({"command": "rocprofv3 --pmc <TCC atomic request counters> --kernel-trace -- python3 bench_raycast.py "
                               "--no-check (config 3, clouds A then B)",

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vgt_hip_raycast_points_f64": (_int, [_p, _p, _sz, _p, _i64, _f64, _p, _f64, _f64, _f64, _f64,
                                           _f64, _i32, _i32, _i32]),
     "vgt_hip_filter_grid_create": (_int, [_p, _i64, _p, ctypes.POINTER(_p)]),
+    "vgt_hip_filter_grid_create_deferred": (_int, [_p, _i64, _p, ctypes.POINTER(_p)]),
     "vgt_hip_filter_grid_destroy": (None, [_p]),
     "vgt_hip_filter_grid_num_cells": (_i64, [_p]),
     "vgt_hip_filter_grid_dev_ptr": (_p, [_p]),

@@ -75,6 +75,10 @@ VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
   EnforceAvailable();
 
   const auto start_time = std::chrono::steady_clock::now();
+  const auto seconds_since = [](const std::chrono::steady_clock::time_point& t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+  VoxelizePhases phases;
 
   // at least one tracking grid so that filtering is uniform when there are no clouds
   const size_t num_tracking_grids = std::max(pointclouds.size(), static_cast<size_t>(1));
@@ -82,6 +86,20 @@ VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
       static_environment.NumTotalVoxels(), static_cast<int32_t>(num_tracking_grids));
   if (tracking_grids->GetNumTrackingGrids() != num_tracking_grids)
     throw std::runtime_error("Failed to allocate device tracking grid");
+  phases.prepare_tracking_grids_s = seconds_since(start_time);
+
+  // The static environment goes to the device FIRST, without waiting for the copy (the reference prepares the filter grid
+  // after the raycasts, device_pointcloud_voxelization.cpp:161-165: with a blocking copy the order does not matter
+  // there): its 4 bytes per cell then cross the link while the clouds are raycast.  The results are the same.
+  std::unique_ptr<FilterGridHandle> filter_grid;
+  const auto upload_time = std::chrono::steady_clock::now();
+  hip_helpers::DeferredFilterGridInterface* deferred =
+      dynamic_cast<hip_helpers::DeferredFilterGridInterface*>(helper_interface_.get());
+  if (deferred != nullptr)
+    filter_grid = deferred->PrepareFilterGridDeferred(static_environment.NumTotalVoxels(),
+                                                      static_environment.GetImmutableRawData().data());
+  phases.filter_grid_enqueue_s = seconds_since(upload_time);
+  const auto raycast_start_time = std::chrono::steady_clock::now();
 
   const Isometry3& X_GW = static_environment.InverseOriginTransform();
   const float voxel_size = static_cast<float>(static_environment.VoxelXSize());
@@ -159,14 +177,30 @@ VoxelizerRuntime HipPointCloudVoxelizer::VoxelizePointClouds(
   }
 
   const auto raycasted_time = std::chrono::steady_clock::now();
+  phases.raycast_s = std::chrono::duration<double>(raycasted_time - raycast_start_time).count();
 
-  std::unique_ptr<FilterGridHandle> filter_grid = helper_interface_->PrepareFilterGrid(
-      static_environment.NumTotalVoxels(), static_environment.GetImmutableRawData().data());
+  if (!filter_grid)
+    filter_grid = helper_interface_->PrepareFilterGrid(static_environment.NumTotalVoxels(),
+                                                       static_environment.GetImmutableRawData().data());
+  phases.filter_grid_blocking_upload_s = seconds_since(raycasted_time);
+  const auto filter_time = std::chrono::steady_clock::now();
   helper_interface_->FilterTrackingGrids(
       *tracking_grids, static_cast<float>(filter_options.PercentSeenFree()),
       filter_options.OutlierPointsThreshold(), filter_options.NumCamerasSeenFree(), *filter_grid);
+  phases.filter_enqueue_s = seconds_since(filter_time);
+  const auto download_time = std::chrono::steady_clock::now();
   helper_interface_->RetrieveFilteredGrid(*filter_grid,
                                           output_environment.GetMutableRawData().data());
+  phases.filter_and_download_s = seconds_since(download_time);
+  const auto release_time = std::chrono::steady_clock::now();
+  filter_grid.reset();
+  tracking_grids.reset();
+  phases.release_s = seconds_since(release_time);
+  phases.total_s = seconds_since(start_time);
+  {
+    std::lock_guard<std::mutex> lock(phases_mutex_);
+    last_phases_ = phases;
+  }
 
   const auto done_time = std::chrono::steady_clock::now();
   return VoxelizerRuntime(std::chrono::duration<double>(raycasted_time - start_time).count(),

@@ -67,7 +67,9 @@ private:
   vgt_hip_filter* filter_;
 };
 
-class HipVoxelizationHelper : public DeviceVoxelizationHelperInterface, public StridedRaycastInterface
+class HipVoxelizationHelper : public DeviceVoxelizationHelperInterface,
+                              public StridedRaycastInterface,
+                              public DeferredFilterGridInterface
 {
 public:
   HipVoxelizationHelper(const std::map<std::string, int32_t>& options,
@@ -165,6 +167,16 @@ public:
     vgt_hip_filter* filter = nullptr;
     const int rc = vgt_hip_filter_grid_create(ctx_, num_cells,
                                               static_cast<const float*>(host_data_ptr), &filter);
+    if (rc != VGT_HIP_OK) throw std::runtime_error(vgt_hip_last_error());
+    return std::unique_ptr<FilterGridHandle>(new HipFilterGridHandle(filter));
+  }
+
+  std::unique_ptr<FilterGridHandle> PrepareFilterGridDeferred(
+      const int64_t num_cells, const void* host_data_ptr) override
+  {
+    vgt_hip_filter* filter = nullptr;
+    const int rc = vgt_hip_filter_grid_create_deferred(ctx_, num_cells,
+                                                       static_cast<const float*>(host_data_ptr), &filter);
     if (rc != VGT_HIP_OK) throw std::runtime_error(vgt_hip_last_error());
     return std::unique_ptr<FilterGridHandle>(new HipFilterGridHandle(filter));
   }

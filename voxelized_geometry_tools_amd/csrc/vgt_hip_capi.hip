@@ -107,6 +107,11 @@ struct vgt_hip_filter
   int device = -1;
   float* dev = nullptr;
   int64_t num_cells = 0;
+  // vgt_hip_filter_grid_create_deferred: the upload runs on the context's copy stream; `uploaded` is recorded behind it
+  // and the caller's array stays page-locked (`pin`, a ScopedHostPin) until a call has waited for the copy
+  hipEvent_t uploaded = nullptr;
+  bool upload_pending = false;
+  void* pin = nullptr;
 };
 
 // Device copy of a grid of cell records (occupancy + optional object id) and the buffers the
@@ -1206,11 +1211,73 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
   return VGT_HIP_OK;
 }
 
+namespace
+{
+// The filter kernel / a download is about to use the grid on the context's stream: order it behind a deferred upload.
+hipError_t OrderBehindUpload(vgt_hip_ctx* ctx, const vgt_hip_filter* filter)
+{
+  if (!filter->upload_pending) return hipSuccess;
+  return hipStreamWaitEvent(ctx->stream, filter->uploaded, 0);
+}
+// The host has waited for work that was ordered behind the upload (or for the upload itself): the caller's array is free.
+void UploadHasFinished(vgt_hip_filter* filter)
+{
+  filter->upload_pending = false;
+  delete static_cast<ScopedHostPin*>(filter->pin);
+  filter->pin = nullptr;
+}
+}  // namespace
+
+int vgt_hip_filter_grid_create_deferred(vgt_hip_ctx* ctx, int64_t num_cells, const float* occupancy_host,
+                                        vgt_hip_filter** out_filter)
+{
+  if (!ctx || !out_filter) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *out_filter = nullptr;
+  if (num_cells <= 0) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "num_elements must be > 0");
+  if (!occupancy_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "to_copy cannot be nullptr");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt_hip_filter* f = new (std::nothrow) vgt_hip_filter();
+  if (!f) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
+  f->ctx = ctx;
+  f->device = ctx->device;
+  f->num_cells = num_cells;
+  const size_t bytes = static_cast<size_t>(num_cells) * sizeof(float);
+  hipError_t err = PoolAllocate(ctx, reinterpret_cast<void**>(&f->dev), bytes);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&f->uploaded, hipEventDisableTiming);
+  if (err == hipSuccess)
+  {
+    f->pin = new ScopedHostPin(occupancy_host, bytes);
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (!ctx->copy_in) err = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
+    // (a pooled buffer may still be read by work queued on the context's stream: the copy starts behind it)
+    if (err == hipSuccess) err = hipEventRecord(f->uploaded, ctx->stream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(ctx->copy_in, f->uploaded, 0);
+    if (err == hipSuccess) err = hipMemcpyAsync(f->dev, occupancy_host, bytes, hipMemcpyHostToDevice, ctx->copy_in);
+    if (err == hipSuccess) err = hipEventRecord(f->uploaded, ctx->copy_in);
+    f->upload_pending = err == hipSuccess;
+  }
+  if (err != hipSuccess)
+  {
+    if (f->uploaded) (void)hipStreamSynchronize(ctx->copy_in);
+    delete static_cast<ScopedHostPin*>(f->pin);
+    if (f->uploaded) (void)hipEventDestroy(f->uploaded);
+    if (f->dev) (void)hipFree(f->dev);
+    delete f;
+    return FailHip("Failed to prepare filter grid", err);
+  }
+  AdoptChild(ctx);
+  *out_filter = f;
+  return VGT_HIP_OK;
+}
+
 void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter)
 {
   if (!filter) return;
   vgt_hip_ctx* const ctx = filter->ctx;
   (void)hipSetDevice(filter->device);
+  if (filter->upload_pending) (void)hipEventSynchronize(filter->uploaded);
+  UploadHasFinished(filter);
+  if (filter->uploaded) (void)hipEventDestroy(filter->uploaded);
   if (ctx->destroyed.load())
     (void)hipDeviceSynchronize();
   else
@@ -1240,6 +1307,7 @@ static int FilterImpl(vgt_hip_ctx* ctx, const vgt_hip_grids* grids, double perce
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "tracking grids and filter grid differ in size");
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(OrderBehindUpload(ctx, filter), "order the filter behind the grid's upload");
   VGT_TRY_HIP(vgt::LaunchFilter(grids->dev, grids->num_cells, grids->num_grids, percent_seen_free,
                                 outlier_points_threshold, num_cameras_seen_free, ratio_in_double,
                                 filter->dev, ctx->threads_per_block, ctx->stream),
@@ -1288,9 +1356,12 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
   const size_t bytes = static_cast<size_t>(filter->num_cells) * sizeof(float);
   const ScopedHostPin pin(host_out, bytes);
   std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(OrderBehindUpload(ctx, filter), "order the download behind the grid's upload");
   VGT_TRY_HIP(hipMemcpyAsync(host_out, filter->dev, bytes, hipMemcpyDeviceToHost, ctx->stream),
               "Failed to memcpy the filter grid back to the host");
   VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "retrieve filtered grid");
+  // (the handle is logically const for the caller; the finished upload's bookkeeping is not part of its value)
+  if (filter->upload_pending) UploadHasFinished(const_cast<vgt_hip_filter*>(filter));
   return VGT_HIP_OK;
 }
 
