@@ -102,6 +102,15 @@ inline unsigned long long vgt_emulated_vote(bool pred)
 #define __builtin_amdgcn_alignbit(hi, lo, shift) \
   (static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | static_cast<uint64_t>(lo)) >> (shift)))
 #define __builtin_amdgcn_readfirstlane(value) (value)
+inline uint32_t vgt_emulated_bitreverse32(uint32_t v)
+{
+  uint32_t r = 0;
+  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+#ifndef __clang__
+#define __builtin_bitreverse32(value) vgt_emulated_bitreverse32(value)
+#endif
 inline int __any(int pred) { return pred != 0; }
 inline int __shfl_xor(int v, int) { return v; }
 inline void __syncthreads() {}

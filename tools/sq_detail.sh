@@ -14,7 +14,7 @@ for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_D
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python3 bench.py $ARGS --steps 1 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -- python3 bench.py $ARGS --no-secondary --steps 1 --warmup 1 > /dev/null 2>&1
 done
 python3 - $OUT > $OUT/summary.txt <<'PY'
 import csv, glob, sys, collections, os
@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(out, "p*", "*", "*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"]
         if "vgt::" not in name: continue
-        short = "ScanZ" if "ScanZ" in name else ("X" if "<int, float" in name else "Y")
+        short = "Records" if ("ClassRecordKernel" in name or "ScanZ" in name) else ("X" if "<int, float" in name else "Y")
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)

@@ -782,16 +782,24 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           for (int k = 0; k < kBand; k++)
           {
             if (k % kChunk == 0) check_ring();
-            if (kGuard && r0 + k >= n) bits >>= 1;  // (keeps the rows of a partial band at their bit positions)
+            if (kGuard && r0 + k >= n) bits <<= 1;  // (keeps the rows of a partial band at their bit positions)
             if (!kGuard || r0 + k < n)
             {
               const int q = r0 + k;
               const int32_t v = cur[k];
-              const int32_t sign = v >> 31;
-              bits = __builtin_amdgcn_alignbit(static_cast<uint32_t>(sign), bits, 1);  // shifted in from the top
+              // the class (bit 31 of either input format) is shifted in from the bottom by ONE instruction, (bits : v) >> 31;
+              // the band's bits come out in reverse order and are turned round once per band below
+              bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(v), 31);
               // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
               // sign and magnitude (bit 31 = class), which one `and` takes apart
-              int32_t f = (sizeof(InT) == 2) ? (v ^ sign) - sign : (v & 0x7fffffff);
+              int32_t f;
+              if constexpr (sizeof(InT) == 2)
+              {
+                const int32_t sign = v >> 31;
+                f = (v ^ sign) - sign;
+              }
+              else
+                f = v & 0x7fffffff;
               // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
               if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
               {
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           rows(std::false_type{});
         else
           rows(std::true_type{});
-        band_done(r0, bits);
+        band_done(r0, __builtin_bitreverse32(bits));  // (row k of the band: bit kBand - 1 - k -> bit 32 - kBand + k)
       }
     }
   }
@@ -823,7 +831,45 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     VGT_SWEEP_COUNT(9, classes ? 1 : 0);
   }
 #endif
-  if (!(VGT_SWEEP_EXP & 8) || any_transition == 0x12345u)
+  // No site on any of the wave's 64 lines and no class change along them (more than half of the Y pass's items on a sparse
+  // scene: the slice holds no voxel whose Z line changes class): every row's result is "no voxel of the other class",
+  // +-infinity by the line's class, and the evaluation is a fill from the sign words.  (The virtual border turns "none" into a finite distance: then the
+  // general evaluation runs.)
+  bool all_empty = !classes && __builtin_amdgcn_ballot_w64(D != (4u << kShift)) == 0ull;
+  if constexpr (kFinal && !kPlain) all_empty = all_empty && !g.add_virtual_border;
+  if (all_empty && !(VGT_SWEEP_EXP & 32))
+  {
+    const int nwords = g.nwords;
+    VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));
+    uint2 info = LoadPair(wave_info + static_cast<int64_t>(nwords - 1) * kWaveSize + lane);
+    for (int w = nwords - 1; w >= 0; w--)
+    {
+      const uint32_t sw = info.x;
+      if (w > 0) info = LoadPair(wave_info + static_cast<int64_t>(w - 1) * kWaveSize + lane);
+      const int valid = min(kWord, n - w * kWord);
+      if constexpr (kFinal)
+      {
+        const uint32_t rows_mask = LowBits(valid);
+        if (sw & rows_mask) lo_value = -INFINITY;
+        if (~sw & rows_mask) hi_value = INFINITY;
+      }
+      for (int k = valid - 1; k >= 0; k--)
+      {
+        const uint32_t sign = (sw >> k) << 31;
+        if constexpr (kFinal)
+        {
+          VGT_STREAM_STORE(__uint_as_float(0x7f800000u | sign), LaneAddress(row_out, zl * 4u));
+        }
+        else
+        {
+          // (sign and magnitude, like the general evaluation)
+          VGT_STREAM_STORE(static_cast<OutT>(static_cast<uint32_t>(kInf32) | sign), &row_out[zl]);
+        }
+        row_out = UniformPointer(row_out - rstride);
+      }
+    }
+  }
+  else if (!(VGT_SWEEP_EXP & 8) || any_transition == 0x12345u)
   {
     // Every kStep rows the chunks requested at the last step go into the ring and up to two more are requested
     // when the ring has room (between two steps the ring only shrinks).
