@@ -1123,6 +1123,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               const int32_t d2 =
                   (kClasses && best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
               // (sign and magnitude, not two's complement: see sweep 1 of the X pass)
+#if VGT_SWEEP_EXP & 64
+              if (d2 == 0x12345679)  // (experiment: the evaluation without its stores)
+#endif
               VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), &row_out[zl]);
               row_out = UniformPointer(row_out - rstride);
             }
