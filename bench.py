@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--dist spheres]
 
-One "step" = one full ExtractSignedDistanceField<float> pass (Z scan, Y pass, X pass +
+One "step" = one full ExtractSignedDistanceField<float> pass (pass 1 to class records, Y pass, X pass +
 finalize + min/max) over a synthetic occupancy grid that is already resident in HBM; the
 SDF is left in HBM.  Workloads (--workload): c4 = BASELINE config 4 (1024^3, distribution D1
 "spheres", seed 42, resolution 0.01), the headline and the default at N = 1; c5 = BASELINE
@@ -241,7 +241,7 @@ def end_to_end(ctx, torch, occ_dev, shape, res):
                           "end_to_end": round(2 * nbytes / pageable / 1e9, 1),
                           "end_to_end_pinned": round(2 * nbytes / pinned / 1e9, 1)},
             "vs_pcie_lower_bound": round(pinned / bound, 3), "host_results_identical": same,
-            "note": "host-pointer entry point: H2D, Z scan + Y pass per X chunk as it arrives, X pass per Y range, D2H "
+            "note": "host-pointer entry point: H2D, pass 1 + Y pass per X chunk as it arrives, X pass per Y range, D2H "
                     "per range (three streams).  end_to_end_ms: warm call from pageable host memory (the library "
                     "page-locks the two arrays per call; after one earlier call on the same arrays the pages are "
                     "resident and the device buffers cached); end_to_end_pinned_ms: from pinned memory; "

@@ -208,7 +208,7 @@ int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, in
                     int add_virtual_border, float* sdf_dev, void* workspace_dev,
                     size_t workspace_bytes, float* minmax_dev);
 /* As vgt_hip_sdf_dev, bracketing each kernel with HIP events on the context's stream.
- * kernel_ms[0..2] = Z-scan, Y-pass, X-pass(+finalize) durations of this call. Blocking. */
+ * kernel_ms[0..2] = pass 1 (class records), Y-pass, X-pass(+finalize) durations of this call. Blocking. */
 int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx,
                           int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
@@ -231,6 +231,13 @@ int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t cou
 /* Smallest grid (voxels) that the host-pointer SDF entry points pipeline (upload / kernels / download overlapped);
  * default 2^27, negative = never.  Lets the tests run that path on small grids. */
 int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels);
+/* Pass 1 alone, for a test of the record format itself (csrc/vgt_internal.hpp, ClassRecord): the class records of a
+ * device-resident occupancy grid, [x][64-voxel word][y] x 4 uint32 (mask_lo, mask_hi, below2, above2), into records_dev
+ * (vgt_hip_testing_class_record_bytes bytes); summary_dev (optional): the 4-byte slab summaries per line, in which case the
+ * records carry no one-class marks (a slab cannot know).  Blocking. */
+size_t vgt_hip_testing_class_record_bytes(int64_t nx, int64_t ny, int64_t nz);
+int vgt_hip_testing_class_records_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      int unknown_is_filled, int64_t z_offset, void* records_dev, void* summary_dev);
 #endif /* VGT_HIP_TESTING */
 
 /* ---- SDFs of the map types whose cells carry more than an occupancy ----
@@ -274,7 +281,7 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
  * Between start and stop every vgt_hip_sdf_dev call (or vgt_hip_sdf_slab_begin_dev /
  * _finish_dev pair called with kernel_ms == NULL) on this context records HIP events around its
  * kernels on the stream they run on, WITHOUT synchronising; stop waits for the stream once and
- * returns, per call, the milliseconds of {Z scan (+ slab fix-up), Y pass, X pass}.  Calls beyond
+ * returns, per call, the milliseconds of {pass 1 (+ slab record fix-up), Y pass, X pass}.  Calls beyond
  * max_calls are not recorded. */
 int vgt_hip_timing_start(vgt_hip_ctx* ctx, int32_t max_calls);
 int vgt_hip_timing_stop(vgt_hip_ctx* ctx, float* kernel_ms /* [max_calls][3] */,
@@ -342,7 +349,7 @@ int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, in
  * Lines along Y and X are local to a slab; only the first pass (nearest voxel of the other class
  * along Z) crosses slabs, and all it needs from the other slabs is, per (x, y) line, the nearest
  * filled / free voxel below and above.  So:
- *   1. vgt_hip_sdf_slab_begin_dev   local Z scan + per-line summary of this slab: 4 bytes per line.  A slab's
+ *   1. vgt_hip_sdf_slab_begin_dev   local pass 1 (class records) + per-line summary of this slab: 4 bytes per line.  A slab's
  *                                    first voxel is filled or free, so the record holds, for the slab's first and
  *                                    for its last voxel, the class (bit 15: filled) and the global z of the first /
  *                                    last voxel of the OTHER class inside the slab (bits 0-14, 0x7fff when absent)

@@ -537,3 +537,67 @@ def test_slab_finish_rejects_carries_of_another_slab(ctx):
         torch.cuda.synchronize()
     finally:
         ctx.reset_stream()
+
+
+def _records_reference(filled, mark_no_site):
+    """numpy restatement of the class-record format (csrc/vgt_internal.hpp): filled bool [nx, ny, nz] ->
+    uint32 [nx, nwords, ny, 4] = (mask_lo, mask_hi, below2, above2)."""
+    bias, none_below, none_above, no_site = 1 << 17, 0, 2 << 17, 0xFFFFFFF0
+    nx, ny, nz = filled.shape
+    nwords = (nz + 63) // 64
+    padded = np.concatenate([filled, np.repeat(filled[:, :, -1:], nwords * 64 - nz, axis=2)], axis=2)
+    bits = padded.reshape(nx, ny, nwords, 64).astype(np.uint64)
+    weights = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+    masks = (bits * weights).sum(axis=3, dtype=np.uint64)                       # [nx, ny, nwords]
+    out = np.zeros((nx, nwords, ny, 4), dtype=np.uint32)
+    out[..., 0] = (masks & np.uint64(0xFFFFFFFF)).astype(np.uint32).transpose(0, 2, 1)
+    out[..., 1] = (masks >> np.uint64(32)).astype(np.uint32).transpose(0, 2, 1)
+    trans = filled[:, :, :-1] != filled[:, :, 1:] if nz > 1 else np.zeros((nx, ny, 0), dtype=bool)
+    t = np.arange(max(nz - 1, 0))
+    last = np.maximum.accumulate(np.where(trans, t, -1), axis=2) if nz > 1 else trans.astype(np.int64)
+    nxt = np.minimum.accumulate(np.where(trans, t, 1 << 30)[:, :, ::-1], axis=2)[:, :, ::-1] if nz > 1 else last
+    any_transition = trans.any(axis=2)
+    for w in range(nwords):
+        begin = 64 * w
+        below = last[:, :, begin - 1] if begin >= 1 and nz > 1 else np.full((nx, ny), -1)
+        above = nxt[:, :, begin + 63] if begin + 63 <= nz - 2 else np.full((nx, ny), 1 << 30)
+        b2 = np.where(below < 0, none_below, 2 * (below - begin) + bias)
+        a2 = np.where(above >= (1 << 30), none_above, 2 * (above - begin) + bias)
+        if mark_no_site:
+            a2 = np.where(any_transition, a2, no_site)
+        out[:, w, :, 2] = b2.astype(np.uint32)
+        out[:, w, :, 3] = a2.astype(np.uint32)
+    return out
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1), (3, 5, 63), (3, 5, 64), (2, 7, 65), (5, 3, 128), (2, 9, 200), (3, 4, 1000),
+                                   (2, 6, 1024), (2, 5, 1025), (1, 3, 2048), (2, 2, 4096), (1, 3, 4097), (2, 2, 5000),
+                                   (37, 41, 130)])
+def test_class_records_against_the_format_definition(vctx, shape):
+    """Pass 1 alone (a hook of the testing library): the records of every kernel geometry -- 1 to 64 words per line, the
+    long-line kernel beyond 4096 voxels, partial last words, steps that straddle X planes -- against a numpy restatement
+    of the record format, with and without the one-class marks, plus the slab summaries that come with the latter."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    rng = np.random.default_rng(sum(shape) * 7 + 1)
+    nx, ny, nz = shape
+    occ = np.zeros(shape, dtype=np.float32)
+    runs = rng.random(shape) < (8.0 / max(nz, 8))                 # class changes every ~nz / 8 voxels
+    occ[np.cumsum(runs, axis=2) % 2 == 1] = 1.0
+    occ[rng.random((nx, ny)) < 0.3] = 0.0                         # lines of one class ...
+    occ[rng.random((nx, ny)) < 0.1] = 1.0
+    occ[rng.random(shape) < 0.01] = 0.5                           # ... and unknown cells (filled here)
+    filled = occ >= 0.5
+    occ_dev = torch.from_numpy(occ).cuda()
+    nbytes = capi.load(testing=True).vgt_hip_testing_class_record_bytes(nx, ny, nz)
+    nwords = (nz + 63) // 64
+    for with_summary in (False, True):
+        rec_dev = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+        summary = torch.zeros((nx * ny, 2), dtype=torch.int16, device="cuda") if with_summary else None
+        vctx.class_records(occ_dev.data_ptr(), shape, True, 5 if with_summary else 0, rec_dev.data_ptr(),
+                           summary.data_ptr() if with_summary else None)
+        got = rec_dev.cpu().numpy().view(np.uint32)[:nx * nwords * ny * 4].reshape(nx, nwords, ny, 4)
+        want = _records_reference(filled, mark_no_site=not with_summary)
+        assert np.array_equal(got, want), (shape, with_summary, np.argwhere(got != want)[:5])
+        if with_summary:
+            assert np.array_equal(summary.cpu().numpy(), multi_gpu.summary_reference(filled, 5)), shape

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Soak test on the GPU: the default line passes (lane-per-line sweeps, EDT variant 0) against the independent
-LDS-tiled envelope implementation (variant 2) on large device-resident grids, bit for bit, over many seeds,
-distributions and shapes -- sizes at which the CPU oracle would take minutes per case.  The two variants
-share the Z scan and nothing else, and tests/ pins both to the oracle at sizes the oracle finishes.
+"""Soak test on the GPU: the default pipeline of the PRODUCT library (class records + lane-per-line sweeps) against the
+independent LDS-tiled envelope implementation of the testing library (EDT variant 2, fed by the int16 Z scan) on large
+device-resident grids, bit for bit, over many seeds, distributions and shapes -- sizes at which the CPU oracle would take
+minutes per case.  The two pipelines share no kernel, and tests/ pins both to the oracle at sizes the oracle finishes.
 
 Usage: python tools/soak_variants.py [seeds]     (prints one line per case, exits non-zero on a mismatch)
 """
@@ -17,7 +17,8 @@ import torch
 import bench
 from voxelized_geometry_tools_amd import capi
 
-SHAPES = [(512, 512, 512), (1024, 512, 256), (300, 700, 1000), (2048, 256, 512), (1024, 1024, 128), (40, 2048, 2048)]
+SHAPES = [(512, 512, 512), (1024, 512, 256), (300, 700, 1000), (2048, 256, 512), (1024, 1024, 128), (40, 2048, 2048),
+          (96, 300, 4100), (200, 1500, 320)]
 CASES = [("spheres", 0.0), ("unknown_mix", 0.0), ("salt", 1e-4), ("salt", 1e-2), ("salt", 0.3), ("single", 0.0)]
 
 
@@ -36,6 +37,8 @@ def extract(ctx, occ, shape, variant, vb):
 def main():
     seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     dev = torch.device("cuda", 0)
+    product = capi.Context(0)
+    product.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx = capi.Context(0, testing=True)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     bad = 0
@@ -44,7 +47,7 @@ def main():
             for seed in range(seeds):
                 occ = bench.device_occupancy(torch, shape, dist, 1000 + seed, dev, salt_p=p or 0.01)
                 vb = bool(seed & 1)
-                a, ma = extract(ctx, occ, shape, 0, vb)
+                a, ma = extract(product, occ, shape, 0, vb)
                 b, mb = extract(ctx, occ, shape, 2, vb)
                 same = torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(
                     ma.view(torch.int32), mb.view(torch.int32))

@@ -109,6 +109,8 @@ TESTING_SIGNATURES = {
     "vgt_hip_set_edt_variant": (_int, [_p, _int]),
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_testing_set_host_pipeline_min_voxels": (_int, [ctypes.c_int64]),
+    "vgt_hip_testing_class_record_bytes": (_sz, [_i64, _i64, _i64]),
+    "vgt_hip_testing_class_records_dev": (_int, [_p, _p, _i64, _i64, _i64, _int, _i64, _p, _p]),
 }
 
 
@@ -293,7 +295,7 @@ class Context:
         check(self._lib.vgt_hip_timing_start(self.handle, int(max_calls)))
 
     def timing_stop(self):
-        """-> float32 array [calls, 3]: ms of (Z scan [+ slab fix-up], Y pass, X pass) per recorded call."""
+        """-> float32 array [calls, 3]: ms of (pass 1 [+ slab record fix-up], Y pass, X pass) per recorded call."""
         out = np.zeros((self._timing_capacity, 3), dtype=np.float32)
         n = ctypes.c_int32(0)
         check(self._lib.vgt_hip_timing_stop(self.handle, _ptr(out), ctypes.byref(n)))
@@ -306,6 +308,13 @@ class Context:
                 return
             raise VgtHipError("EDT variants other than 0 exist in libvgt_hip_testing.so only: Context(testing=True)")
         check(self._lib.vgt_hip_set_edt_variant(self.handle, int(variant)))
+
+    def class_records(self, occ_ptr, shape, unknown_is_filled=True, z_offset=0, records_ptr=None, summary_ptr=None):
+        """Testing library only: pass 1 alone (vgt_hip_testing_class_records_dev)."""
+        nx, ny, nz = shape
+        check(self._lib.vgt_hip_testing_class_records_dev(self.handle, _ptr(occ_ptr), nx, ny, nz,
+                                                          int(bool(unknown_is_filled)), int(z_offset), _ptr(records_ptr),
+                                                          _ptr(summary_ptr)))
 
     def set_host_pipeline_min_voxels(self, min_voxels):
         """Testing library only (process-wide there): smallest grid the host-pointer SDF entry points pipeline."""

@@ -934,6 +934,29 @@ int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels)
   g_host_pipeline_min_voxels.store(min_voxels);
   return VGT_HIP_OK;
 }
+
+size_t vgt_hip_testing_class_record_bytes(int64_t nx, int64_t ny, int64_t nz)
+{
+  if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return vgt::ClassRecordBytes(nx, ny, nz);
+}
+
+int vgt_hip_testing_class_records_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny, int64_t nz,
+                                      int unknown_is_filled, int64_t z_offset, void* records_dev, void* summary_dev)
+{
+  if (!ctx || !occupancy_dev || !records_dev) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int rc = CheckSdfShape(nx, ny, nz, 1.0);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::SdfParams p{nx, ny, nz, 1.0, unknown_is_filled ? 1 : 0, 0};
+  p.z_offset = z_offset;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  VGT_TRY_HIP(vgt::LaunchClassRecordsFromOccupancy(occupancy_dev, static_cast<vgt::ClassRecord*>(records_dev), p,
+                                                   static_cast<vgt::SlabLineSummary*>(summary_dev), ctx->stream),
+              "pass 1");
+  VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "synchronize");
+  return VGT_HIP_OK;
+}
 #endif  // VGT_HIP_TESTING
 
 /* ------------------------------ tracking grids ------------------------------ */
