@@ -544,13 +544,12 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     uint32_t prev_bit = 0;   // class of the row below this word
     uint32_t sw = 0;         // sign bits of the word being swept
     const int32_t n2m = 2 * (n - 1);
-    // A site at row q with cost f (already squared).  It is pushed when it beats the top before the last row
+    // A site at row q, as the hull point G = cost + q^2.  It is pushed when it beats the top before the last row
     // (G - Gt < 2 (n - 1) (q - rt)); a site that does not cannot pop the top either (the top beat ITS predecessor before
     // the last row when it was pushed, so its interval ends before the new site's would begin), and a site that pops
     // the top beats the entry below it even earlier: the one comparison against the top decides the push, and the pop
     // tests -- two 64-bit multiply-adds and a 64-bit compare each -- are only paid by sites that will be pushed.
-    auto site = [&](int q, int32_t f) {
-      const int32_t G = f + q * q;
+    auto site = [&](int q, int32_t G) {
       int32_t dG = G - Gt;
       int dr = q - rt;
       __builtin_assume(dr >= 0 && dr < 16384);  // (0: a site at row 0 against the row-0 sentinel)
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         if (f2 < 2u * static_cast<uint32_t>(kInf16))
         {
           const int32_t f = static_cast<int32_t>(f2 >> 1);
-          site(q, __mul24(f, f));
+          site(q, __mul24(f, f) + q * q);
         }
       };
       uint4 blk0 = load_block(0), blk1 = load_block(kBlock), blk2 = load_block(2 * kBlock);
@@ -768,6 +767,31 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       };
       int32_t nxt[kBand];
       load_band(nxt, 0);
+      // hull point of a row (valid: the row is a site)
+      auto decode = [&](int32_t v, int q, int32_t& G) -> bool {
+        // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
+        // sign and magnitude (bit 31 = class), which one `and` takes apart
+        int32_t f;
+        if constexpr (sizeof(InT) == 2)
+        {
+          const int32_t sign = v >> 31;
+          f = (v ^ sign) - sign;
+        }
+        else
+          f = v & 0x7fffffff;
+        // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
+        const bool valid = f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit);
+        if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
+        G = f + q * q;
+        return valid;
+      };
+      // A site whose hull point lies on or above the segment between its two NEIGHBOUR rows' points (2 G(q) >= G(q - 1) +
+      // G(q + 1), both sites) is not on the lower hull whatever else the line holds: it never touches the stack.  Along a
+      // stretch where G is concave -- the common case: every site would pop its predecessor and be popped by its
+      // successor -- that is every row but the ends.
+      int32_t G_prev = 0, G_cur = 0;
+      bool valid_prev = false;
+      bool valid_cur = decode(nxt[0], 0, G_cur);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
@@ -786,26 +810,18 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             if (!kGuard || r0 + k < n)
             {
               const int q = r0 + k;
-              const int32_t v = cur[k];
               // the class (bit 31 of either input format) is shifted in from the bottom by ONE instruction, (bits : v) >> 31;
               // the band's bits come out in reverse order and are turned round once per band below
-              bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(v), 31);
-              // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
-              // sign and magnitude (bit 31 = class), which one `and` takes apart
-              int32_t f;
-              if constexpr (sizeof(InT) == 2)
-              {
-                const int32_t sign = v >> 31;
-                f = (v ^ sign) - sign;
-              }
-              else
-                f = v & 0x7fffffff;
-              // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
-              if (f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit))
-              {
-                if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
-                site(q, f);
-              }
+              bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(cur[k]), 31);
+              int32_t G_next = 0;
+              bool valid_next = false;
+              if (q + 1 < n) valid_next = decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
+              const bool dropped = valid_prev && valid_next && (G_cur - G_prev >= G_next - G_cur);
+              if (valid_cur && !dropped) site(q, G_cur);
+              G_prev = G_cur;
+              valid_prev = valid_cur;
+              G_cur = G_next;
+              valid_cur = valid_next;
             }
           }
         };
