@@ -782,7 +782,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
         const bool valid = f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit);
         if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
-        G = f + q * q;
+        // (wrapping arithmetic: a row that is no site carries "infinity", its G is never looked at)
+        G = static_cast<int32_t>(static_cast<uint32_t>(f) + static_cast<uint32_t>(q * q));
         return valid;
       };
       // A site whose hull point lies on or above the segment between its two NEIGHBOUR rows' points (2 G(q) >= G(q - 1) +
@@ -816,7 +817,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               int32_t G_next = 0;
               bool valid_next = false;
               if (q + 1 < n) valid_next = decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
-              const bool dropped = valid_prev && valid_next && (G_cur - G_prev >= G_next - G_cur);
+              const int32_t rise_in = static_cast<int32_t>(static_cast<uint32_t>(G_cur) - static_cast<uint32_t>(G_prev));
+              const int32_t rise_out = static_cast<int32_t>(static_cast<uint32_t>(G_next) - static_cast<uint32_t>(G_cur));
+              const bool dropped = valid_prev && valid_next && rise_in >= rise_out;
               if (valid_cur && !dropped) site(q, G_cur);
               G_prev = G_cur;
               valid_prev = valid_cur;
