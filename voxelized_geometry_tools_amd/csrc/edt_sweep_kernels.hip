@@ -27,6 +27,12 @@
 //     bounding rows of the other class are running counters fed by the line's sign bits (one word per 32 rows, kept
 //     in the scratch buffer between the sweeps); waves whose 64 lines hold one class only skip that part.
 //   * X pass: fused sqrt / resolution / sign / virtual border / min-max as in the other variants.
+//   * The Y pass of the default pipeline does not read a distance field: its rows come as CLASS RECORDS (pass 1,
+//     edt_record_kernels.hip; vgt_internal.hpp) -- 64 rows per vector load, two blocks ahead -- and a lane's distance
+//     along Z is the minimum over the transitions around it, one v_sad_u32 each.  Rows whose lines hold one class only
+//     are marked by pass 1 and cost a few scalar instructions per band of 16.
+//   * A site on or above the segment between its two neighbour rows' hull points is not on the lower hull and never
+//     touches the stack (X pass and the int16-fed Y pass of the cross-check pipelines).
 //
 // The kernels are bound by instruction issue and by the latency of their dependent chains, not by HBM: rows are
 // processed kBand at a time (registers), the code below keeps rare paths (refills, exact final conversion) out of
