@@ -266,27 +266,53 @@ __device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, in
 #endif
 }
 
+// A copy by an instruction of its own.  Sweep 2's rare pop moves its register pairs one place up (second <- third); written
+// as plain assignments the compiler renames the registers instead and pays for it with two copies per ROW on the path
+// that does not pop.
+__device__ __forceinline__ int32_t FreshCopy(int32_t v)
+{
+#ifdef VGT_HOST_EMULATION
+  return v;
+#else
+  int32_t d;
+  asm("v_mov_b32 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+#endif
+}
+
 // The lane's element of a row of 4-byte values: wave-uniform base + 32-bit byte offset, the scalar-base addressing mode.
 // The empty asm keeps the zero-extension of the offset next to the access: hoisted out of the loop it reaches instruction
-// selection as a 64-bit register, and every access takes a 64-bit vector add and a vector address pair.  (X pass only:
-// the Y pass's 16-bit loads lose their sign extension to a separate instruction this way, and its stores gain nothing.)
-__device__ __forceinline__ uint32_t PinnedOffset(uint32_t byte_offset)
+// selection as a 64-bit register, and every access takes a 64-bit vector add and a vector address pair.  (Not for the 16-bit
+// loads of the cross-check Y pass: they lose their sign extension to a separate instruction this way.)
+// Stores pass the offset through the asm IN PLACE (one variable for all of them: the old value is dead, so no copy); loads
+// pin a copy, which costs a v_mov per load -- and measures 3.5 % FASTER on the X pass than the sixteen loads of a band
+// back to back (profiles/r4/experiments.md).
+template <bool kInPlace>
+__device__ __forceinline__ uint32_t PinnedOffset(uint32_t& byte_offset)
 {
 #ifndef VGT_HOST_EMULATION
-  asm volatile("" : "+v"(byte_offset));
+  if constexpr (kInPlace)
+    asm volatile("" : "+v"(byte_offset));
+  else
+  {
+    uint32_t copy = byte_offset;
+    asm volatile("" : "+v"(copy));
+    return copy;
+  }
 #endif
   return byte_offset;
 }
 template <typename T>
-__device__ __forceinline__ const VGT_GLOBAL T* LaneAddress(const VGT_GLOBAL T* row, uint32_t byte_offset)
+__device__ __forceinline__ const VGT_GLOBAL T* LaneAddress(const VGT_GLOBAL T* row, uint32_t& byte_offset)
 {
   return reinterpret_cast<const VGT_GLOBAL T*>(reinterpret_cast<const VGT_GLOBAL unsigned char*>(row) +
-                                                PinnedOffset(byte_offset));
+                                                PinnedOffset<false>(byte_offset));
 }
 template <typename T>
-__device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t byte_offset)
+__device__ __forceinline__ VGT_GLOBAL T* LaneAddress(VGT_GLOBAL T* row, uint32_t& byte_offset)
 {
-  return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) + PinnedOffset(byte_offset));
+  return reinterpret_cast<VGT_GLOBAL T*>(reinterpret_cast<VGT_GLOBAL unsigned char*>(row) +
+                                         PinnedOffset<true>(byte_offset));
 }
 
 // |a - b| + 1 with b the same in every lane.  Written so that the compiler selects ONE v_sad_u32 with a scalar operand
@@ -423,6 +449,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
   const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
+  [[maybe_unused]] uint32_t lane_bytes = zl * 4u;  // the lane's byte offset inside a row of 4-byte values (see LaneAddress)
   // (records: [outer][64-voxel segment][row], one per row of this item)
   const InT* const wave_in = kRecords ? in + static_cast<int64_t>(item) * n
                                       : in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
@@ -558,7 +585,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     auto site = [&](int q, int32_t G) {
       int32_t dG = G - Gt;
       int dr = q - rt;
-      __builtin_assume(dr >= 0 && dr < 16384);  // (0: a site at row 0 against the row-0 sentinel)
+      // (no __builtin_assume(dr >= 0) here: knowing the sign, the compiler multiplies unsigned and corrects -- three
+      // multiply-adds and three moves for the first hull test of a row instead of two multiply-adds)
       if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
       {
         if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
@@ -756,7 +784,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, lane_bytes) : &row_in[zl]));
             row_in = UniformPointer(row_in + rstride);
           }
         }
@@ -766,7 +794,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, zl * 4u) : &row_in[zl]));
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, lane_bytes) : &row_in[zl]));
             if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
           }
         }
@@ -822,7 +850,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(cur[k]), 31);
               int32_t G_next = 0;
               bool valid_next = false;
-              if (q + 1 < n) valid_next = decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
+              // (every row of a full band but its last has a successor: no test)
+              if ((!kGuard && k + 1 < kBand) || q + 1 < n)
+                valid_next = decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
               const int32_t rise_in = static_cast<int32_t>(static_cast<uint32_t>(G_cur) - static_cast<uint32_t>(G_prev));
               const int32_t rise_out = static_cast<int32_t>(static_cast<uint32_t>(G_next) - static_cast<uint32_t>(G_cur));
               const bool dropped = valid_prev && valid_next && rise_in >= rise_out;
@@ -883,12 +913,12 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         const uint32_t sign = (sw >> k) << 31;
         if constexpr (kFinal)
         {
-          VGT_STREAM_STORE(__uint_as_float(0x7f800000u | sign), LaneAddress(row_out, zl * 4u));
+          VGT_STREAM_STORE(__uint_as_float(0x7f800000u | sign), LaneAddress(row_out, lane_bytes));
         }
         else
         {
           // (sign and magnitude, like the general evaluation)
-          VGT_STREAM_STORE(static_cast<OutT>(static_cast<uint32_t>(kInf32) | sign), &row_out[zl]);
+          VGT_STREAM_STORE(static_cast<OutT>(static_cast<uint32_t>(kInf32) | sign), LaneAddress(row_out, lane_bytes));
         }
         row_out = UniformPointer(row_out - rstride);
       }
@@ -946,8 +976,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #endif
       Gt += nB;
       rt -= A;
-      A = A2;
-      nB = nB2;
+      A = FreshCopy(A2);
+      nB = FreshCopy(nB2);
       A2 = (rt - A) - C::Row(e4);
       nB2 = C::G(e4) - (Gt + nB);
       D -= kSlot;
@@ -1121,7 +1151,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                 for (int j = kGroup - 1; j >= 0; j--)
                 {
                   value[j] = __uint_as_float(__float_as_uint(dist[j]) | (static_cast<uint32_t>(grp_sign[j]) & 0x80000000u));
-                  VGT_STREAM_STORE(value[j], LaneAddress(store_at, zl * 4u));
+                  VGT_STREAM_STORE(value[j], LaneAddress(store_at, lane_bytes));
                   store_at = UniformPointer(store_at - rstride);
                 }
                 row_out = store_at;
@@ -1151,7 +1181,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #if VGT_SWEEP_EXP & 64
               if (d2 == 0x12345679)  // (experiment: the evaluation without its stores)
 #endif
-              VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), &row_out[zl]);
+              VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), LaneAddress(row_out, lane_bytes));
               row_out = UniformPointer(row_out - rstride);
             }
           }
