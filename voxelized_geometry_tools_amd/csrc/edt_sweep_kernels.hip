@@ -266,6 +266,24 @@ __device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, in
 #endif
 }
 
+// Calibration builds (-DVGT_SWEEP_BALLAST_S=n / -DVGT_SWEEP_BALLAST_V=n): n scalar / vector instructions of ballast per row of
+// either sweep -- what a pass pays per instruction of each kind (profiles/r4/experiments.md).
+#ifndef VGT_SWEEP_BALLAST_S
+#define VGT_SWEEP_BALLAST_S 0
+#endif
+#ifndef VGT_SWEEP_BALLAST_V
+#define VGT_SWEEP_BALLAST_V 0
+#endif
+__device__ __forceinline__ void RowBallast([[maybe_unused]] uint32_t& scalar_sink, [[maybe_unused]] uint32_t& vector_sink)
+{
+#ifndef VGT_HOST_EMULATION
+#pragma unroll
+  for (int i = 0; i < VGT_SWEEP_BALLAST_S; i++) asm volatile("s_cmp_eq_u32 0, 0" : : : "scc");  // (writes the condition bit only)
+#pragma unroll
+  for (int i = 0; i < VGT_SWEEP_BALLAST_V; i++) asm volatile("v_add_u32 %0, 1, %0" : "+v"(vector_sink));
+#endif
+}
+
 // A copy by an instruction of its own.  Sweep 2's rare pop moves its register pairs one place up (second <- third); written
 // as plain assignments the compiler renames the registers instead and pays for it with two copies per ROW on the path
 // that does not pop.
@@ -419,6 +437,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
   float lo_value = INFINITY, hi_value = -INFINITY;
+  [[maybe_unused]] uint32_t ballast_s = 0, ballast_v = 0;
 #ifdef VGT_HOST_EMULATION
   int emulated_round = 0;
 #endif
@@ -582,12 +601,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     // the last row when it was pushed, so its interval ends before the new site's would begin), and a site that pops
     // the top beats the entry below it even earlier: the one comparison against the top decides the push, and the pop
     // tests -- two 64-bit multiply-adds and a 64-bit compare each -- are only paid by sites that will be pushed.
-    auto site = [&](int q, int32_t G) {
+    // (`wanted`: what the caller knows against the site, folded into the same test -- one exec-mask region per row, not two)
+    auto site = [&](int q, int32_t G, bool wanted) {
       int32_t dG = G - Gt;
       int dr = q - rt;
       // (no __builtin_assume(dr >= 0) here: knowing the sign, the compiler multiplies unsigned and corrects -- three
       // multiply-adds and three moves for the first hull test of a row instead of two multiply-adds)
-      if (dG < static_cast<int32_t>(__umul24(n2m, dr)))
+      if (static_cast<int>(wanted) & static_cast<int>(dG < static_cast<int32_t>(__umul24(n2m, dr))))
       {
         if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
         {
@@ -614,6 +634,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         rt = q;
         D += kSlot;
       }
+#ifndef VGT_HOST_EMULATION
+      // (Opaque: otherwise the compiler forwards "the next row's G - Gt is its rise over this row where this row was pushed"
+      // through the merge and pays for the one saved subtraction with an else-region -- three scalar instructions -- per row.)
+      asm volatile("" : "+v"(Gt));
+#endif
     };
     // the band [r0, r0 + kBand) has been swept: its sign bits join the word, a complete word goes to the scratch
     auto band_done = [&](int r0, uint32_t bits) {
@@ -713,11 +738,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             own &= own - 1ull;
           } while (own != 0ull);
         }
-        if (f2 < 2u * static_cast<uint32_t>(kInf16))
-        {
-          const int32_t f = static_cast<int32_t>(f2 >> 1);
-          site(q, __mul24(f, f) + q * q);
-        }
+        // (a lane without any transition around it: f = kInf16 - 1 or more, its square is never pushed -- `wanted` says so)
+        const int32_t f = static_cast<int32_t>(f2 >> 1);
+        site(q, __mul24(f, f) + q * q, f2 < 2u * static_cast<uint32_t>(kInf16));
       };
       uint4 blk0 = load_block(0), blk1 = load_block(kBlock), blk2 = load_block(2 * kBlock);
       uint64_t marks = 0, filled = 0;
@@ -801,8 +824,12 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       };
       int32_t nxt[kBand];
       load_band(nxt, 0);
-      // hull point of a row (valid: the row is a site)
-      auto decode = [&](int32_t v, int q, int32_t& G) -> bool {
+      // Hull point of a row.  A row that is no site gets G = kNoSiteG + q^2: above every real hull point by more than any
+      // site can make up before the last row (site()'s first test rejects it: kNoSiteG - G > 2 (n - 1)^2 for every real G of
+      // either entry kind) and small enough that differences of two hull points never overflow.  So no row needs a "valid"
+      // flag: the neighbour test below and site() see an ordinary, hopeless point.
+      constexpr int32_t kNoSiteG = 0x60000000;
+      auto decode = [&](int32_t v, int q, int32_t& G) {
         // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
         // sign and magnitude (bit 31 = class), which one `and` takes apart
         int32_t f;
@@ -813,20 +840,21 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         }
         else
           f = v & 0x7fffffff;
-        // (pass-1 distances are below kInf16 < kLimit; squared distances of the X pass's input below kLimit)
-        const bool valid = f < (sizeof(InT) == 2 ? static_cast<int32_t>(kInf16) : kLimit);
-        if constexpr (sizeof(InT) == 2) f = __mul24(f, f);
-        // (wrapping arithmetic: a row that is no site carries "infinity", its G is never looked at)
-        G = static_cast<int32_t>(static_cast<uint32_t>(f) + static_cast<uint32_t>(q * q));
-        return valid;
+        // (pass-1 distances are below kInf16; the X pass's input holds squared distances below kLimit or kInf32)
+        if constexpr (sizeof(InT) == 2)
+          f = (f < static_cast<int32_t>(kInf16)) ? __mul24(f, f) : kNoSiteG;
+        else
+          f = static_cast<int32_t>(min(static_cast<uint32_t>(f), static_cast<uint32_t>(kNoSiteG)));
+        G = f + q * q;
       };
       // A site whose hull point lies on or above the segment between its two NEIGHBOUR rows' points (2 G(q) >= G(q - 1) +
       // G(q + 1), both sites) is not on the lower hull whatever else the line holds: it never touches the stack.  Along a
       // stretch where G is concave -- the common case: every site would pop its predecessor and be popped by its
       // successor -- that is every row but the ends.
-      int32_t G_prev = 0, G_cur = 0;
-      bool valid_prev = false;
-      bool valid_cur = decode(nxt[0], 0, G_cur);
+      // (with "no site" as a huge hull point the test needs no flags: next to such a neighbour the site is kept, and a row
+      // that is no site itself is dropped here or rejected by site())
+      int32_t G_prev = kNoSiteG, G_cur = 0;
+      decode(nxt[0], 0, G_cur);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
@@ -845,22 +873,16 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             if (!kGuard || r0 + k < n)
             {
               const int q = r0 + k;
+              if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0) RowBallast(ballast_s, ballast_v);
               // the class (bit 31 of either input format) is shifted in from the bottom by ONE instruction, (bits : v) >> 31;
               // the band's bits come out in reverse order and are turned round once per band below
               bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(cur[k]), 31);
-              int32_t G_next = 0;
-              bool valid_next = false;
+              int32_t G_next = kNoSiteG + (q + 1) * (q + 1);  // (past the last row: no site)
               // (every row of a full band but its last has a successor: no test)
-              if ((!kGuard && k + 1 < kBand) || q + 1 < n)
-                valid_next = decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
-              const int32_t rise_in = static_cast<int32_t>(static_cast<uint32_t>(G_cur) - static_cast<uint32_t>(G_prev));
-              const int32_t rise_out = static_cast<int32_t>(static_cast<uint32_t>(G_next) - static_cast<uint32_t>(G_cur));
-              const bool dropped = valid_prev && valid_next && rise_in >= rise_out;
-              if (valid_cur && !dropped) site(q, G_cur);
+              if ((!kGuard && k + 1 < kBand) || q + 1 < n) decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
+              site(q, G_cur, G_cur - G_prev < G_next - G_cur);
               G_prev = G_cur;
-              valid_prev = valid_cur;
               G_cur = G_next;
-              valid_cur = valid_next;
             }
           }
         };
@@ -1057,6 +1079,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           {
             const int q = r0 + k;
             const int q2 = 2 * q;
+            if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0) RowBallast(ballast_s, ballast_v);
             // t1 = value of the second entry at row q minus the top's, t2 = the third's minus the second's
             // (rows and row differences are below 2^14: plain unsigned 24-bit multiplies)
             __builtin_assume(A >= 0 && A < 16384 && A2 >= 0 && A2 < 16384 && rt >= 0 && rt < 16384);
@@ -1215,6 +1238,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     atomicAdd(&g_sweep_exit[kFinal ? 1 : 0][3], 1ull);
   }
 #endif
+  if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0)
+  {
+    if (ballast_s + ballast_v == 0x12345u) lo_value = 0.0f;  // (keeps the sinks alive)
+  }
   if constexpr (kFinal)
   {
     uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
