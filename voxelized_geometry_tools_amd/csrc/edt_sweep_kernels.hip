@@ -521,8 +521,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     }
     pf_count = 0;
   };
-  // top <- second <- third <- ring (the sentinels are never popped, so the third always exists)
-  auto pop = [&]() {
+  // top <- second <- third <- ring (the sentinels are never popped, so the third always exists).  Sweep 1 pops only on behalf
+  // of a site that is then pushed, and a push leaves the third entry in its register: a row's FIRST pop finds it there
+  // (`third_in_register`), every further pop of the row reads the ring -- neither needs a test.
+  auto pop = [&](auto third_in_register) {
 #ifdef VGT_SWEEP_STATS
     {
       const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
@@ -531,12 +533,19 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         VGT_SWEEP_COUNT(stat_phase == 0 ? 7 : 8, 1);
     }
 #endif
-    // Most pops of sweep 1 are followed by a push, which sets the third entry itself: the ring is read only when a pop
-    // finds the third entry not loaded (a second pop in a row, or a pop after a row that popped without pushing).
     Gt += nB;
     rt -= A;
-    if (__builtin_expect(C::IsUnknown(e3), 0))
+    if constexpr (decltype(third_in_register)::value)
     {
+#ifdef VGT_HOST_EMULATION
+      assert(!C::IsUnknown(e3));
+#endif
+    }
+    else
+    {
+#ifdef VGT_HOST_EMULATION
+      assert(C::IsUnknown(e3));
+#endif
       if (__builtin_expect(D - 3 * kSlot < L, 0)) refill_now();
       e3 = ring_ref(D - 3 * kSlot);
     }
@@ -612,14 +621,14 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         if (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0)
         {
           // (one pop is the common case: it is laid out as straight code, further pops out of line)
-          pop();
+          pop(std::true_type{});
           dG = G - Gt;
           dr = q - rt;
           if (__builtin_expect(static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0, 0))
           {
             do
             {
-              pop();
+              pop(std::false_type{});
               dG = G - Gt;
               dr = q - rt;
             } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
