@@ -722,30 +722,32 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       auto row = [&](int q, const uint4& rec, uint32_t& bits) {
         const uint64_t m = (static_cast<uint64_t>(rec.y) << 32) | rec.x;
         bits = __builtin_amdgcn_alignbit(SpreadLaneMask(m, lane), bits, 1);  // shifted in from the top
-        // the word's own transitions: the first two inline, more (rare) in a loop
-        uint64_t own = (m ^ (m >> 1)) & 0x7fffffffffffffffull;
-        uint32_t t1 = rec.z, t2 = rec.z;
-        if (own)
+        // The two transitions the record names, then the word's own (most words have none: one scalar test; two are the common
+        // case of a word that has any -- in and out of an obstacle -- and sit inline, more in a loop out of line).
+        uint32_t f2 = min(AbsDiffPlusOne(xq, rec.z), AbsDiffPlusOne(xq, rec.w));
+        // (a word of one class is all zeros or all ones: its own sign bit, spread)
+        if (__builtin_expect(static_cast<int64_t>(m) != (static_cast<int64_t>(m) >> 63), 0))
         {
-          t1 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
+          uint64_t own = (m ^ (m >> 1)) & 0x7fffffffffffffffull;
+          const uint32_t t1 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
           own &= own - 1ull;
-        }
-        if (own)
-        {
-          t2 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
-          own &= own - 1ull;
-        }
-        uint32_t f2 = min(min(AbsDiffPlusOne(xq, rec.z), AbsDiffPlusOne(xq, rec.w)),
-                          min(AbsDiffPlusOne(xq, t1), AbsDiffPlusOne(xq, t2)));
-        if (__builtin_expect(own != 0ull, 0))
-        {
-          VGT_COLD_PATH();
-          do
+          uint32_t t2 = t1;
+          if (own)
           {
-            const uint32_t t = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
-            f2 = min(f2, AbsDiffPlusOne(xq, t));
+            t2 = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
             own &= own - 1ull;
-          } while (own != 0ull);
+          }
+          f2 = min(f2, min(AbsDiffPlusOne(xq, t1), AbsDiffPlusOne(xq, t2)));
+          if (__builtin_expect(own != 0ull, 0))
+          {
+            VGT_COLD_PATH();
+            do
+            {
+              const uint32_t t = 2u * static_cast<uint32_t>(__ffsll(static_cast<long long>(own)) - 1) + kRecordBias;
+              f2 = min(f2, AbsDiffPlusOne(xq, t));
+              own &= own - 1ull;
+            } while (own != 0ull);
+          }
         }
         // (a lane without any transition around it: f = kInf16 - 1 or more, its square is never pushed -- `wanted` says so)
         const int32_t f = static_cast<int32_t>(f2 >> 1);
