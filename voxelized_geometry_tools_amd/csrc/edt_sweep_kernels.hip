@@ -390,7 +390,24 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 __device__ unsigned long long g_sweep_item_bins[2][2][32];
 __device__ unsigned long long g_sweep_exit[2][4];  // [pass]: first item start (min), last exit (max), sum of exits, waves
 #endif
-#ifdef VGT_SWEEP_STATS
+#ifdef VGT_SWEEP_PHASES
+// diagnostic build (-DVGT_SWEEP_PHASES, tools/sweep_phases.py): where a wave's time goes, in shader-clock ticks of s_memtime summed
+// over the waves (lane 0 adds): [0] sweep 1, waiting for the band's rows at the top of a band (all loads drained),
+// [1] sweep 1, the ring checks, [2] sweep 1, the rows, [3] sweep 2, the refill steps, [4] sweep 2, the rows,
+// [5] items (whole), [6] the first band's loads, [7] between the sweeps.  Read with vgt_hip_debug_sweep_stats.
+__device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X pass
+#define VGT_SWEEP_COUNT(i, v)
+#define VGT_PHASE_MARK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+// (summed in registers, added to the global counters once per item: an atomic per mark would be what gets measured)
+#define VGT_PHASE_ADD(i, from, to) phase_acc[i] += static_cast<unsigned long long>((to) - (from))
+#define VGT_PHASE_FLUSH()                                                                                \
+  do                                                                                                     \
+  {                                                                                                      \
+    if (lane == 0)                                                                                       \
+      for (int phase_i = 0; phase_i < 8; phase_i++) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + phase_i], phase_acc[phase_i]); \
+  } while (0)
+#define VGT_PHASE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#elif defined(VGT_SWEEP_STATS)
 // diagnostic build: [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the same in
 // sweep 2, [4] spilled chunks (lanes), [6] exact conversions (wave events), [7] / [8] wave-level pop iterations in
 // sweep 1 / 2, [9] waves with class changes, [10] waves, [11] / [12] lane pops in sweep 1 / 2, [13] lane pushes
@@ -398,6 +415,12 @@ __device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X 
 #define VGT_SWEEP_COUNT(i, v) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + (i)], static_cast<unsigned long long>(v))
 #else
 #define VGT_SWEEP_COUNT(i, v)
+#endif
+#ifndef VGT_SWEEP_PHASES
+#define VGT_PHASE_MARK(var)
+#define VGT_PHASE_ADD(i, from, to)
+#define VGT_PHASE_DRAIN()
+#define VGT_PHASE_FLUSH()
 #endif
 
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
@@ -464,6 +487,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const unsigned long long item_begin = wall_clock64();
   if (lane == 0) atomicMin(&g_sweep_exit[kFinal ? 1 : 0][0], item_begin);
 #endif
+#ifdef VGT_SWEEP_PHASES
+  unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  VGT_PHASE_MARK(phase_item_begin);
   const int outer = item / g.zsegs;
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
@@ -834,7 +861,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         }
       };
       int32_t nxt[kBand];
+      VGT_PHASE_MARK(phase_first_a);
       load_band(nxt, 0);
+      VGT_PHASE_DRAIN();
+      VGT_PHASE_MARK(phase_first_b);
+      VGT_PHASE_ADD(6, phase_first_a, phase_first_b);
       // Hull point of a row.  A row that is no site gets G = kNoSiteG + q^2: above every real hull point by more than any
       // site can make up before the last row (site()'s first test rejects it: kNoSiteG - G > 2 (n - 1)^2 for every real G of
       // either entry kind) and small enough that differences of two hull points never overflow.  So no row needs a "valid"
@@ -870,6 +901,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
         int32_t cur[kBand];
+        VGT_PHASE_MARK(phase_top_a);
+        VGT_PHASE_DRAIN();
+        VGT_PHASE_MARK(phase_top_b);
+        VGT_PHASE_ADD(0, phase_top_a, phase_top_b);
 #pragma unroll
         for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
         if (r0 + kBand < n) load_band(nxt, r0 + kBand);
@@ -879,7 +914,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            if (k % kChunk == 0) check_ring();
+            if (k % kChunk == 0)
+            {
+              VGT_PHASE_MARK(phase_ring_a);
+              check_ring();
+              VGT_PHASE_MARK(phase_ring_b);
+              VGT_PHASE_ADD(1, phase_ring_a, phase_ring_b);
+            }
             if (kGuard && r0 + k >= n) bits <<= 1;  // (keeps the rows of a partial band at their bit positions)
             if (!kGuard || r0 + k < n)
             {
@@ -897,10 +938,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             }
           }
         };
+        VGT_PHASE_MARK(phase_rows_a);
         if (r0 + kBand <= n)
           rows(std::false_type{});
         else
           rows(std::true_type{});
+        VGT_PHASE_MARK(phase_rows_b);
+        VGT_PHASE_ADD(2, phase_rows_a, phase_rows_b);
         band_done(r0, __builtin_bitreverse32(bits));  // (row k of the band: bit kBand - 1 - k -> bit 32 - kBand + k)
       }
     }
@@ -1072,7 +1116,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
-          if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4)) refill_step();
+          if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4))
+          {
+            VGT_PHASE_MARK(phase_refill_a);
+            refill_step();
+            VGT_PHASE_MARK(phase_refill_b);
+            VGT_PHASE_ADD(3, phase_refill_a, phase_refill_b);
+          }
           if (kClasses && k % 8 == 7)
           {
             const int first = sub + k - 7;  // position of the group's first row in the word
@@ -1221,12 +1271,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           }
         }
       };
+      VGT_PHASE_MARK(phase_eval_a);
       if (r0 + kBand > n)
         rows(std::true_type{}, std::true_type{});  // (the partial band: one copy, the candidates are "far" without classes)
       else if (classes || any_empty)
         rows(std::false_type{}, std::true_type{});
       else
         rows(std::false_type{}, std::false_type{});
+      VGT_PHASE_MARK(phase_eval_b);
+      VGT_PHASE_ADD(4, phase_eval_a, phase_eval_b);
       if (classes) dn = min(dn, kFar);
     }
   }
@@ -1239,6 +1292,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     atomicAdd(&g_sweep_item_bins[kFinal ? 1 : 0][classes ? 1 : 0][bin], 1ull);
   }
 #endif
+  {
+    VGT_PHASE_MARK(phase_item_end);
+    VGT_PHASE_ADD(5, phase_item_begin, phase_item_end);
+    VGT_PHASE_FLUSH();
+  }
   }  // next unit of work
 #ifdef VGT_SWEEP_TIMING
   if (lane == 0)
@@ -1474,7 +1532,7 @@ extern "C" int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned l
 }
 #endif
 
-#ifdef VGT_SWEEP_STATS
+#if defined(VGT_SWEEP_STATS) || defined(VGT_SWEEP_PHASES)
 extern "C" int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
 {
   hipError_t err = hipDeviceSynchronize();
