@@ -515,6 +515,21 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   auto ring_ref = [&](uint32_t scaled_index) -> Entry& {
     return *reinterpret_cast<Entry*>(ring_bytes + ((scaled_index & kRingMask) | lane_entry));
   };
+  // The ring slots of the chunk that starts at entry `first` (scaled like D and L; a multiple of kChunk, as every lo is):
+  // contiguous in the ring -- its size is a multiple of the chunk's -- so ONE address serves the chunk's entries, as
+  // base[j * kWaveSize] (an immediate offset of the LDS instruction; addressed entry by entry each costs two instructions).
+  // (32-bit entries only: the paired 64-bit LDS accesses the compiler makes of it measure 1 % slower on config 5 than
+  // entry-by-entry addresses, which the 64-bit kind keeps.)
+  auto chunk_in_ring = [&](uint32_t scaled_first) -> Entry* {
+    return reinterpret_cast<Entry*>(ring_bytes + ((scaled_first & kRingMask) | lane_entry));
+  };
+  auto chunk_slot = [&](Entry* slots, uint32_t scaled_first, int j) -> Entry& {
+    if constexpr (kPacked)
+      return slots[j * kWaveSize];
+    else
+      return ring_ref(scaled_first + (static_cast<uint32_t>(j) << kShift));
+  };
+  static_assert(kRing % kChunk == 0, "a chunk must not wrap inside the ring");
   auto spill_ptr = [&](uint32_t scaled_first) -> Entry* {
     return reinterpret_cast<Entry*>(wave_spill + (scaled_first + lane_chunk));
   };
@@ -539,12 +554,13 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #endif
     L -= kChunkSlots;
     const Entry* src = spill_ptr(L);
+    Entry* const slots = chunk_in_ring(L);
 #pragma unroll 1
     for (int j = 0; j < kChunk; j += 2)
     {
       const Entry a = src[j], b = src[j + 1];
-      ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = a;
-      ring_ref(L + (static_cast<uint32_t>(j + 1) << kShift)) = b;
+      chunk_slot(slots, L, j) = a;
+      chunk_slot(slots, L, j + 1) = b;
     }
     pf_count = 0;
   };
@@ -583,8 +599,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   };
   auto commit = [&](const Entry (&buf)[kChunk]) {
     L -= kChunkSlots;
+    Entry* const slots = chunk_in_ring(L);
 #pragma unroll
-    for (int j = 0; j < kChunk; j++) ring_ref(L + (static_cast<uint32_t>(j) << kShift)) = buf[j];
+    for (int j = 0; j < kChunk; j++) chunk_slot(slots, L, j) = buf[j];
   };
 
   // =====================================================================================================
@@ -618,8 +635,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           if (D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift))
           {
             Entry buf[kChunk];
+            Entry* const slots = chunk_in_ring(L);
 #pragma unroll
-            for (int j = 0; j < kChunk; j++) buf[j] = ring_ref(L + (static_cast<uint32_t>(j) << kShift));
+            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, L, j);
             StoreChunk(spill_ptr(L), buf);
             L += kChunkSlots;
             VGT_SWEEP_COUNT(4, 1);
