@@ -613,8 +613,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     auto check_ring = [&]() {
       // nothing to do while no request is pending, the ring has room and is not about to run dry
       const uint32_t resident = D - L;
-      const bool busy = pf_count != 0 || (L != 0 && resident <= kChunkSlots) ||
-                        resident > (static_cast<uint32_t>(kRing - kChunk) << kShift);
+      // (bitwise, not short-circuit: the compiler turns `||` / `&&` of these comparisons into nested exec-mask regions)
+      const bool busy = static_cast<int>(pf_count != 0) |
+                        (static_cast<int>(L != 0) & static_cast<int>(resident <= kChunkSlots)) |
+                        static_cast<int>(resident > (static_cast<uint32_t>(kRing - kChunk) << kShift));
       if (__builtin_amdgcn_ballot_w64(busy) != 0ull)
       {
         // a chunk requested at the last check goes into the ring (the ring had at most kChunk entries then and
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           pf_count = 0;
         }
         // a ring that pops have nearly emptied asks for the chunk below it before a pop has to wait for it
-        if (L != 0 && D - L <= kChunkSlots)
+        if (static_cast<int>(L != 0) & static_cast<int>(D - L <= kChunkSlots))
         {
           LoadChunk(spill_ptr(L - kChunkSlots), pf0);
           pf_count = 1;
@@ -1025,18 +1027,22 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     // when the ring has room (between two steps the ring only shrinks).
     pf_count = 0;  // (sweep 1 may leave a request behind: dropped)
     auto refill_step = [&]() {
-      if (__builtin_amdgcn_ballot_w64(pf_count != 0 ||
-                                      (L != 0 && D - L <= (static_cast<uint32_t>(kRing - kChunk) << kShift))) != 0ull)
+      // (bitwise, not short-circuit: see check_ring)
+      const bool refilling =
+          static_cast<int>(pf_count != 0) |
+          (static_cast<int>(L != 0) & static_cast<int>(D - L <= (static_cast<uint32_t>(kRing - kChunk) << kShift)));
+      if (__builtin_amdgcn_ballot_w64(refilling) != 0ull)
       {
         if (pf_count > 0) commit(pf0);
         if (pf_count > 1) commit(pf1);
         pf_count = 0;
         const uint32_t resident = D - L;  // (after the commits)
-        if (L != 0 && resident <= (static_cast<uint32_t>(kRing - kChunk) << kShift))
+        if (static_cast<int>(L != 0) & static_cast<int>(resident <= (static_cast<uint32_t>(kRing - kChunk) << kShift)))
         {
           LoadChunk(spill_ptr(L - kChunkSlots), pf0);
           pf_count = 1;
-          if (L != kChunkSlots && resident <= (static_cast<uint32_t>(kRing - 2 * kChunk) << kShift))
+          if (static_cast<int>(L != kChunkSlots) &
+              static_cast<int>(resident <= (static_cast<uint32_t>(kRing - 2 * kChunk) << kShift)))
           {
             LoadChunk(spill_ptr(L - 2 * kChunkSlots), pf1);
             pf_count = 2;
