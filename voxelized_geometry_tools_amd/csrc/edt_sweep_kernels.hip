@@ -32,7 +32,11 @@
 //     along Z is the minimum over the transitions around it, one v_sad_u32 each.  Rows whose lines hold one class only
 //     are marked by pass 1 and cost a few scalar instructions per band of 16.
 //   * A site on or above the segment between its two neighbour rows' hull points is not on the lower hull and never
-//     touches the stack (X pass and the int16-fed Y pass of the cross-check pipelines).
+//     touches the stack (X pass and the int16-fed Y pass of the cross-check pipelines).  A row that is no site is a hull
+//     point far above every real one there (kNoSiteG): the same two comparisons handle it, no validity flags.
+//   * What the listing taught (profiles/r4/experiments.md): a row pays for exec-mask regions and scalar flag logic more
+//     than for vector instructions; a chunk of the ring is addressed ONCE (it never wraps), which turns its eight LDS
+//     accesses into four paired instructions; conditions of rare paths are combined bitwise, not with || and &&.
 //
 // The kernels are bound by instruction issue and by the latency of their dependent chains, not by HBM: rows are
 // processed kBand at a time (registers), the code below keeps rare paths (refills, exact final conversion) out of
