@@ -278,7 +278,8 @@ __device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, in
 #ifndef VGT_SWEEP_BALLAST_V
 #define VGT_SWEEP_BALLAST_V 0
 #endif
-__device__ __forceinline__ void RowBallast([[maybe_unused]] uint32_t& scalar_sink, [[maybe_unused]] uint32_t& vector_sink)
+[[maybe_unused]] __device__ __forceinline__ void RowBallast([[maybe_unused]] uint32_t& scalar_sink,
+                                                            [[maybe_unused]] uint32_t& vector_sink)
 {
 #ifndef VGT_HOST_EMULATION
 #pragma unroll
