@@ -355,6 +355,30 @@ def test_long_axes(ctx, vctx, oracle, shape):
         assert (lo, hi) == (wlo, whi)
 
 
+@pytest.mark.parametrize("shape", [(16384, 2, 70), (3, 16384, 65), (2, 3, 16384)])
+def test_longest_axis(ctx, oracle, shape):
+    """The per-axis limit itself (16384 voxels: rows up to 16383, the bound the 64-bit stack entries, the "no site" hull
+    point and the 24-bit multiplies of the sweeps are sized for), on every axis, with sites at the far ends, lines without
+    any site and a sparse random field."""
+    rng = np.random.default_rng(sum(shape))
+    fields = []
+    occ = np.zeros(shape, dtype=np.float32)
+    occ[0, 0, 0] = 1.0
+    fields.append(occ)
+    occ = np.zeros(shape, dtype=np.float32)
+    occ[-1, -1, -1] = 1.0
+    occ[0, 0, shape[2] // 2] = 1.0
+    fields.append(occ)
+    occ = (rng.random(shape) < 0.0005).astype(np.float32)
+    occ[:, 0, :] = 0.0  # (lines without any site next to lines with some)
+    fields.append(occ)
+    for occ in fields:
+        want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.05)
+        got, lo, hi = ctx.sdf_from_occupancy(occ, 0.05)
+        assert bits_equal(got, want), shape
+        assert (lo, hi) == (wlo, whi)
+
+
 @pytest.mark.parametrize("resolution", [0.01, 0.25, 1.0, 1.0 / 3.0, 0.1, 0.05, 2.5e-3, 7.0, 1.0e-20, 3.0e25, 1.0e-42])
 def test_fast_finalize_matches_exact_for_every_d2(vctx, resolution):
     """The final conversion float(sqrt(double(d2)) * res) (signed_distance_field_generation.hpp:98-105) has a
