@@ -616,14 +616,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   {
     // every kChunk rows: the ring must have room for kChunk pushes
     auto check_ring = [&]() {
-      // nothing to do while no request is pending, the ring has room and is not about to run dry
+      // Two separate things.  Rare: a ring that pops have nearly emptied, and the chunk requested for it at the last check
+      // (kept apart and hinted cold, so that what it does to pf0's registers stays off the common path).
       const uint32_t resident = D - L;
       // (bitwise, not short-circuit: the compiler turns `||` / `&&` of these comparisons into nested exec-mask regions)
-      const bool busy = static_cast<int>(pf_count != 0) |
-                        (static_cast<int>(L != 0) & static_cast<int>(resident <= kChunkSlots)) |
-                        static_cast<int>(resident > (static_cast<uint32_t>(kRing - kChunk) << kShift));
-      if (__builtin_amdgcn_ballot_w64(busy) != 0ull)
+      const bool refilling = static_cast<int>(pf_count != 0) |
+                             (static_cast<int>(L != 0) & static_cast<int>(resident <= kChunkSlots));
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(refilling) != 0ull, 0))
       {
+        VGT_COLD_PATH();
         // a chunk requested at the last check goes into the ring (the ring had at most kChunk entries then and
         // has taken at most kChunk more)
         if (pf_count != 0)
@@ -637,18 +638,20 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           LoadChunk(spill_ptr(L - kChunkSlots), pf0);
           pf_count = 1;
         }
-        while (__builtin_amdgcn_ballot_w64(D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift)) != 0ull)
+      }
+      // Common (in the X pass at nearly every check, for some lanes): a ring without room for kChunk more pushes spills
+      // its oldest chunk.
+      while (__builtin_amdgcn_ballot_w64(D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift)) != 0ull)
+      {
+        if (D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift))
         {
-          if (D - L > (static_cast<uint32_t>(kRing - kChunk) << kShift))
-          {
-            Entry buf[kChunk];
-            Entry* const slots = chunk_in_ring(L);
+          Entry buf[kChunk];
+          Entry* const slots = chunk_in_ring(L);
 #pragma unroll
-            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, L, j);
-            StoreChunk(spill_ptr(L), buf);
-            L += kChunkSlots;
-            VGT_SWEEP_COUNT(4, 1);
-          }
+          for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, L, j);
+          StoreChunk(spill_ptr(L), buf);
+          L += kChunkSlots;
+          VGT_SWEEP_COUNT(4, 1);
         }
       }
     };
