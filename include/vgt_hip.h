@@ -28,6 +28,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the functions declared between this push and the pop at the end
+ * of the header are its whole dynamic symbol table (tests/test_capi_symbols.py checks `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VGT_HIP_ABI_VERSION 2
 
@@ -178,8 +183,8 @@ int vgt_hip_retrieve_filtered_grid(vgt_hip_ctx* ctx, const vgt_hip_filter* filte
  * (I/signed_distance_field.hpp:765-787) and may be NULL.  Blocking.  The two host arrays are
  * page-locked for the call, the context keeps its device buffers between calls (vgt_hip_trim
  * returns them), and grids of 2^27 voxels and more overlap upload, kernels and download chunk
- * by chunk on three streams (environment: VGT_HIP_HOST_PIPELINE_MIN_VOXELS = smallest
- * pipelined grid, negative = never); the result does not depend on it. */
+ * by chunk on three streams (the threshold is fixed in the product library; testing builds can move
+ * it with vgt_hip_testing_set_host_pipeline_min_voxels); the result does not depend on it. */
 int vgt_hip_sdf_from_occupancy_f32(vgt_hip_ctx* ctx, const float* occupancy_host,
                                    int64_t nx, int64_t ny, int64_t nz, double resolution,
                                    int unknown_is_filled, int add_virtual_border,
@@ -359,10 +364,12 @@ int vgt_hip_sdf_local_extrema_map_dev(vgt_hip_ctx* ctx, const float* sdf_dev, in
  *      (4 x int16: prev_filled, next_filled, prev_free, next_free as global z, -1 when absent)
  *   3. vgt_hip_sdf_slab_finish_dev  folds the carries in, then Y pass and X pass + finalize.
  * The slabs must be the ranges of vgt_hip_sdf_slab_range (equal shares of nz_global, earlier slabs take the
- * remainder): the carries are decoded with them, and vgt_hip_sdf_slab_finish_dev rejects carries that
- * vgt_hip_sdf_slab_carries_dev computed for another (z_offset, nz_local, nz_global) than the one it is given
- * (VGT_HIP_ERR_INVALID_ARGUMENT; ABI version 2.  Version 1 exchanged 8-byte records with absolute positions and
- * accepted any partition).
+ * remainder): the carries are decoded with them.  As a guard against the likeliest mistake,
+ * vgt_hip_sdf_slab_finish_dev rejects carries that vgt_hip_sdf_slab_carries_dev computed ON THE SAME CONTEXT for
+ * another (z_offset, nz_local, nz_global) than the one it is given (VGT_HIP_ERR_INVALID_ARGUMENT; ABI version 2.
+ * Version 1 exchanged 8-byte records with absolute positions and accepted any partition).  The guard is
+ * best-effort: it goes by the address of the carries buffer, one finish consumes it, and carries that were written
+ * by another context, a copy or a collective are not checked -- the partition rule above is the contract.
  * The workspace is the one of vgt_hip_sdf_dev for the slab's extents and must be the same buffer
  * in both calls.  kernel_ms (optional): begin -> [scan]; finish -> [fix-up, Y pass, X pass];
  * when given, the call blocks until the work has finished.
@@ -426,6 +433,9 @@ int vgt_hipx_raycast_points_split(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t
                                   float grid_y_size, float grid_z_size, int32_t num_x_voxels,
                                   int32_t num_y_voxels, int32_t num_z_voxels);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

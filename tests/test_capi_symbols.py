@@ -57,6 +57,21 @@ def test_testing_hooks_live_in_the_testing_library_only(lib):
         assert b"VGT_HIP_HOST_PIPELINE" not in fh.read()
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_dynamic_symbol_table_is_the_c_abi_and_nothing_else(lib):
+    """-fvisibility=hidden + csrc/exports.map: a drop-in library for someone else's process exports the functions of
+    include/vgt_hip.h and nothing else -- no vgt:: internals, no bare helper names, no libstdc++ instantiations."""
+    product = _exported(capi.LIB_PATH)
+    assert product == _declared_symbols(), sorted(set(product) ^ set(_declared_symbols()))
+    testing = _exported(capi.TESTING_LIB_PATH)
+    assert testing == sorted(_declared_symbols() + _declared_symbols(testing=True))
+
+
 def test_abi_version_and_workspace_size(lib):
     assert lib.vgt_hip_abi_version() == 2
     # class records (16 bytes per 64-voxel word of a Z line, plus 256 records of padding) + the int32 intermediate, a

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-phase cycle shares and operation counts of the tiled envelope passes.
 
-Needs the diagnostic build:  make -C voxelized_geometry_tools_amd/csrc STATS=1 \
+Needs the diagnostic build:  make -C voxelized_geometry_tools_amd/csrc testing STATS=1 \
     OUT=../libvgt_hip_stats.so OBJDIR=stats
-Usage: VGT_HIP_LIB=voxelized_geometry_tools_amd/libvgt_hip_stats.so python tools/hull_stats.py [size] [dist]
+(the tiled envelope lives in the TESTING library, which the Makefile names after OUT: libvgt_hip_stats_testing.so)
+Usage: VGT_HIP_LIB=voxelized_geometry_tools_amd/libvgt_hip_stats_testing.so python tools/hull_stats.py [size] [dist]
 """
 import ctypes
 import os
@@ -11,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("VGT_HIP_LIB", os.path.join(ROOT, "voxelized_geometry_tools_amd", "libvgt_hip_stats.so"))
+os.environ.setdefault("VGT_HIP_LIB", os.path.join(ROOT, "voxelized_geometry_tools_amd", "libvgt_hip_stats_testing.so"))
 
 import numpy as np
 import torch

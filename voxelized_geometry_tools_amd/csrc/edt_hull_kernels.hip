@@ -1263,7 +1263,7 @@ hipError_t LaunchPassXHullFinalizeRange(const int32_t* in32, float* sdf, uint32_
 
 #ifdef VGT_HULL_STATS
 // Diagnostic build only: read (and clear) the counters.
-extern "C" int vgt_hip_debug_hull_stats(unsigned long long* out32, int reset)
+extern "C" __attribute__((visibility("default"))) int vgt_hip_debug_hull_stats(unsigned long long* out32, int reset)
 {
   hipError_t err = hipDeviceSynchronize();
   if (err == hipSuccess)

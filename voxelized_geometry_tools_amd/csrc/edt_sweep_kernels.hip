@@ -1511,6 +1511,8 @@ hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch sc
 #endif
 
 // Y pass of the default pipeline: class records (pass 1, edt_record_kernels.hip) of p.nx slices -> int32.
+// `records` must be followed by kRecordPadding readable records (vgt_internal.hpp: the block loads run up to 191 rows
+// past a line's end; what they fetch there is never used).
 hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                                    hipStream_t stream)
 {
@@ -1548,7 +1550,7 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
 }  // namespace vgt
 
 #ifdef VGT_SWEEP_TIMING
-extern "C" int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned long long* exit8, int reset)
+extern "C" __attribute__((visibility("default"))) int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned long long* exit8, int reset)
 {
   hipError_t err = hipDeviceSynchronize();
   if (err == hipSuccess) err = hipMemcpyFromSymbol(bins128, HIP_SYMBOL(vgt::g_sweep_item_bins), 128 * sizeof(unsigned long long));
@@ -1565,7 +1567,7 @@ extern "C" int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned l
 #endif
 
 #if defined(VGT_SWEEP_STATS) || defined(VGT_SWEEP_PHASES)
-extern "C" int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
+extern "C" __attribute__((visibility("default"))) int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
 {
   hipError_t err = hipDeviceSynchronize();
   if (err == hipSuccess) err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_sweep_stats), 32 * sizeof(unsigned long long));

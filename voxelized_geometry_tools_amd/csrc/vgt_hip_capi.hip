@@ -892,6 +892,11 @@ int vgt_hip_synchronize(vgt_hip_ctx* ctx)
   if (!ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   VGT_TRY_HIP(hipStreamSynchronize(ctx->stream), "synchronize");
+  {
+    // deferred filter-grid uploads run on the copy stream: "all work of the context has finished" includes them
+    std::lock_guard<std::mutex> lock(ctx->mutex);
+    if (ctx->copy_in) VGT_TRY_HIP(hipStreamSynchronize(ctx->copy_in), "synchronize the copy stream");
+  }
   return VGT_HIP_OK;
 }
 
@@ -1237,13 +1242,13 @@ int vgt_hip_filter_grid_create(vgt_hip_ctx* ctx, int64_t num_cells, const float*
 namespace
 {
 // The filter kernel / a download is about to use the grid on the context's stream: order it behind a deferred upload.
-hipError_t OrderBehindUpload(vgt_hip_ctx* ctx, const vgt_hip_filter* filter)
+static hipError_t OrderBehindUpload(vgt_hip_ctx* ctx, const vgt_hip_filter* filter)
 {
   if (!filter->upload_pending) return hipSuccess;
   return hipStreamWaitEvent(ctx->stream, filter->uploaded, 0);
 }
 // The host has waited for work that was ordered behind the upload (or for the upload itself): the caller's array is free.
-void UploadHasFinished(vgt_hip_filter* filter)
+static void UploadHasFinished(vgt_hip_filter* filter)
 {
   filter->upload_pending = false;
   delete static_cast<ScopedHostPin*>(filter->pin);
@@ -1269,7 +1274,7 @@ int vgt_hip_filter_grid_create_deferred(vgt_hip_ctx* ctx, int64_t num_cells, con
   if (err == hipSuccess) err = hipEventCreateWithFlags(&f->uploaded, hipEventDisableTiming);
   if (err == hipSuccess)
   {
-    f->pin = new ScopedHostPin(occupancy_host, bytes);
+    f->pin = new (std::nothrow) ScopedHostPin(occupancy_host, bytes);  // (nullptr: the copy runs from pageable memory)
     std::lock_guard<std::mutex> lock(ctx->mutex);
     if (!ctx->copy_in) err = hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking);
     // (a pooled buffer may still be read by work queued on the context's stream: the copy starts behind it)
@@ -1281,7 +1286,11 @@ int vgt_hip_filter_grid_create_deferred(vgt_hip_ctx* ctx, int64_t num_cells, con
   }
   if (err != hipSuccess)
   {
-    if (f->uploaded) (void)hipStreamSynchronize(ctx->copy_in);
+    {
+      // (a copy that was enqueued before the failure must not outlive the caller's array)
+      std::lock_guard<std::mutex> lock(ctx->mutex);
+      if (f->uploaded && ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
+    }
     delete static_cast<ScopedHostPin*>(f->pin);
     if (f->uploaded) (void)hipEventDestroy(f->uploaded);
     if (f->dev) (void)hipFree(f->dev);
@@ -1316,7 +1325,15 @@ int64_t vgt_hip_filter_grid_num_cells(const vgt_hip_filter* filter)
 }
 void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter)
 {
-  return filter ? filter->dev : nullptr;
+  if (!filter) return nullptr;
+  // A deferred upload is ordered behind nothing the caller's own streams know of: wait for it here, so that the
+  // pointer can be used on any stream (the pin on the caller's array is released by retrieve / destroy as before).
+  if (filter->upload_pending)
+  {
+    (void)hipSetDevice(filter->device);
+    (void)hipEventSynchronize(filter->uploaded);
+  }
+  return filter->dev;
 }
 
 static int FilterImpl(vgt_hip_ctx* ctx, const vgt_hip_grids* grids, double percent_seen_free,
@@ -1485,7 +1502,7 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
 
 namespace
 {
-void FreeCells(vgt_hip_cells* c)
+static void FreeCells(vgt_hip_cells* c)
 {
   if (!c) return;
   if (c->records) (void)hipFree(c->records);
@@ -1498,7 +1515,7 @@ void FreeCells(vgt_hip_cells* c)
   delete c;
 }
 
-int CheckCells(const vgt_hip_ctx* ctx, const vgt_hip_cells* cells)
+static int CheckCells(const vgt_hip_ctx* ctx, const vgt_hip_cells* cells)
 {
   if (!ctx || !cells) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (cells->ctx != ctx) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "cells belong to another context");
@@ -1507,7 +1524,7 @@ int CheckCells(const vgt_hip_ctx* ctx, const vgt_hip_cells* cells)
 
 // mask (mode, objects) -> signed distance field in `sdf_dev`, extrema in ctx->minmax_out.
 // Caller holds the context mutex.
-int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, const vgt::SdfParams& p,
+static int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, const vgt::SdfParams& p,
                 float* sdf_dev)
 {
   const int64_t n = c->nx * c->ny * c->nz;
@@ -1527,7 +1544,7 @@ int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, c
                                  ctx->minmax_out, nullptr);
 }
 
-int CopySdfToHost(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t n, float* sdf_host, float* out_min,
+static int CopySdfToHost(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t n, float* sdf_host, float* out_min,
                   float* out_max)
 {
   float mm[2] = {0.0f, 0.0f};
@@ -1764,7 +1781,7 @@ int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* ce
 
 namespace
 {
-void ReleaseTiming(vgt_hip_ctx* ctx)
+static void ReleaseTiming(vgt_hip_ctx* ctx)
 {
   for (hipEvent_t e : ctx->timing_events)
     if (e) (void)hipEventDestroy(e);
@@ -2122,10 +2139,16 @@ int vgt_hip_sdf_slab_finish_dev(vgt_hip_ctx* ctx, int64_t nx, int64_t ny, int64_
   std::lock_guard<std::mutex> lock(ctx->mutex);
   {
     const auto note = ctx->slab_notes.find(carries_dev);
-    if (note != ctx->slab_notes.end() && (note->second.z_offset != z_offset || note->second.nz_local != nz_local ||
-                                          note->second.nz_global != nz_global))
-      return Fail(VGT_HIP_ERR_INVALID_ARGUMENT,
-                  "the carries were computed for another slab: slabs must be the ranges of vgt_hip_sdf_slab_range");
+    if (note != ctx->slab_notes.end())
+    {
+      const bool other = note->second.z_offset != z_offset || note->second.nz_local != nz_local ||
+                         note->second.nz_global != nz_global;
+      // (consumed either way: a later buffer at the same address -- a caching allocator's reuse -- starts without a note)
+      ctx->slab_notes.erase(note);
+      if (other)
+        return Fail(VGT_HIP_ERR_INVALID_ARGUMENT,
+                    "the carries were computed for another slab: slabs must be the ranges of vgt_hip_sdf_slab_range");
+    }
   }
   hipStream_t s = ctx->stream;
   hipEvent_t* slot = kernel_ms ? nullptr : TimingSlot(ctx);

@@ -70,7 +70,10 @@ constexpr uint32_t kRecordNoneBelow = 0u;
 constexpr uint32_t kRecordNoneAbove = 2u * kRecordBias;
 constexpr uint32_t kRecordNoSite = 0xfffffff0u;
 inline int64_t RecordWords(int64_t nz) { return (nz + 63) / 64; }
-// records of a grid (+ padding: the Y pass fetches records up to 136 rows past the end of the line it works on)
+// records of a grid (+ padding: the Y pass loads whole 64-row blocks three blocks ahead, so it FETCHES records up to
+// 3 * 64 - 1 = 191 rows past the end of the line it works on -- the next lines' records, a later chunk's not yet written
+// ones, or this padding, which nobody initialises.  It never USES them: every row is guarded by `row < n`.  Whoever hands
+// LaunchPassYSweepRecords a record buffer must keep the padding behind it, or the fetch leaves the allocation.)
 constexpr int kRecordPadding = 256;
 inline size_t ClassRecordBytes(int64_t nx, int64_t ny, int64_t nz)
 {
