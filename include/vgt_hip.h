@@ -218,6 +218,28 @@ int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t 
                           int64_t ny, int64_t nz, double resolution, int unknown_is_filled,
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
                           size_t workspace_bytes, float* minmax_dev, float* kernel_ms);
+/* ---- Batches: `batch` grids of the same extents in one call (many small maps, or many masks of one map).
+ * The reference extracts one field per call and loops -- TaggedObjectOccupancyMap::MakeSeparateObjectSDFs /
+ * MakeAllObjectSDFs run one whole ExtractSignedDistanceField per object id
+ * (I/tagged_object_occupancy_map.hpp:249-290) -- and on the grid sizes of its own examples and tests (8^3 - 40^3)
+ * one extraction is a few hundred work items for a GPU that holds 16 384 waves.  Here the three passes run ONCE
+ * over the whole batch: the grids lie one after the other, [batch][nx][ny][nz], in the input, in the output and in
+ * every intermediate buffer; pass 1 and the Y pass see one grid of batch * nx slices (their lines never leave a
+ * slice), the X pass deals (grid, y, z segment) items to the same persistent workgroups, every grid has its own
+ * extrema.  Results are bit-identical to `batch` single calls.
+ *   limits      the per-axis limit of every SDF entry point for nx, ny, nz; batch * nx * ny < 2^28
+ *   minmax_dev  NULL or 2 * batch floats: {min, max} of grid 0, of grid 1, ...
+ * vgt_hip_sdf_batch_from_occupancy_f32 takes `batch` host arrays (any addresses) and hands back `batch` fields and
+ * their extrema (out_min / out_max: NULL or `batch` floats each); it cuts batches that exceed the limits or 2 GiB of
+ * device buffers into several launches by itself.  Blocking. */
+size_t vgt_hip_sdf_batch_workspace_bytes(int64_t batch, int64_t nx, int64_t ny, int64_t nz);
+int vgt_hip_sdf_batch_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t batch, int64_t nx, int64_t ny,
+                          int64_t nz, double resolution, int unknown_is_filled, int add_virtual_border,
+                          float* sdf_dev, void* workspace_dev, size_t workspace_bytes, float* minmax_dev);
+int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* occupancy_host, int64_t batch,
+                                         int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                         int unknown_is_filled, int add_virtual_border, float* const* sdf_host,
+                                         float* out_min, float* out_max);
 #ifdef VGT_HIP_TESTING
 /* ---- Testing builds only: libvgt_hip_testing.so (make -C voxelized_geometry_tools_amd/csrc testing), which the parity
  * tests load next to the product library.  The product library exports none of these and contains none of the
@@ -275,6 +297,15 @@ int vgt_hip_cells_object_ids(vgt_hip_ctx* ctx, vgt_hip_cells* cells, uint32_t* i
 int vgt_hip_cells_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* objects_to_use,
                       int64_t num_objects, double resolution, int unknown_is_filled,
                       int add_virtual_border, float* sdf_host, float* out_min, float* out_max);
+/* MakeSeparateObjectSDFs(object_ids) / MakeAllObjectSDFs (:249-290) as ONE batch: sdf_host[k] receives
+ * ExtractSignedDistanceField({object_ids[k]}) -- the field of vgt_hip_cells_sdf with that one id, bit for bit --
+ * and out_min[k] / out_max[k] (NULL or num_objects floats each) its extrema.  One pass over the cells writes every
+ * object's mask, the EDT passes run once over all of them (see "Batches" above), the fields come back through
+ * page-locked copies.  Object lists that exceed the limits of a batch or 4 GiB of device buffers are cut into several
+ * launches.  Blocking. */
+int vgt_hip_cells_object_sdfs(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* object_ids,
+                              int64_t num_objects, double resolution, int unknown_is_filled, int add_virtual_border,
+                              float* const* sdf_host, float* out_min, float* out_max);
 /* ExtractFreeAndNamedObjectsSignedDistanceField: the field of all filled cells where it is >= 0,
  * the field of the filled cells of named objects (id > 0) where that is <= 0, else 0. */
 int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells,

@@ -82,6 +82,11 @@ private:
 // reference rejects, std::runtime_error when no HIP device can be used (no CPU fallback).
 SignedDistanceField ExtractSignedDistanceField(
     const OccupancyMap& map, const SignedDistanceFieldGenerationParameters& parameters);
+// The same for a batch of maps of one size (e.g. the per-object or per-frame maps of a planner): one batched extraction
+// (vgt_hip_sdf_batch_from_occupancy_f32) instead of a loop of calls; fields[i] belongs to maps[i] and is what the single
+// call returns for it, bit for bit.  Throws std::invalid_argument when the maps' sizes differ.
+std::vector<SignedDistanceField> ExtractSignedDistanceFields(
+    const std::vector<const OccupancyMap*>& maps, const SignedDistanceFieldGenerationParameters& parameters);
 // The free-standing SDF entry points share one context per device for the life of the process; that
 // context keeps its device buffers between calls (no hipMalloc / hipFree per extraction).  This
 // returns the memory (e.g. after one very large grid).

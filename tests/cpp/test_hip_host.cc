@@ -34,12 +34,6 @@ static bool AlmostEqualUlps(float a, float b)  // gtest's EXPECT_FLOAT_EQ: withi
 
 static bool CloseEnough(float a, float b) { return a == b || std::abs(a - b) <= 0.0001f; }
 
-static OccupancyMap MakeMap(double res, double xs, double ys, double zs, float fill)
-{
-  return OccupancyMap::FromGridSizes(Isometry3::Translation(-5.0, -5.0, -5.0), "test_frame", res,
-                                     xs, ys, zs, fill);
-}
-
 static void FillBox(OccupancyMap& m, int x0, int x1, int y0, int y1, int z0, int z1)
 {
   for (int x = x0; x < x1; x++)
@@ -47,72 +41,191 @@ static void FillBox(OccupancyMap& m, int x0, int x1, int y0, int y1, int z0, int
       for (int z = z0; z < z1; z++) m.SetIndex(x, y, z, 1.0f);
 }
 
-// TestSDFGeneration (test/sdf_generation_test.cpp:140-260): extrema + sign of every voxel.
-static void CheckSdf(const OccupancyMap& map, float expected_min, float expected_max)
+// The four map types of one test scene, built cell by cell as test/sdf_generation_test.cpp does (:279-294, :387-418):
+// filled cells are OccupancyCell(1), OccupancyComponentCell(1), TaggedObjectOccupancyCell(1, 1u) and
+// TaggedObjectOccupancyComponentCell(1, 1u), the background cells (v) / (v) / (v, v != 0 ? 1u : 0u).
+struct FourMaps
 {
-  const SignedDistanceField sdf = ExtractSignedDistanceField(map, {});
-  EXPECT_TRUE(sdf.IsLocked());
-  EXPECT_TRUE(CloseEnough(sdf.minimum, expected_min));
-  EXPECT_TRUE(CloseEnough(sdf.maximum, expected_max));
-  EXPECT_EQ(sdf.grid.NumXVoxels(), map.NumXVoxels());
-  for (int64_t x = 0; x < map.NumXVoxels(); x++)
-    for (int64_t y = 0; y < map.NumYVoxels(); y++)
-      for (int64_t z = 0; z < map.NumZVoxels(); z++)
-      {
-        if (map.GetIndexImmutable(x, y, z) >= 0.5f)
-          EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) < 0.0f);
-        else
-          EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) > 0.0f);
-      }
+  OccupancyMap occupancy;
+  OccupancyComponentMap component;
+  TaggedObjectOccupancyMap tagged;
+  TaggedObjectOccupancyComponentMap tagged_component;
+  FourMaps(const Isometry3& origin, double res, double xs, double ys, double zs, float fill)
+      : occupancy(OccupancyMap::FromGridSizes(origin, "test_frame", res, xs, ys, zs, fill)),
+        component(origin, "test_frame", res, occupancy.NumXVoxels(), occupancy.NumYVoxels(), occupancy.NumZVoxels(),
+                  OccupancyComponentCell{fill, 0u}),
+        tagged(origin, "test_frame", res, occupancy.NumXVoxels(), occupancy.NumYVoxels(), occupancy.NumZVoxels(),
+               TaggedObjectOccupancyCell{fill, fill != 0.0f ? 1u : 0u}),
+        tagged_component(origin, "test_frame", res, occupancy.NumXVoxels(), occupancy.NumYVoxels(),
+                         occupancy.NumZVoxels(), TaggedObjectOccupancyComponentCell{fill, fill != 0.0f ? 1u : 0u, 0u, 0u})
+  {
+  }
+  void FillBox(int x0, int x1, int y0, int y1, int z0, int z1)
+  {
+    for (int x = x0; x < x1; x++)
+      for (int y = y0; y < y1; y++)
+        for (int z = z0; z < z1; z++)
+        {
+          occupancy.SetIndex(x, y, z, 1.0f);
+          component.SetIndex(x, y, z, OccupancyComponentCell{1.0f, 0u});
+          tagged.SetIndex(x, y, z, TaggedObjectOccupancyCell{1.0f, 1u});
+          tagged_component.SetIndex(x, y, z, TaggedObjectOccupancyComponentCell{1.0f, 1u, 0u, 0u});
+        }
+  }
+  // GenerateSignedDistanceFields (test/sdf_generation_test.cpp:42-110): each type through its own entry point, the
+  // tagged ones with an empty object list
+  std::vector<SignedDistanceField> Fields() const
+  {
+    const SignedDistanceFieldGenerationParameters params;
+    std::vector<SignedDistanceField> fields;
+    fields.push_back(ExtractSignedDistanceField(occupancy, params));
+    fields.push_back(ExtractSignedDistanceField(component, params));
+    fields.push_back(DeviceTaggedObjectMap(tagged).ExtractSignedDistanceField({}, params));
+    fields.push_back(DeviceTaggedObjectMap(tagged_component).ExtractSignedDistanceField({}, params));
+    return fields;
+  }
+};
+
+// TestSDFGeneration (test/sdf_generation_test.cpp:140-260): extrema + sign of every voxel, on all four map types.
+static void CheckSdf(const FourMaps& maps, float expected_min, float expected_max)
+{
+  const OccupancyMap& map = maps.occupancy;
+  for (const SignedDistanceField& sdf : maps.Fields())
+  {
+    EXPECT_TRUE(sdf.IsLocked());
+    EXPECT_TRUE(CloseEnough(sdf.minimum, expected_min));
+    EXPECT_TRUE(CloseEnough(sdf.maximum, expected_max));
+    EXPECT_EQ(sdf.grid.NumXVoxels(), map.NumXVoxels());
+    EXPECT_EQ(sdf.grid.NumYVoxels(), map.NumYVoxels());
+    EXPECT_EQ(sdf.grid.NumZVoxels(), map.NumZVoxels());
+    for (int64_t x = 0; x < map.NumXVoxels(); x++)
+      for (int64_t y = 0; y < map.NumYVoxels(); y++)
+        for (int64_t z = 0; z < map.NumZVoxels(); z++)
+        {
+          if (map.GetIndexImmutable(x, y, z) >= 0.5f)
+            EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) < 0.0f);
+          else
+            EXPECT_TRUE(sdf.GetIndexImmutable(x, y, z) > 0.0f);
+        }
+  }
 }
 
 static void SdfGenerationTests()
 {
   const float inf = std::numeric_limits<float>::infinity();
-  CheckSdf(MakeMap(0.25, 1, 2, 3, 1.0f), -inf, -inf);  // FullyFilledTest
-  CheckSdf(MakeMap(0.25, 1, 2, 3, 0.0f), inf, inf);    // FullyEmptyTest
-  {                                                     // CenterObstacleTest
-    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
-    EXPECT_EQ(m.NumXVoxels(), 4);
-    EXPECT_EQ(m.NumYVoxels(), 8);
-    EXPECT_EQ(m.NumZVoxels(), 12);
-    FillBox(m, 1, 3, 2, 6, 3, 9);
+  const Isometry3 origin = Isometry3::Translation(-5.0, -5.0, -5.0);
+  CheckSdf(FourMaps(origin, 0.25, 1, 2, 3, 1.0f), -inf, -inf);  // FullyFilledTest
+  CheckSdf(FourMaps(origin, 0.25, 1, 2, 3, 0.0f), inf, inf);    // FullyEmptyTest
+  {                                                              // CenterObstacleTest
+    FourMaps m(origin, 0.25, 1, 2, 3, 0.0f);
+    EXPECT_EQ(m.occupancy.NumXVoxels(), 4);
+    EXPECT_EQ(m.occupancy.NumYVoxels(), 8);
+    EXPECT_EQ(m.occupancy.NumZVoxels(), 12);
+    m.FillBox(1, 3, 2, 6, 3, 9);
     CheckSdf(m, -0.25f, static_cast<float>(std::sqrt(0.25 * 0.25 + 0.5 * 0.5 + 0.75 * 0.75)));
   }
   {  // CornerObstacleTest
-    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
-    FillBox(m, 0, 2, 0, 4, 0, 6);
+    FourMaps m(origin, 0.25, 1, 2, 3, 0.0f);
+    m.FillBox(0, 2, 0, 4, 0, 6);
     CheckSdf(m, -0.5f, 1.8708f);
   }
   {  // FaceObstacleTest
-    OccupancyMap m = MakeMap(0.25, 1, 2, 3, 0.0f);
-    FillBox(m, 0, 4, 0, 8, 0, 1);
+    FourMaps m(origin, 0.25, 1, 2, 3, 0.0f);
+    m.FillBox(0, 4, 0, 8, 0, 1);
     CheckSdf(m, -0.25f, 2.75f);
   }
-  {  // LinearExactTest
-    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 1, 1, 4, 0.0f);
-    FillBox(m, 0, 1, 0, 1, 0, 2);
-    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+  {  // LinearExactTest (:586-701)
+    FourMaps m(Isometry3::Identity(), 1.0, 1, 1, 4, 0.0f);
+    m.FillBox(0, 1, 0, 1, 0, 2);
     const float want[4] = {-2.0f, -1.0f, 1.0f, 2.0f};
-    for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
+    for (const SignedDistanceField& sdf : m.Fields())
+      for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, 0, z), want[z]);
   }
-  {  // PlanarExactTest
-    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 1, 4, 4, 0.0f);
-    FillBox(m, 0, 1, 0, 2, 0, 2);
-    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+  {  // PlanarExactTest (:703-902)
+    FourMaps m(Isometry3::Identity(), 1.0, 1, 4, 4, 0.0f);
+    m.FillBox(0, 1, 0, 2, 0, 2);
     const float s2 = std::sqrt(2.0f), s5 = std::sqrt(5.0f), s8 = std::sqrt(8.0f);
     const float want[4][4] = {{-2, -1, 1, 2}, {-1, -1, 1, 2}, {1, 1, s2, s5}, {2, 2, s5, s8}};
-    for (int y = 0; y < 4; y++)
-      for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, y, z), want[y][z]);
+    for (const SignedDistanceField& sdf : m.Fields())
+      for (int y = 0; y < 4; y++)
+        for (int z = 0; z < 4; z++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(0, y, z), want[y][z]);
   }
-  {  // CubeExactTest
-    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 1.0, 2, 2, 2, 0.0f);
-    m.SetIndex(0, 0, 0, 1.0f);
-    const SignedDistanceField sdf = ExtractSignedDistanceField(m, {});
+  {  // CubeExactTest (:904-1055)
+    FourMaps m(Isometry3::Identity(), 1.0, 2, 2, 2, 0.0f);
+    m.FillBox(0, 1, 0, 1, 0, 1);
     const float s2 = std::sqrt(2.0f), s3 = std::sqrt(3.0f);
     const float want[8] = {-1, 1, 1, s2, 1, s2, s2, s3};
-    for (int i = 0; i < 8; i++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(i >> 2, (i >> 1) & 1, i & 1), want[i]);
+    for (const SignedDistanceField& sdf : m.Fields())
+      for (int i = 0; i < 8; i++) EXPECT_FLOAT_EQ(sdf.GetIndexImmutable(i >> 2, (i >> 1) & 1, i & 1), want[i]);
   }
+}
+
+// Batches: many maps of one size in one extraction, and MakeAllObjectSDFs as one batch -- each field bit-equal to the
+// single call's.
+static void BatchedSdfTests()
+{
+  std::vector<OccupancyMap> maps;
+  for (int i = 0; i < 9; i++)
+  {
+    OccupancyMap m = OccupancyMap::FromGridSizes(Isometry3::Translation(0.1 * i, 0, 0), "test_frame", 0.05, 1.0, 1.2, 0.9, 0.0f);
+    FillBox(m, i, i + 4, 2 + i, 9 + i, 1, 3 + i);
+    if (i == 4) FillBox(m, 0, 20, 0, 24, 0, 18);  // a full grid inside the batch
+    if (i == 7) m.SetIndex(3, 3, 3, 0.5f);
+    maps.push_back(m);
+  }
+  maps.push_back(OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 0.05, 1.0, 1.2, 0.9, 0.0f));  // empty
+  std::vector<const OccupancyMap*> pointers;
+  for (const OccupancyMap& m : maps) pointers.push_back(&m);
+  SignedDistanceFieldGenerationParameters params;
+  for (int vb = 0; vb < 2; vb++)
+  {
+    params.add_virtual_border = vb != 0;
+    const std::vector<SignedDistanceField> fields = ExtractSignedDistanceFields(pointers, params);
+    EXPECT_EQ(fields.size(), maps.size());
+    for (size_t i = 0; i < maps.size(); i++)
+    {
+      const SignedDistanceField single = ExtractSignedDistanceField(maps[i], params);
+      EXPECT_TRUE(fields[i].IsLocked());
+      EXPECT_TRUE(std::memcmp(fields[i].grid.GetImmutableRawData().data(), single.grid.GetImmutableRawData().data(),
+                              single.grid.GetImmutableRawData().size() * sizeof(float)) == 0);
+      EXPECT_TRUE(fields[i].minimum == single.minimum && fields[i].maximum == single.maximum);
+    }
+  }
+  bool threw = false;
+  try
+  {
+    const OccupancyMap other = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 0.05, 1.0, 1.0, 0.9, 0.0f);
+    ExtractSignedDistanceFields({&maps[0], &other}, params);
+  }
+  catch (const std::invalid_argument&)
+  {
+    threw = true;
+  }
+  EXPECT_TRUE(threw);
+  // tagged map: 12 box-shaped objects; the batched MakeAllObjectSDFs against one ExtractSignedDistanceField({id}) each
+  TaggedObjectOccupancyMap tagged(Isometry3::Identity(), "test_frame", 0.1, 30, 26, 22, TaggedObjectOccupancyCell());
+  for (uint32_t id = 1; id <= 12; id++)
+    for (int x = 0; x < 4; x++)
+      for (int y = 0; y < 3; y++)
+        for (int z = 0; z < 5; z++)
+          tagged.SetIndex((id * 7) % 26 + x, (id * 5) % 23 + y, (id * 3) % 17 + z,
+                          TaggedObjectOccupancyCell{(id == 5 && z == 0) ? 0.5f : 1.0f, id});
+  const DeviceTaggedObjectMap device_map(tagged);
+  SignedDistanceFieldGenerationParameters tagged_params;
+  const std::map<uint32_t, SignedDistanceField> all = device_map.MakeAllObjectSDFs(tagged_params);
+  const std::vector<uint32_t> ids = device_map.ObjectIds();
+  EXPECT_EQ(all.size(), ids.size());
+  for (const uint32_t id : ids)
+  {
+    const SignedDistanceField single = device_map.ExtractSignedDistanceField({id}, tagged_params);
+    const SignedDistanceField& batched = all.at(id);
+    EXPECT_TRUE(batched.IsLocked());
+    EXPECT_TRUE(std::memcmp(batched.grid.GetImmutableRawData().data(), single.grid.GetImmutableRawData().data(),
+                            single.grid.GetImmutableRawData().size() * sizeof(float)) == 0);
+    EXPECT_TRUE(batched.minimum == single.minimum && batched.maximum == single.maximum);
+  }
+  // duplicated ids in the list: one entry per distinct id, as a std::map gives
+  EXPECT_EQ(device_map.MakeSeparateObjectSDFs({3u, 3u, 9u}, tagged_params).size(), 2u);
 }
 
 // The large-grid branch (vgt_hipx_sdf_multi: one process, one Z slab per listed device).  With one GPU the
@@ -439,6 +552,7 @@ int main(int argc, char** argv)
     MultiDeviceSdfTests();
     SdfConsumerTests();
     TaggedObjectSdfTests();
+    BatchedSdfTests();
     PointCloudVoxelizationTests(1);
     PointCloudVoxelizationTests(4);
   }

@@ -401,6 +401,34 @@ def test_exact_finalize_matches_numpy(ctx):
         assert bits_equal(sdf[:, 0, 0], expect)
 
 
+def _check_few_site_field(torch, sdf, shape, sites, res):
+    """A grid whose only filled voxels are a few isolated `sites` has an analytic field: float32(sqrt(float64(min over
+    the sites of the squared point distance)) * res), and -res on the sites themselves (their nearest free voxel is a
+    neighbour).  Checks EVERY voxel of the device tensor `sdf` against it, 64 X slices at a time; returns the largest
+    value seen."""
+    ay = torch.arange(shape[1], device="cuda", dtype=torch.int64)
+    az = torch.arange(shape[2], device="cuda", dtype=torch.int64)
+    worst = 0
+    hi = 0.0
+    for x0 in range(0, shape[0], 64):
+        ax = torch.arange(x0, min(x0 + 64, shape[0]), device="cuda", dtype=torch.int64)
+        d2 = None
+        for (sx, sy, sz) in sites:
+            d = ((ax - sx) ** 2)[:, None, None] + ((ay - sy) ** 2)[None, :, None] + ((az - sz) ** 2)[None, None, :]
+            d2 = d if d2 is None else torch.minimum(d2, d)
+        del d
+        want = (torch.sqrt(d2.to(torch.float64)) * res).to(torch.float32)
+        got = sdf[x0:x0 + 64]
+        want = torch.where(d2 == 0, torch.full_like(want, -float(np.float32(res))), want)
+        del d2
+        diff = (got.view(torch.int32) - want.view(torch.int32)).abs().max().item()
+        worst = max(worst, diff)
+        hi = max(hi, got.max().item())
+        del want
+    assert worst == 0
+    return hi
+
+
 def test_two_giga_voxel_slab_is_indexed_with_64_bits(ctx):
     """One rank's share of BASELINE config 5 at two GPUs (2048 x 2048 x 512 = 2^31 voxels), device-resident.
     Three filled voxels in far corners make the field analytic (min over three point distances), so every
@@ -425,28 +453,66 @@ def test_two_giga_voxel_slab_is_indexed_with_64_bits(ctx):
         torch.cuda.synchronize()
     finally:
         ctx.reset_stream()
-    del ws
-    ay = torch.arange(shape[1], device="cuda", dtype=torch.int64)
-    az = torch.arange(shape[2], device="cuda", dtype=torch.int64)
-    worst = 0
-    hi = 0.0
-    for x0 in range(0, shape[0], 64):
-        ax = torch.arange(x0, x0 + 64, device="cuda", dtype=torch.int64)
-        d2 = None
-        for (sx, sy, sz) in sites:
-            d = ((ax - sx) ** 2)[:, None, None] + ((ay - sy) ** 2)[None, :, None] + ((az - sz) ** 2)[None, None, :]
-            d2 = d if d2 is None else torch.minimum(d2, d)
-        want = (torch.sqrt(d2.to(torch.float64)) * res).to(torch.float32)
-        got = sdf[x0:x0 + 64]
-        filled = d2 == 0
-        # a filled voxel's distance is to the nearest FREE voxel: 1 voxel here
-        want = torch.where(filled, torch.full_like(want, -float(np.float32(res))), want)
-        diff = (got.view(torch.int32) - want.view(torch.int32)).abs().max().item()
-        worst = max(worst, diff)
-        hi = max(hi, got.max().item())
-    assert worst == 0
+    del ws, occ
+    hi = _check_few_site_field(torch, sdf, shape, sites, res)
     mm = minmax.cpu().numpy()
     assert mm[0] == -np.float32(res) and mm[1] == np.float32(hi)
+
+
+# BASELINE config 5 at its OWN size: 2048 x 2048 x 1024 = 2^32 voxels -- exactly where a 32-bit voxel index wraps
+# (the reference's device kernels index with int32: S/cuda_voxelization_helpers.cu:85,365,377).  Sites sit on the
+# last voxel (linear index 2^32 - 1), on index 2^31 exactly, just above 2^31 and 2^32 - 2^22, in the first and the last
+# Z slab of an 8-way cut and in the middle ones.
+CONFIG5_SHAPE = (2048, 2048, 1024)
+CONFIG5_SITES = [(2047, 2047, 1023), (1024, 0, 0), (1024, 1, 130), (2046, 2047, 900), (0, 2040, 3), (1999, 1, 1000),
+                 (600, 1000, 517), (1400, 700, 300)]
+
+
+@pytest.mark.parametrize("path", ["plain", "slabs8"])
+def test_config5_at_its_own_size(ctx, path):
+    """Every voxel of a 2^32-voxel field, device-resident, through the plain pipeline (the one-GPU reference of the
+    scaling series) and through the Z-slab pipeline with the 8 slabs of the 8-GPU run, all on this device
+    (begin -> summaries of all slabs -> carries -> finish per slab), against the analytic few-site field; extrema too."""
+    import torch
+    from voxelized_geometry_tools_amd import multi_gpu
+    shape, sites, res = CONFIG5_SHAPE, CONFIG5_SITES, 0.01
+    n = int(np.prod(shape))
+    assert n == 2 ** 32 and all(0 <= c < e for s in sites for c, e in zip(s, shape))
+    linear = sorted((x * shape[1] + y) * shape[2] + z for x, y, z in sites)
+    assert linear[-1] == 2 ** 32 - 1 and 2 ** 31 in linear and sum(i >= 2 ** 31 for i in linear) >= 4
+    ws_bytes = capi.sdf_workspace_bytes(shape)
+    slab_ws = 8 * capi.sdf_workspace_bytes((shape[0], shape[1], shape[2] // 8))
+    # occupancy + field + workspace(s) + the checker's temporaries (+ the slabs' contiguous copies and fields)
+    need = 8 * n + (ws_bytes if path == "plain" else slab_ws + 8 * n) + 12 * 2 ** 30
+    free = torch.cuda.mem_get_info()[0]
+    if free < need:
+        pytest.skip("needs %.0f GiB of free HBM, %.0f free" % (need / 2 ** 30, free / 2 ** 30))
+    occ = torch.zeros(shape, dtype=torch.float32, device="cuda")
+    for s in sites:
+        occ[s] = 1.0
+    if path == "plain":
+        sdf = torch.empty(shape, dtype=torch.float32, device="cuda")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        minmax = torch.zeros(2, dtype=torch.float32, device="cuda")
+        ctx.set_stream(None)
+        try:
+            ctx.sdf_dev(occ.data_ptr(), shape, res, sdf.data_ptr(), ws.data_ptr(), ws_bytes, minmax.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            ctx.reset_stream()
+        del ws, occ
+        lo, hi_reported = (float(v) for v in minmax.cpu().numpy())
+    else:
+        sdf, lo, hi_reported = multi_gpu.sdf_slabs_single_device(ctx, torch, occ, 8, res)
+        del occ
+    torch.cuda.empty_cache()
+    hi = _check_few_site_field(torch, sdf, shape, sites, res)
+    assert lo == -np.float32(res) and hi_reported == np.float32(hi)
+    # spot values at the index boundaries, spelled out: the last voxel is a site; its Z neighbour is one voxel away
+    assert sdf[2047, 2047, 1023].item() == -np.float32(res) and sdf[2047, 2047, 1022].item() == np.float32(res)
+    assert sdf[1024, 0, 0].item() == -np.float32(res) and sdf[1023, 2047, 1023].item() > 0
+    del sdf
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("shape", [(5, 6, 1024), (4, 3, 516), (3, 4, 260), (2, 2, 2048), (2, 3, 768), (3, 2, 1028),

@@ -48,6 +48,49 @@ def test_fixture_objects_to_use_and_free_and_named(ctx, sdf_tagged_cases, dtype)
         cells.close()
 
 
+def _kat_records(occ, dtype):
+    """The reference test's cells for an occupancy scene (test/sdf_generation_test.cpp:279-294, 387-418): filled cells
+    carry object id 1, empty ones 0; components / segments are left at their constructors' 0."""
+    rec = np.zeros(occ.shape, dtype=dtype)
+    rec["occupancy"] = occ
+    if "object_id" in dtype.names:
+        rec["object_id"] = (occ != 0.0).astype(np.uint32)
+    return rec
+
+
+KAT_TYPES = [(capi.OCCUPANCY_COMPONENT_CELL, -1), (capi.TAGGED_OBJECT_CELL, 4), (capi.TAGGED_OBJECT_COMPONENT_CELL, 4)]
+
+
+@pytest.mark.parametrize("dtype,id_offset", KAT_TYPES, ids=["component8", "tagged8", "tagged16"])
+def test_reference_known_answers_on_every_map_type(ctx, sdf_kats, dtype, id_offset):
+    """test/sdf_generation_test.cpp asserts its five extrema cases, the sign of every voxel (:140-256) and the three
+    exact-value grids (:586-1055) on all FOUR map types; tests/test_gpu_sdf.py replays them through the OccupancyMap
+    entry point, this test through vgt_hip_cells_sdf with the other three cell layouts (empty object list, as
+    GenerateSignedDistanceFields calls them, :72-81)."""
+    from conftest import kat_occupancy
+    tol = sdf_kats["extrema_tolerance"]
+    for case in sdf_kats["extrema_cases"]:
+        occ = kat_occupancy(case)
+        cells = ctx.cells(_kat_records(occ, dtype), occ.shape, object_id_offset=id_offset)
+        sdf, lo, hi = cells.sdf(case["resolution"])
+        cells.close()
+        exp_lo, exp_hi = float(case["min"]), float(case["max"])
+        assert lo == exp_lo or abs(lo - exp_lo) <= tol, case["name"]
+        assert hi == exp_hi or abs(hi - exp_hi) <= tol, case["name"]
+        assert np.all(sdf[occ >= 0.5] < 0) and np.all(sdf[occ < 0.5] > 0), case["name"]
+        # and the same field as the OccupancyMap entry point, bit for bit
+        plain, plo, phi = ctx.sdf_from_occupancy(occ, case["resolution"])
+        assert bits_equal(sdf, plain) and (lo, hi) == (plo, phi), case["name"]
+    for case in sdf_kats["exact_cases"]:
+        occ = kat_occupancy(case)
+        cells = ctx.cells(_kat_records(occ, dtype), occ.shape, object_id_offset=id_offset)
+        sdf, _, _ = cells.sdf(case["resolution"])
+        cells.close()
+        sq = np.array(case["expected_sq"], dtype=np.float32)
+        expected = (np.sign(sq) * np.sqrt(np.abs(sq))).astype(np.float32).reshape(case["shape"])
+        assert bits_equal(sdf, expected), case["name"]
+
+
 def test_component_map(ctx, sdf_tagged_cases):
     for name, case in sdf_tagged_cases.items():
         rec = tagged_records(case, capi.OCCUPANCY_COMPONENT_CELL)

@@ -81,6 +81,10 @@ SIGNATURES = {
                                              _f32, _i32, _i32, _i32]),
     "vgt_hip_sdf_dev": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
     "vgt_hip_sdf_dev_timed": (_int, [_p, _p, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p, _p]),
+    "vgt_hip_sdf_batch_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "vgt_hip_sdf_batch_dev": (_int, [_p, _p, _i64, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _sz, _p]),
+    "vgt_hip_sdf_batch_from_occupancy_f32": (_int, [_p, _p, _i64, _i64, _i64, _i64, _f64, _int, _int, _p, _p, _p]),
+    "vgt_hip_cells_object_sdfs": (_int, [_p, _p, _p, _i64, _f64, _int, _int, _p, _p, _p]),
     "vgt_hip_cells_create": (_int, [_p, _p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                    ctypes.c_int32, _p]),
     "vgt_hip_cells_destroy": (None, [_p]),
@@ -361,6 +365,33 @@ class Context:
             int(bool(add_virtual_border)), _ptr(out), ctypes.byref(lo), ctypes.byref(hi)))
         return out, lo.value, hi.value
 
+    def sdf_batch_from_occupancy(self, grids, resolution, unknown_is_filled=True, add_virtual_border=False):
+        """vgt_hip_sdf_batch_from_occupancy_f32: a list of equal-shape float32 grids (any addresses) ->
+        (list of fields, mins, maxs) from one batched extraction."""
+        grids = [np.ascontiguousarray(g, dtype=np.float32) for g in grids]
+        if not grids or any(g.ndim != 3 or g.shape != grids[0].shape for g in grids):
+            raise ValueError("a batch is a non-empty list of (nx, ny, nz) grids of one shape")
+        nx, ny, nz = grids[0].shape
+        outs = [np.empty(g.shape, dtype=np.float32) for g in grids]
+        batch = len(grids)
+        in_ptrs = (ctypes.c_void_p * batch)(*[g.ctypes.data for g in grids])
+        out_ptrs = (ctypes.c_void_p * batch)(*[o.ctypes.data for o in outs])
+        lo = np.zeros(batch, dtype=np.float32)
+        hi = np.zeros(batch, dtype=np.float32)
+        check(self._lib.vgt_hip_sdf_batch_from_occupancy_f32(
+            self.handle, ctypes.cast(in_ptrs, ctypes.c_void_p), batch, nx, ny, nz, float(resolution),
+            int(bool(unknown_is_filled)), int(bool(add_virtual_border)), ctypes.cast(out_ptrs, ctypes.c_void_p),
+            _ptr(lo), _ptr(hi)))
+        return outs, lo, hi
+
+    def sdf_batch_dev(self, occ_ptr, batch, shape, resolution, sdf_ptr, ws_ptr, ws_bytes, minmax_ptr=None,
+                      unknown_is_filled=True, add_virtual_border=False):
+        """vgt_hip_sdf_batch_dev: [batch][nx][ny][nz] device buffers in and out."""
+        nx, ny, nz = shape
+        check(self._lib.vgt_hip_sdf_batch_dev(
+            self.handle, _ptr(occ_ptr), int(batch), nx, ny, nz, float(resolution), int(bool(unknown_is_filled)),
+            int(bool(add_virtual_border)), _ptr(sdf_ptr), _ptr(ws_ptr), ws_bytes, _ptr(minmax_ptr)))
+
     def sdf_from_mask(self, mask, resolution, add_virtual_border=False):
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         nx, ny, nz = m.shape
@@ -448,6 +479,10 @@ def sdf_multi_last_timing():
     ms = (ctypes.c_float * 5)()
     check(load().vgt_hipx_last_timing(ms))
     return dict(zip(("setup_ms", "upload_ms", "compute_ms", "download_ms", "total_ms"), [float(v) for v in ms]))
+
+
+def sdf_batch_workspace_bytes(batch, shape):
+    return int(load().vgt_hip_sdf_batch_workspace_bytes(int(batch), *[int(v) for v in shape]))
 
 
 def sdf_workspace_bytes(shape, variant=0):
@@ -652,8 +687,23 @@ class Cells:
                                           ctypes.byref(hi)))
         return out, float(lo.value), float(hi.value)
 
-    def separate_object_sdfs(self, resolution, object_ids, **kw):
-        """MakeSeparateObjectSDFs: {object id: (sdf, min, max)}."""
+    def separate_object_sdfs(self, resolution, object_ids, unknown_is_filled=True, add_virtual_border=False):
+        """MakeSeparateObjectSDFs: {object id: (sdf, min, max)}, all objects in one batched extraction
+        (vgt_hip_cells_object_sdfs)."""
+        ids = np.ascontiguousarray(np.asarray(list(object_ids), dtype=np.uint32))
+        if ids.size == 0:
+            return {}
+        outs = [np.empty(self.shape, dtype=np.float32) for _ in range(ids.size)]
+        out_ptrs = (ctypes.c_void_p * ids.size)(*[o.ctypes.data for o in outs])
+        lo = np.zeros(ids.size, dtype=np.float32)
+        hi = np.zeros(ids.size, dtype=np.float32)
+        check(self._lib.vgt_hip_cells_object_sdfs(
+            self.ctx.handle, self.handle, _ptr(ids), ids.size, float(resolution), int(bool(unknown_is_filled)),
+            int(bool(add_virtual_border)), ctypes.cast(out_ptrs, ctypes.c_void_p), _ptr(lo), _ptr(hi)))
+        return {int(i): (outs[k], float(lo[k]), float(hi[k])) for k, i in enumerate(ids)}
+
+    def separate_object_sdfs_one_by_one(self, resolution, object_ids, **kw):
+        """The reference's own loop: one ExtractSignedDistanceField({id}) per object (vgt_hip_cells_sdf)."""
         return {int(i): self.sdf(resolution, [int(i)], **kw) for i in object_ids}
 
     def all_object_sdfs(self, resolution, **kw):

@@ -69,6 +69,26 @@ __global__ __launch_bounds__(kCellBlock) void CellMaskKernel(const uint8_t* __re
   }
 }
 
+// One byte mask PER LISTED OBJECT in one pass over the cells (MakeSeparateObjectSDFs / MakeAllObjectSDFs,
+// tagged_object_occupancy_map.hpp:249-290: one ExtractSignedDistanceField({id}) per object): masks[b][i] = the cell is
+// filled and belongs to object ids[b].  The masks lie one after the other, which is the layout of a batch
+// (SdfParams::batch): the three EDT passes then run ONCE for all the objects.
+__global__ __launch_bounds__(kCellBlock) void CellObjectMasksKernel(const uint8_t* __restrict__ cells,
+                                                                   int64_t num_cells, int cell_bytes,
+                                                                   int object_id_offset,
+                                                                   const uint32_t* __restrict__ ids, int num_ids,
+                                                                   int unknown_is_filled, uint8_t* __restrict__ masks)
+{
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < num_cells;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+  {
+    const uint8_t* rec = cells + i * cell_bytes;
+    const bool filled = OccupancyIsFilled(*reinterpret_cast<const float*>(rec), unknown_is_filled);
+    const uint32_t id = *reinterpret_cast<const uint32_t*>(rec + object_id_offset);
+    for (int b = 0; b < num_ids; b++) masks[static_cast<int64_t>(b) * num_cells + i] = (filled && id == ids[b]) ? 1 : 0;
+  }
+}
+
 // The distinct object ids > 0 of a grid in ONE pass (MakeAllObjectSDFs' std::set, tagged_object_occupancy_map.hpp:
 // 268-289): a hash set in device memory (0 = empty slot: valid ids are > 0).  Objects are contiguous in space, so a
 // lane whose id equals its left neighbour's leaves the insert to it.  count_overflow[1] is set when a key finds no
@@ -189,6 +209,16 @@ hipError_t LaunchCellMask(const void* cells_dev, int64_t num_cells, int cell_byt
   hipLaunchKernelGGL(CellMaskKernel, dim3(CellGrid(num_cells)), dim3(kCellBlock), 0, stream,
                      static_cast<const uint8_t*>(cells_dev), num_cells, cell_bytes, object_id_offset, mode,
                      objects_dev, num_objects, unknown_is_filled, mask_dev);
+  return hipGetLastError();
+}
+
+hipError_t LaunchCellObjectMasks(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                                 const uint32_t* ids_dev, int num_ids, int unknown_is_filled, uint8_t* masks_dev,
+                                 hipStream_t stream)
+{
+  hipLaunchKernelGGL(CellObjectMasksKernel, dim3(CellGrid(num_cells)), dim3(kCellBlock), 0, stream,
+                     static_cast<const uint8_t*>(cells_dev), num_cells, cell_bytes, object_id_offset, ids_dev, num_ids,
+                     unknown_is_filled, masks_dev);
   return hipGetLastError();
 }
 

@@ -599,15 +599,18 @@ __global__ __launch_bounds__(256) void PassXBruteFinalizeKernel(
 }
 
 #endif  // VGT_HIP_TESTING
-__global__ void InitMinMaxKernel(uint32_t* minmax_enc)
+__global__ void InitMinMaxKernel(uint32_t* minmax_enc, int count)
 {
-  minmax_enc[0] = 0xffffffffu;
-  minmax_enc[1] = 0u;
+  for (int i = static_cast<int>(threadIdx.x); i < count; i += static_cast<int>(blockDim.x))
+  {
+    minmax_enc[2 * i] = 0xffffffffu;
+    minmax_enc[2 * i + 1] = 0u;
+  }
 }
-__global__ void DecodeMinMaxKernel(const uint32_t* minmax_enc, float* out)
+__global__ void DecodeMinMaxKernel(const uint32_t* minmax_enc, float* out, int count)
 {
-  out[0] = DecodeOrdered(minmax_enc[0]);
-  out[1] = DecodeOrdered(minmax_enc[1]);
+  for (int i = static_cast<int>(threadIdx.x); i < 2 * count; i += static_cast<int>(blockDim.x))
+    out[i] = DecodeOrdered(minmax_enc[i]);
 }
 
 int GridFor(int64_t work_items, int block)
@@ -829,15 +832,16 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
 #endif
 }
 
-hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream)
+hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream, int64_t count)
 {
-  hipLaunchKernelGGL(InitMinMaxKernel, dim3(1), dim3(1), 0, stream, minmax_enc);
+  hipLaunchKernelGGL(InitMinMaxKernel, dim3(1), dim3(count > 1 ? 64 : 1), 0, stream, minmax_enc, static_cast<int>(count));
   return hipGetLastError();
 }
 
-hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream)
+hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream, int64_t count)
 {
-  hipLaunchKernelGGL(DecodeMinMaxKernel, dim3(1), dim3(1), 0, stream, minmax_enc, minmax_out);
+  hipLaunchKernelGGL(DecodeMinMaxKernel, dim3(1), dim3(count > 1 ? 64 : 1), 0, stream, minmax_enc, minmax_out,
+                     static_cast<int>(count));
   return hipGetLastError();
 }
 }  // namespace vgt

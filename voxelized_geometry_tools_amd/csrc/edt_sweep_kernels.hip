@@ -111,6 +111,11 @@ struct SweepGeom
   int add_virtual_border;
   int z_offset, nz_global;
   int outer_begin;
+  // Batches of equal grids (X pass; the Y pass sees a batch as one grid of batch x nx slices): outer index o belongs to
+  // grid o / batch_outers, whose lines start batch_skip elements further on per grid than outer_stride alone says, and
+  // whose extrema go to minmax_enc[2 * grid].  One grid: batch_outers = outers (grid 0 for every item), batch_skip = 0.
+  int batch_outers;
+  int64_t batch_skip;
 };
 
 template <bool kPacked>
@@ -428,6 +433,32 @@ __device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X 
 #define VGT_PHASE_FLUSH()
 #endif
 
+// The wave's extrema (none when lo > hi) into minmax_enc[0 / 1], ordered encodings: one atomic pair per call.
+__device__ __forceinline__ void WaveMinMax(float lo_value, float hi_value, uint32_t* minmax_enc)
+{
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  if (lo_value <= hi_value)
+  {
+    lo = EncodeOrdered(lo_value);
+    hi = EncodeOrdered(hi_value);
+  }
+#ifdef VGT_HOST_EMULATION
+  minmax_enc[0] = min(minmax_enc[0], lo);
+  minmax_enc[1] = max(minmax_enc[1], hi);
+#else
+  for (int off = kWaveSize / 2; off > 0; off >>= 1)
+  {
+    lo = min(lo, static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), off)));
+    hi = max(hi, static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), off)));
+  }
+  if (threadIdx.x == 0)
+  {
+    atomicMin(&minmax_enc[0], lo);
+    atomicMax(&minmax_enc[1], hi);
+  }
+#endif
+}
+
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
 template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
 __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
@@ -498,13 +529,17 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   VGT_PHASE_MARK(phase_item_begin);
   const int outer = item / g.zsegs;
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
+  // (a batch of grids: which grid, and the outer index inside it -- one grid: 0 and `outer`)
+  const bool batched = g.batch_outers != g.outers;
+  const int batch_index = batched ? outer / g.batch_outers : 0;
+  const int outer_in_grid = outer - batch_index * g.batch_outers;
+  const int64_t outer_offset = static_cast<int64_t>(outer) * g.outer_stride + static_cast<int64_t>(batch_index) * g.batch_skip;
   // Lanes beyond the grid repeat the last line of the grid: same input, same result, stored to the same address.
   const uint32_t zl = static_cast<uint32_t>(min(lane, g.nz - 1 - z0));
   [[maybe_unused]] uint32_t lane_bytes = zl * 4u;  // the lane's byte offset inside a row of 4-byte values (see LaneAddress)
   // (records: [outer][64-voxel segment][row], one per row of this item)
-  const InT* const wave_in = kRecords ? in + static_cast<int64_t>(item) * n
-                                      : in + (static_cast<int64_t>(outer) * g.outer_stride + z0);
-  OutT* const wave_out = out + (static_cast<int64_t>(outer) * g.outer_stride + z0);
+  const InT* const wave_in = kRecords ? in + static_cast<int64_t>(item) * n : in + (outer_offset + z0);
+  OutT* const wave_out = out + (outer_offset + z0);
 
   // ---- stack state.  Entries [0, depth): [0, lo) live in the spill buffer, [lo, depth) in the ring (slot = index
   // mod kRing).  D and L are depth and lo times the slot size, so that (D & kRingMask) | lane_entry is the ring
@@ -1224,8 +1259,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                     if (g.add_virtual_border)
                     {
                       const int qq = q + j;
-                      const int x = (g.pass_axis == 0) ? qq : outer + g.outer_begin;
-                      const int y = (g.pass_axis == 0) ? outer + g.outer_begin : qq;
+                      const int x = (g.pass_axis == 0) ? qq : outer_in_grid + g.outer_begin;
+                      const int y = (g.pass_axis == 0) ? outer_in_grid + g.outer_begin : qq;
                       const int32_t site = (d2 >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(d2);
                       const int32_t clamped = ClampToVirtualBorder(site, x, y, z0 + static_cast<int>(zl) + g.z_offset, g.nx,
                                                                    g.ny, g.nz_global);
@@ -1329,6 +1364,16 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     VGT_PHASE_ADD(5, phase_item_begin, phase_item_end);
     VGT_PHASE_FLUSH();
   }
+  if constexpr (kFinal)
+  {
+    // a batch of grids: every grid has its own extrema, so a workgroup hands them over item by item
+    if (batched)
+    {
+      WaveMinMax(lo_value, hi_value, minmax_enc + 2 * batch_index);
+      lo_value = INFINITY;
+      hi_value = -INFINITY;
+    }
+  }
   }  // next unit of work
 #ifdef VGT_SWEEP_TIMING
   if (lane == 0)
@@ -1407,6 +1452,11 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
   if (items > 0x7fffffffLL) return hipErrorInvalidValue;
   g.items = static_cast<int>(items);
   g.outers = static_cast<int>(outer_count);
+  if (g.batch_outers <= 0)
+  {
+    g.batch_outers = g.outers;  // one grid
+    g.batch_skip = 0;
+  }
   const bool packed = PackedEntries(g.n, max_input);
   int64_t slots = items < kSweepSlots ? items : kSweepSlots;
   {
@@ -1490,11 +1540,11 @@ int64_t MaxInputX(const SdfParams& p) { return MaxInputY(p) + (p.ny - 1) * (p.ny
 
 // Scratch of the sweep passes for a grid: the larger of the two passes' needs (they use the same bytes, one after
 // the other).
-size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz)
+size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz, int64_t batch)
 {
   const int64_t zsegs = (nz + kWaveSize - 1) / kWaveSize;
   const int64_t max_y = (nz - 1) * (nz - 1), max_x = max_y + (ny - 1) * (ny - 1);
-  const size_t y = PassScratchBytes(ny, nx * zsegs, max_y), x = PassScratchBytes(nx, ny * zsegs, max_x);
+  const size_t y = PassScratchBytes(ny, batch * nx * zsegs, max_y), x = PassScratchBytes(nx, batch * ny * zsegs, max_x);
   return (y > x ? y : x) + 256;
 }
 
@@ -1530,6 +1580,15 @@ hipError_t LaunchPassXSweepFinalizeRange(const int32_t* in32, float* sdf, uint32
 {
   int64_t outer_count = 0;
   SweepGeom g = SweepGeometry(p, 0, &outer_count);
+  if (p.batch > 1)
+  {
+    // p.batch grids of p.nx x p.ny x p.nz, one after the other in both fields: the outer indices of grid b are
+    // [b * ny, (b + 1) * ny), its lines begin (nx - 1) * ny * nz elements further on per grid than y * nz alone says
+    if (outer_count_or_all >= 0 || p.batch * outer_count > 0x7fffffffLL) return hipErrorInvalidValue;
+    g.batch_outers = static_cast<int>(outer_count);
+    g.batch_skip = (p.nx - 1) * p.ny * p.nz;
+    outer_count *= p.batch;
+  }
   if (outer_count_or_all >= 0)
   {
     in32 += outer_begin * g.outer_stride;

@@ -285,6 +285,43 @@ SignedDistanceField ExtractSignedDistanceField(
   return sdf;
 }
 
+std::vector<SignedDistanceField> ExtractSignedDistanceFields(
+    const std::vector<const OccupancyMap*>& maps, const SignedDistanceFieldGenerationParameters& parameters)
+{
+  std::vector<SignedDistanceField> fields(maps.size());
+  if (maps.empty()) return fields;
+  std::vector<const float*> inputs;
+  std::vector<float*> outputs;
+  for (size_t i = 0; i < maps.size(); i++)
+  {
+    const OccupancyMap* map = maps[i];
+    if (!map || !map->IsInitialized()) throw std::invalid_argument("Grid must be initialized");
+    if (!map->SameSizes(*maps[0])) throw std::invalid_argument("the maps of a batch must have the same sizes");
+    fields[i].oob_value = parameters.oob_value;
+    fields[i].grid = DenseGrid(map->OriginTransform(), map->Frame(), map->Resolution(), map->NumXVoxels(),
+                               map->NumYVoxels(), map->NumZVoxels(), parameters.oob_value);
+    inputs.push_back(map->GetImmutableRawData().data());
+    outputs.push_back(fields[i].grid.GetMutableRawData().data());
+  }
+  std::vector<float> minima(maps.size()), maxima(maps.size());
+  vgt_hip_ctx* ctx = SharedSdfContext(parameters.hip_device);
+  const OccupancyMap& first = *maps[0];
+  const int rc = vgt_hip_sdf_batch_from_occupancy_f32(
+      ctx, inputs.data(), static_cast<int64_t>(maps.size()), first.NumXVoxels(), first.NumYVoxels(),
+      first.NumZVoxels(), first.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+      parameters.add_virtual_border ? 1 : 0, outputs.data(), minima.data(), maxima.data());
+  const std::string msg = (rc == VGT_HIP_OK) ? std::string() : std::string(vgt_hip_last_error());
+  if (rc == VGT_HIP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+  if (rc != VGT_HIP_OK) throw std::runtime_error(msg);
+  for (size_t i = 0; i < maps.size(); i++)
+  {
+    fields[i].minimum = minima[i];
+    fields[i].maximum = maxima[i];
+    fields[i].locked = true;
+  }
+  return fields;
+}
+
 namespace
 {
 [[noreturn]] void ThrowForCode(int rc, const std::string& msg)
@@ -468,9 +505,33 @@ SignedDistanceField DeviceTaggedObjectMap::ExtractSignedDistanceField(
 std::map<uint32_t, SignedDistanceField> DeviceTaggedObjectMap::MakeSeparateObjectSDFs(
     const std::vector<uint32_t>& object_ids, const SignedDistanceFieldGenerationParameters& parameters) const
 {
+  // The reference runs one whole ExtractSignedDistanceField({id}) per object (tagged_object_occupancy_map.hpp:
+  // 249-263); here the objects are one batch: one pass over the cells for all their masks, the EDT passes once over
+  // all of them, the fields straight into the map's entries (vgt_hip_cells_object_sdfs).
   std::map<uint32_t, SignedDistanceField> per_object_sdfs;
+  std::vector<uint32_t> ids;
   for (const uint32_t object_id : object_ids)
-    per_object_sdfs[object_id] = ExtractSignedDistanceField(std::vector<uint32_t>{object_id}, parameters);
+    if (per_object_sdfs.find(object_id) == per_object_sdfs.end())
+    {
+      per_object_sdfs.emplace(object_id, EmptyField(parameters));
+      ids.push_back(object_id);
+    }
+  if (ids.empty()) return per_object_sdfs;
+  std::vector<float*> fields;
+  for (const uint32_t object_id : ids) fields.push_back(per_object_sdfs.at(object_id).grid.GetMutableRawData().data());
+  std::vector<float> minima(ids.size()), maxima(ids.size());
+  const int rc = vgt_hip_cells_object_sdfs(ctx_, cells_, ids.data(), static_cast<int64_t>(ids.size()),
+                                           shape_.Resolution(), parameters.unknown_is_filled ? 1 : 0,
+                                           parameters.add_virtual_border ? 1 : 0, fields.data(), minima.data(),
+                                           maxima.data());
+  if (rc != VGT_HIP_OK) ThrowForCode(rc, vgt_hip_last_error());
+  for (size_t k = 0; k < ids.size(); k++)
+  {
+    SignedDistanceField& sdf = per_object_sdfs.at(ids[k]);
+    sdf.minimum = minima[k];
+    sdf.maximum = maxima[k];
+    sdf.locked = true;
+  }
   return per_object_sdfs;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <new>
@@ -132,6 +133,13 @@ struct vgt_hip_cells
   uint32_t* objects = nullptr;  // object list of the current call
   size_t objects_capacity = 0;
   uint32_t* scalar = nullptr;   // two uint32: result of a reduction + found flag
+  // vgt_hip_cells_object_sdfs: masks, fields (+ extrema) and workspace of a batch of per-object extractions (grow-only)
+  void* batch_masks = nullptr;
+  size_t batch_masks_bytes = 0;
+  void* batch_sdf = nullptr;
+  size_t batch_sdf_bytes = 0;
+  void* batch_ws = nullptr;
+  size_t batch_ws_bytes = 0;
 };
 
 namespace
@@ -323,17 +331,19 @@ struct SdfWorkspace
   size_t bytes;
 };
 
-SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, vgt::EdtVariant variant)
+// (batch > 1: `batch` grids of nx x ny x nz one after the other -- records and the intermediate field of batch * nx
+// slices, a pair of extrema per grid, the line passes' scratch for the batch's items; default pipeline only)
+SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, vgt::EdtVariant variant, int64_t batch = 1)
 {
   SdfWorkspace ws;
-  const size_t n = static_cast<size_t>(nx * ny * nz);
+  const size_t n = static_cast<size_t>(batch * nx * ny * nz);
   size_t off = 0;
   ws.records = nullptr;
   ws.t16 = nullptr;
   if (variant == vgt::EdtVariant::kDefault)
   {
     ws.records = reinterpret_cast<vgt::ClassRecord*>(static_cast<char*>(base) + off);
-    off = AlignUp(off + vgt::ClassRecordBytes(nx, ny, nz), 256);
+    off = AlignUp(off + vgt::ClassRecordBytes(batch * nx, ny, nz), 256);
   }
   else
   {
@@ -343,9 +353,9 @@ SdfWorkspace CarveWorkspace(void* base, int64_t nx, int64_t ny, int64_t nz, vgt:
   ws.t32 = reinterpret_cast<int32_t*>(static_cast<char*>(base) + off);
   off = AlignUp(off + n * sizeof(int32_t), 256);
   ws.minmax_enc = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + off);
-  off += 256;
+  off += AlignUp(static_cast<size_t>(batch) * 2 * sizeof(uint32_t), 256);
   ws.sweep_scratch.ptr = static_cast<char*>(base) + off;
-  ws.sweep_scratch.bytes = vgt::SweepPassScratchBytes(nx, ny, nz);
+  ws.sweep_scratch.bytes = vgt::SweepPassScratchBytes(nx, ny, nz, batch);
   off = AlignUp(off + ws.sweep_scratch.bytes, 256);
   ws.bytes = off;
   return ws;
@@ -414,19 +424,37 @@ int RunSdfPipeline(vgt_hip_ctx* ctx, const InT* input_dev, const vgt::SdfParams&
                    void* workspace_dev, size_t workspace_bytes, float* minmax_dev,
                    hipEvent_t* events)
 {
-  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant);
+  if (p.batch > 1 && ctx->variant != vgt::EdtVariant::kDefault)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batches run on the default EDT pipeline only");
+  const SdfWorkspace ws = CarveWorkspace(workspace_dev, p.nx, p.ny, p.nz, ctx->variant, p.batch);
   if (workspace_dev == nullptr || workspace_bytes < ws.bytes)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
   hipStream_t s = ctx->stream;
-  VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s), "init min/max");
+  // A batch of grids (one after the other in every buffer) is ONE grid of batch * nx slices to pass 1 and to the Y
+  // pass -- their lines never leave a slice -- and p.batch grids to the X pass, whose lines run along x.
+  vgt::SdfParams slices = p;
+  slices.nx = p.nx * p.batch;
+  slices.batch = 1;
+  VGT_TRY_HIP(vgt::LaunchInitMinMax(ws.minmax_enc, s, p.batch), "init min/max");
   if (events) VGT_TRY_HIP(hipEventRecord(events[0], s), "event record");
-  VGT_TRY_HIP(LaunchPassOne<InT>(input_dev, ws, p, 0, nullptr, s), "pass 1");
+  VGT_TRY_HIP(LaunchPassOne<InT>(input_dev, ws, slices, 0, nullptr, s), "pass 1");
   if (events) VGT_TRY_HIP(hipEventRecord(events[1], s), "event record");
-  VGT_TRY_HIP(LaunchPassTwo(ws, p, 0, ctx->variant, s), "Y pass");
+  VGT_TRY_HIP(LaunchPassTwo(ws, slices, 0, ctx->variant, s), "Y pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[2], s), "event record");
   VGT_TRY_HIP(vgt::LaunchPassXFinalize(ws.t32, sdf_dev, ws.minmax_enc, ws.sweep_scratch, p, ctx->variant, s), "X pass");
   if (events) VGT_TRY_HIP(hipEventRecord(events[3], s), "event record");
-  if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s), "min/max");
+  if (minmax_dev) VGT_TRY_HIP(vgt::LaunchDecodeMinMax(ws.minmax_enc, minmax_dev, s, p.batch), "min/max");
+  return VGT_HIP_OK;
+}
+
+// Limits of a batch: the stacked grid's lines and voxels must stay inside what pass 1 and the sweeps index with.
+int CheckBatch(int64_t batch, int64_t nx, int64_t ny, int64_t nz)
+{
+  if (batch <= 0) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batch must be positive");
+  const int64_t zsegs = (nz + 63) / 64;
+  if (batch > (int64_t{1} << 20) || batch * nx * ny >= (int64_t{1} << 28) || batch * nx * zsegs > 0x7fffffffLL ||
+      batch * ny * zsegs > 0x7fffffffLL)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batch too large: batch * nx * ny must stay below 2^28 lines");
   return VGT_HIP_OK;
 }
 
@@ -1459,6 +1487,102 @@ int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, in
   return result;
 }
 
+size_t vgt_hip_sdf_batch_workspace_bytes(int64_t batch, int64_t nx, int64_t ny, int64_t nz)
+{
+  if (batch <= 0 || nx <= 0 || ny <= 0 || nz <= 0) return 0;
+  return CarveWorkspace(nullptr, nx, ny, nz, vgt::EdtVariant::kDefault, batch).bytes;
+}
+
+int vgt_hip_sdf_batch_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t batch, int64_t nx, int64_t ny,
+                          int64_t nz, double resolution, int unknown_is_filled, int add_virtual_border,
+                          float* sdf_dev, void* workspace_dev, size_t workspace_bytes, float* minmax_dev)
+{
+  if (!ctx || !occupancy_dev || !sdf_dev) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc == VGT_HIP_OK) rc = CheckBatch(batch, nx, ny, nz);
+  if (rc != VGT_HIP_OK) return rc;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0, add_virtual_border ? 1 : 0};
+  p.batch = batch;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  hipEvent_t* slot = TimingSlot(ctx);
+  const int result = RunSdfPipeline<float>(ctx, occupancy_dev, p, sdf_dev, workspace_dev, workspace_bytes,
+                                           minmax_dev, slot);
+  if (slot && result == VGT_HIP_OK) ctx->timing_kind[static_cast<size_t>(ctx->timing_used++)] = 1;
+  return result;
+}
+
+int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* occupancy_host, int64_t batch,
+                                         int64_t nx, int64_t ny, int64_t nz, double resolution,
+                                         int unknown_is_filled, int add_virtual_border, float* const* sdf_host,
+                                         float* out_min, float* out_max)
+{
+  if (!ctx || !occupancy_host || !sdf_host) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = CheckSdfShape(nx, ny, nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  if (batch <= 0) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batch must be positive");
+  for (int64_t b = 0; b < batch; b++)
+    if (!occupancy_host[b] || !sdf_host[b]) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null grid in the batch");
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const size_t n = static_cast<size_t>(nx * ny * nz);
+  // Grids per launch: as many as the limits of a batch and a memory budget allow (the context keeps the buffers).
+  int64_t group = batch;
+  const int64_t by_lines = ((int64_t{1} << 28) - 1) / (nx * ny);
+  const int64_t by_bytes = static_cast<int64_t>((size_t{2} << 30) / (n * 9 + 1));
+  if (group > by_lines) group = by_lines;
+  if (group > by_bytes) group = by_bytes;
+  if (group < 1) group = 1;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  const size_t ws_bytes = CarveWorkspace(nullptr, nx, ny, nz, ctx->variant, ctx->variant == vgt::EdtVariant::kDefault ? group : 1).bytes;
+  VGT_TRY_HIP(Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, static_cast<size_t>(group) * n * sizeof(float)), "allocate SDF input");
+  VGT_TRY_HIP(Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, static_cast<size_t>(group) * n * sizeof(float) + static_cast<size_t>(group) * 2 * sizeof(float)),
+              "allocate SDF output");
+  VGT_TRY_HIP(Reserve(&ctx->sdf_ws, &ctx->sdf_ws_bytes, ws_bytes), "allocate SDF workspace");
+  float* const in_dev = static_cast<float*>(ctx->sdf_in);
+  float* const out_dev = static_cast<float*>(ctx->sdf_out);
+  float* const mm_dev = out_dev + static_cast<size_t>(group) * n;
+  std::vector<float> mm(static_cast<size_t>(group) * 2);
+  hipStream_t s = ctx->stream;
+  for (int64_t first = 0; first < batch; first += group)
+  {
+    const int64_t count = batch - first < group ? batch - first : group;
+    for (int64_t b = 0; b < count; b++)
+      VGT_TRY_HIP(hipMemcpyAsync(in_dev + static_cast<size_t>(b) * n, occupancy_host[first + b], n * sizeof(float),
+                                 hipMemcpyHostToDevice, s),
+                  "copy occupancy to device");
+    vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0, add_virtual_border ? 1 : 0};
+    if (ctx->variant == vgt::EdtVariant::kDefault)
+    {
+      p.batch = count;
+      rc = RunSdfPipeline<float>(ctx, in_dev, p, out_dev, ctx->sdf_ws, ctx->sdf_ws_bytes, mm_dev, nullptr);
+      if (rc != VGT_HIP_OK) return rc;
+    }
+    else
+    {
+      // (testing builds with a cross-check variant selected: grid by grid)
+      for (int64_t b = 0; b < count; b++)
+      {
+        rc = RunSdfPipeline<float>(ctx, in_dev + static_cast<size_t>(b) * n, p, out_dev + static_cast<size_t>(b) * n,
+                                   ctx->sdf_ws, ctx->sdf_ws_bytes, mm_dev + 2 * b, nullptr);
+        if (rc != VGT_HIP_OK) return rc;
+      }
+    }
+    for (int64_t b = 0; b < count; b++)
+      VGT_TRY_HIP(hipMemcpyAsync(sdf_host[first + b], out_dev + static_cast<size_t>(b) * n, n * sizeof(float),
+                                 hipMemcpyDeviceToHost, s),
+                  "copy SDF to host");
+    VGT_TRY_HIP(hipMemcpyAsync(mm.data(), mm_dev, static_cast<size_t>(count) * 2 * sizeof(float), hipMemcpyDeviceToHost, s),
+                "copy extrema to host");
+    VGT_TRY_HIP(hipStreamSynchronize(s), "synchronize");
+    for (int64_t b = 0; b < count; b++)
+    {
+      if (out_min) out_min[first + b] = mm[static_cast<size_t>(2 * b)];
+      if (out_max) out_max[first + b] = mm[static_cast<size_t>(2 * b + 1)];
+    }
+  }
+  return VGT_HIP_OK;
+}
+
 int vgt_hip_sdf_dev_timed(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                           int64_t nz, double resolution, int unknown_is_filled,
                           int add_virtual_border, float* sdf_dev, void* workspace_dev,
@@ -1512,6 +1636,9 @@ static void FreeCells(vgt_hip_cells* c)
   if (c->workspace) (void)hipFree(c->workspace);
   if (c->objects) (void)hipFree(c->objects);
   if (c->scalar) (void)hipFree(c->scalar);
+  if (c->batch_masks) (void)hipFree(c->batch_masks);
+  if (c->batch_sdf) (void)hipFree(c->batch_sdf);
+  if (c->batch_ws) (void)hipFree(c->batch_ws);
   delete c;
 }
 
@@ -1737,6 +1864,100 @@ int vgt_hip_cells_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* ob
     return rc;
   }
   return CopySdfToHost(ctx, cells->sdf, cells->nx * cells->ny * cells->nz, sdf_host, out_min, out_max);
+}
+
+int vgt_hip_cells_object_sdfs(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* object_ids,
+                              int64_t num_objects, double resolution, int unknown_is_filled, int add_virtual_border,
+                              float* const* sdf_host, float* out_min, float* out_max)
+{
+  int rc = CheckCells(ctx, cells);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_objects < 0 || (num_objects > 0 && (!object_ids || !sdf_host)))
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (num_objects > 0 && cells->object_id_offset < 0)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "this cell type carries no object id");
+  for (int64_t b = 0; b < num_objects; b++)
+    if (!sdf_host[b]) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "null field in the batch");
+  rc = CheckSdfShape(cells->nx, cells->ny, cells->nz, resolution);
+  if (rc != VGT_HIP_OK) return rc;
+  if (num_objects == 0) return VGT_HIP_OK;
+  VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
+  const int64_t nx = cells->nx, ny = cells->ny, nz = cells->nz;
+  const size_t n = static_cast<size_t>(nx * ny * nz);
+  // Objects per launch: what the limits of a batch and a memory budget allow (9.25 bytes per voxel and object: mask,
+  // intermediate field, field, records).
+  int64_t group = num_objects;
+  const int64_t by_lines = ((int64_t{1} << 28) - 1) / (nx * ny);
+  const int64_t by_bytes = static_cast<int64_t>((size_t{4} << 30) / (n * 10 + 1));
+  if (group > by_lines) group = by_lines;
+  if (group > by_bytes) group = by_bytes;
+  if (group < 1) group = 1;
+  std::lock_guard<std::mutex> lock(ctx->mutex);
+  if (ctx->variant != vgt::EdtVariant::kDefault)
+    return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batches run on the default EDT pipeline only");
+  hipStream_t s = ctx->stream;
+  const size_t ws_bytes = CarveWorkspace(nullptr, nx, ny, nz, ctx->variant, group).bytes;
+  const size_t sdf_bytes = static_cast<size_t>(group) * (n + 2) * sizeof(float);
+  if (cells->batch_masks_bytes < static_cast<size_t>(group) * n || cells->batch_sdf_bytes < sdf_bytes ||
+      cells->batch_ws_bytes < ws_bytes || cells->objects_capacity < static_cast<size_t>(group))
+    VGT_TRY_HIP(hipStreamSynchronize(s), "drain before regrowing the batch buffers");
+  VGT_TRY_HIP(Reserve(&cells->batch_masks, &cells->batch_masks_bytes, static_cast<size_t>(group) * n), "allocate masks");
+  VGT_TRY_HIP(Reserve(&cells->batch_sdf, &cells->batch_sdf_bytes, sdf_bytes), "allocate fields");
+  VGT_TRY_HIP(Reserve(&cells->batch_ws, &cells->batch_ws_bytes, ws_bytes), "allocate SDF workspace");
+  if (cells->objects_capacity < static_cast<size_t>(group))
+  {
+    if (cells->objects) (void)hipFree(cells->objects);
+    cells->objects = nullptr;
+    cells->objects_capacity = 0;
+    VGT_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&cells->objects), static_cast<size_t>(group) * sizeof(uint32_t)),
+                "allocate object list");
+    cells->objects_capacity = static_cast<size_t>(group);
+  }
+  float* const sdf_dev = static_cast<float*>(cells->batch_sdf);
+  float* const mm_dev = sdf_dev + static_cast<size_t>(group) * n;
+  std::vector<float> mm(static_cast<size_t>(group) * 2);
+  for (int64_t first = 0; first < num_objects; first += group)
+  {
+    const int64_t count = num_objects - first < group ? num_objects - first : group;
+    // (pageable source: staged when the call returns)
+    VGT_TRY_HIP(hipMemcpyAsync(cells->objects, object_ids + first, static_cast<size_t>(count) * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, s),
+                "upload object ids");
+    VGT_TRY_HIP(vgt::LaunchCellObjectMasks(cells->records, static_cast<int64_t>(n), cells->cell_bytes,
+                                           cells->object_id_offset, cells->objects, static_cast<int>(count),
+                                           unknown_is_filled ? 1 : 0, static_cast<uint8_t*>(cells->batch_masks), s),
+                "object masks");
+    vgt::SdfParams p{nx, ny, nz, resolution, 0, add_virtual_border ? 1 : 0};
+    p.batch = count;
+    rc = RunSdfPipeline<uint8_t>(ctx, static_cast<const uint8_t*>(cells->batch_masks), p, sdf_dev, cells->batch_ws,
+                                 cells->batch_ws_bytes, mm_dev, nullptr);
+    if (rc != VGT_HIP_OK)
+    {
+      (void)hipStreamSynchronize(s);
+      return rc;
+    }
+    {
+      // the callers' arrays are page-locked for the copies (pageable memory moves at a fraction of the link rate)
+      std::vector<std::unique_ptr<ScopedHostPin>> pins;
+      for (int64_t b = 0; b < count; b++)
+        pins.emplace_back(new (std::nothrow) ScopedHostPin(sdf_host[first + b], n * sizeof(float)));
+      hipError_t err = hipSuccess;
+      for (int64_t b = 0; b < count && err == hipSuccess; b++)
+        err = hipMemcpyAsync(sdf_host[first + b], sdf_dev + static_cast<size_t>(b) * n, n * sizeof(float),
+                             hipMemcpyDeviceToHost, s);
+      if (err == hipSuccess)
+        err = hipMemcpyAsync(mm.data(), mm_dev, static_cast<size_t>(count) * 2 * sizeof(float), hipMemcpyDeviceToHost, s);
+      const hipError_t sync = hipStreamSynchronize(s);
+      if (err == hipSuccess) err = sync;
+      VGT_TRY_HIP(err, "copy the objects' fields to the host");
+    }
+    for (int64_t b = 0; b < count; b++)
+    {
+      if (out_min) out_min[first + b] = mm[static_cast<size_t>(2 * b)];
+      if (out_max) out_max[first + b] = mm[static_cast<size_t>(2 * b + 1)];
+    }
+  }
+  return VGT_HIP_OK;
 }
 
 int vgt_hip_cells_free_and_named_objects_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, double resolution,

@@ -46,6 +46,10 @@ struct SdfParams
   // grid with nz_global voxels along Z.  Single device: z_offset = 0, nz_global = nz.
   int64_t z_offset = 0;
   int64_t nz_global = 0;
+  // A batch of `batch` equal grids, one after the other in every buffer (vgt_hip_sdf_batch_dev): pass 1 and the Y pass
+  // see it as one grid of batch * nx slices (their lines never leave a slice), only the X pass -- whose lines run along
+  // x -- and the extrema need to know.
+  int64_t batch = 1;
 };
 
 // Pass 1 of the default pipeline (edt_record_kernels.hip): the binarised grid as CLASS RECORDS, one 16-byte record per
@@ -166,14 +170,20 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
                                     hipStream_t stream);
 // Scratch for the lane-per-line sweep passes (edt_sweep_kernels.hip): work counter, spilled stack entries and sign
 // words of the workgroups in flight.
-size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz);
-hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream);
-hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream);
+size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz, int64_t batch = 1);
+// `count` pairs of ordered encodings (one per grid of a batch)
+hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream, int64_t count = 1);
+hipError_t LaunchDecodeMinMax(const uint32_t* minmax_enc, float* minmax_out, hipStream_t stream, int64_t count = 1);
 
 // --- launchers (cell_kernels.hip): map types whose cells carry an object id ---
 hipError_t LaunchCellMask(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
                           int mode, const uint32_t* objects_dev, int num_objects, int unknown_is_filled,
                           uint8_t* mask_dev, hipStream_t stream);
+// masks_dev[b * num_cells + i] = cell i is filled and belongs to object ids_dev[b]: the byte masks of a batch of
+// per-object extractions, one pass over the cells.
+hipError_t LaunchCellObjectMasks(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
+                                 const uint32_t* ids_dev, int num_ids, int unknown_is_filled, uint8_t* masks_dev,
+                                 hipStream_t stream);
 // Distinct object ids > 0 in one pass: table_dev = 2^table_log2 zeroed uint32 slots, ids_dev = room for as many ids,
 // count_overflow_dev = {number of ids, 1 if the table overflowed} (zeroed by the caller).
 hipError_t LaunchDistinctObjectIds(const void* cells_dev, int64_t num_cells, int cell_bytes, int object_id_offset,
