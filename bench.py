@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--no-raycast", action="store_true", help="skip the raycast voxelizer section (BASELINE config 3)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary SDF workloads (salt, unknown mix, 512^3, 64^3)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary SDF workloads (salt, unknown mix, 512^3, 64^3, batches)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     return ap.parse_args()
 
@@ -348,6 +348,93 @@ def secondary_workloads(ctx, torch, capi, device, res, steps=3, warmup=1):
             del occ, sdf, ws, minmax
         except Exception as exc:
             out[name] = {"error": repr(exc)}
+    out.update(batched_workloads(ctx, torch, capi, device, res))
+    return out
+
+
+def batched_workloads(ctx, torch, capi, device, res, steps=5, warmup=2):
+    """Many small grids in one call (vgt_hip_sdf_batch_dev) against the same grids one call each, device-resident, and
+    the per-object fields of a tagged map (vgt_hip_cells_object_sdfs, host buffers in and out) against one
+    vgt_hip_cells_sdf call per object: the reference loops one ExtractSignedDistanceField per map / per object id
+    (I/tagged_object_occupancy_map.hpp:249-290)."""
+    out = {}
+    try:
+        shape, batch = (64, 64, 64), 64
+        grids = torch.stack([device_occupancy(torch, shape, "spheres", 42 + b, device) for b in range(batch)])
+        fields = torch.empty_like(grids)
+        ws_bytes = capi.sdf_batch_workspace_bytes(batch, shape)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        mm = torch.zeros((batch, 2), dtype=torch.float32, device=device)
+        one_bytes = capi.sdf_workspace_bytes(shape, 0)
+
+        def batched():
+            ctx.sdf_batch_dev(grids.data_ptr(), batch, shape, res, fields.data_ptr(), ws.data_ptr(), ws_bytes, mm.data_ptr())
+
+        def looped():
+            for b in range(batch):
+                ctx.sdf_dev(grids[b].data_ptr(), shape, res, fields[b].data_ptr(), ws.data_ptr(), one_bytes,
+                            mm[b].data_ptr())
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        looped_ms = timed(looped)
+        reference = fields.clone()
+        fields.zero_()
+        ctx.timing_start(steps + warmup)
+        batched_ms = timed(batched)
+        per_step = ctx.timing_stop().astype(np.float64)
+        avg = per_step[warmup:].mean(axis=0) if len(per_step) > warmup else np.zeros(3)
+        vox = float(np.prod(shape)) * batch
+        out["batch 64 x 64^3 D1 spheres"] = {
+            "ms": round(batched_ms, 4), "Mvoxels_per_s": round(vox / (batched_ms * 1e-3) / 1e6, 1),
+            "kernel_ms": {k: round(float(v), 4) for k, v in zip(KERNEL_NAMES, avg)},
+            "whole_sdf_frac": round(3 * ALG_BYTES_PER_VOXEL_PASS * vox / (avg.sum() * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            if avg.sum() > 0 else None,
+            "same_grids_one_call_each_ms": round(looped_ms, 4), "speedup_over_single_calls": round(looped_ms / batched_ms, 1),
+            "bit_equal_to_single_calls": bool(torch.equal(fields.view(torch.int32), reference.view(torch.int32)))}
+        del grids, fields, ws, mm, reference
+    except Exception as exc:
+        out["batch 64 x 64^3 D1 spheres"] = {"error": repr(exc)}
+    try:
+        shape, objects = (128, 128, 128), 32
+        rng = np.random.default_rng(42)
+        rec = np.zeros(shape, dtype=capi.TAGGED_OBJECT_CELL)
+        for oid in range(1, objects + 1):
+            lo = [int(rng.integers(0, s - 24)) for s in shape]
+            ext = [int(rng.integers(4, 24)) for _ in shape]
+            box = tuple(slice(a, a + e) for a, e in zip(lo, ext))
+            rec["occupancy"][box] = 1.0
+            rec["object_id"][box] = oid
+        cells = ctx.cells(rec, shape)
+        ids = cells.object_ids()
+
+        def timed_host(fn, repeat=3):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(repeat):
+                result = fn()
+            return (time.perf_counter() - t0) / repeat * 1e3, result
+
+        batched_ms, batched = timed_host(lambda: cells.separate_object_sdfs(res, ids))
+        looped_ms, looped = timed_host(lambda: cells.separate_object_sdfs_one_by_one(res, ids))
+        same = all(np.array_equal(batched[int(i)][0].view(np.uint32), looped[int(i)][0].view(np.uint32)) and
+                   batched[int(i)][1:] == looped[int(i)][1:] for i in ids)
+        out["tagged map 128^3, %d object SDFs (host buffers)" % len(ids)] = {
+            "ms": round(batched_ms, 3), "one_call_per_object_ms": round(looped_ms, 3),
+            "speedup_over_single_calls": round(looped_ms / batched_ms, 2), "bit_equal_to_single_calls": bool(same),
+            "download_bound_ms": round(len(ids) * float(np.prod(shape)) * 4 / 25e9 * 1e3, 3),
+            "note": "download_bound = the objects' fields over a 25 GB/s link; both paths return host arrays"}
+        cells.close()
+    except Exception as exc:
+        out["tagged map 128^3 object SDFs"] = {"error": repr(exc)}
     return out
 
 

@@ -258,6 +258,9 @@ int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t cou
 /* Smallest grid (voxels) that the host-pointer SDF entry points pipeline (upload / kernels / download overlapped);
  * default 2^27, negative = never.  Lets the tests run that path on small grids. */
 int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels);
+/* Lines of at most `rows` rows (0 - 64; the product library: always 64) take the short-line kernels
+ * (csrc/edt_short_kernels.hip) instead of the sweeps: lets the tests and benches run either formulation on any length. */
+int vgt_hip_testing_set_short_line_rows(int rows);
 /* Pass 1 alone, for a test of the record format itself (csrc/vgt_internal.hpp, ClassRecord): the class records of a
  * device-resident occupancy grid, [x][64-voxel word][y] x 4 uint32 (mask_lo, mask_hi, below2, above2), into records_dev
  * (vgt_hip_testing_class_record_bytes bytes); summary_dev (optional): the 4-byte slab summaries per line, in which case the

@@ -22,6 +22,8 @@
 // the LDS-tiled lower-envelope passes (variant 2) live in edt_hull_kernels.hip, also a testing-only file.
 #include "edt_device.hpp"
 
+#include <atomic>
+
 namespace vgt
 {
 namespace
@@ -784,6 +786,9 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                                SweepScratch scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream)
 {
+  // (short lines: the default pipeline only -- the cross-check variant 3 keeps the sweeps on every length)
+  if (variant == EdtVariant::kDefault && p.nx <= ShortLineRows())
+    return LaunchPassXShortFinalizeRange(in32, sdf, minmax_enc, p, 0, -1, stream);
   if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, 0, -1, stream);
 #ifdef VGT_HIP_TESTING
@@ -820,6 +825,8 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
                                     const SdfParams& p, EdtVariant variant, int64_t outer_begin, int64_t outer_count,
                                     hipStream_t stream)
 {
+  if (variant == EdtVariant::kDefault && p.nx <= ShortLineRows())
+    return LaunchPassXShortFinalizeRange(in32, sdf, minmax_enc, p, outer_begin, outer_count, stream);
   if (IsSweepVariant(variant))
     return LaunchPassXSweepFinalizeRange(in32, sdf, minmax_enc, scratch, p, outer_begin, outer_count, stream);
 #ifdef VGT_HIP_TESTING
@@ -831,6 +838,14 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
   return hipErrorInvalidValue;
 #endif
 }
+
+#ifdef VGT_HIP_TESTING
+std::atomic<int> g_short_line_rows{kShortLineRows};
+int ShortLineRows() { return g_short_line_rows.load(); }
+void SetShortLineRows(int rows) { g_short_line_rows.store(rows < 0 ? 0 : (rows > kShortLineRows ? kShortLineRows : rows)); }
+#else
+int ShortLineRows() { return kShortLineRows; }
+#endif
 
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream, int64_t count)
 {

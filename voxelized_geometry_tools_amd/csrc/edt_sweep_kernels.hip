@@ -42,6 +42,7 @@
 // processed kBand at a time (registers), the code below keeps rare paths (refills, exact final conversion) out of
 // the straight-line code, and register and LDS use are sized for kWaves waves per SIMD.
 #include "edt_device.hpp"
+#include "edt_line_geom.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -93,30 +94,6 @@ struct RingShape
 constexpr int kFar = 32768;              // "no row of the other class": kFar^2 is above every real squared distance
 static_assert(kWord % kBand == 0 && kBand % 2 == 0, "sizes");
 
-struct SweepGeom
-{
-  int n;                 // rows along the pass axis
-  int nz;                // extent of the contiguous axis
-  int zsegs;             // waves per outer index
-  int items;             // outer indices x zsegs: units of work, dealt to the workgroups through counters
-  int outers;            // outer indices
-  int groups;            // workgroup b draws from counter b % groups, which deals the outer indices = b (mod groups)
-  int nwords;            // ceil(n / 32)
-  int chunks;            // spill chunks per lane
-  int64_t row_stride;    // elements between consecutive rows
-  int64_t outer_stride;  // elements between consecutive outer indices
-  int nx, ny;
-  int pass_axis;         // 0 = X pass (outer = y), 1 = Y pass (outer = x)
-  double resolution;
-  int add_virtual_border;
-  int z_offset, nz_global;
-  int outer_begin;
-  // Batches of equal grids (X pass; the Y pass sees a batch as one grid of batch x nx slices): outer index o belongs to
-  // grid o / batch_outers, whose lines start batch_skip elements further on per grid than outer_stride alone says, and
-  // whose extrema go to minmax_enc[2 * grid].  One grid: batch_outers = outers (grid 0 for every item), batch_skip = 0.
-  int batch_outers;
-  int64_t batch_skip;
-};
 
 template <bool kPacked>
 struct Codec;
@@ -1501,33 +1478,6 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
   return hipGetLastError();
 }
 
-SweepGeom SweepGeometry(const SdfParams& p, int axis, int64_t* outer_count)
-{
-  SweepGeom g{};
-  g.nz = static_cast<int>(p.nz);
-  g.nx = static_cast<int>(p.nx);
-  g.ny = static_cast<int>(p.ny);
-  g.pass_axis = axis;
-  if (axis == 0)
-  {
-    g.n = static_cast<int>(p.nx);
-    g.row_stride = p.ny * p.nz;
-    g.outer_stride = p.nz;
-    *outer_count = p.ny;
-  }
-  else
-  {
-    g.n = static_cast<int>(p.ny);
-    g.row_stride = p.nz;
-    g.outer_stride = p.ny * p.nz;
-    *outer_count = p.nx;
-  }
-  g.resolution = p.resolution;
-  g.add_virtual_border = p.add_virtual_border;
-  g.z_offset = static_cast<int>(p.z_offset);
-  g.nz_global = static_cast<int>(p.nz_global > 0 ? p.nz_global : p.nz);
-  return g;
-}
 
 // Largest magnitudes the passes can meet: squared Z distances in the Y pass, plus squared Y distances in the X pass.
 int64_t MaxInputY(const SdfParams& p)
@@ -1566,6 +1516,7 @@ hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch sc
 hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                                    hipStream_t stream)
 {
+  if (p.ny <= ShortLineRows()) return LaunchPassYShortRecords(records, out32, p, stream);
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);
   return LaunchSweep<ClassRecord, int32_t, false>(records, out32, scratch.ptr, scratch.bytes, nullptr, g, outer_count,

@@ -161,6 +161,17 @@ hipError_t LaunchPassY(const int16_t* in16, int32_t* out32, SweepScratch scratch
 hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax_enc,
                                SweepScratch scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
+// Lines of at most kShortLineRows rows take the short-line kernels (edt_short_kernels.hip: the whole line in registers,
+// exhaustive search) instead of the sweeps; same encodings, same results.  ShortLineRows() is the limit in force:
+// kShortLineRows, or what a testing build was told (vgt_hip_testing_set_short_line_rows; 0 = sweeps for every length).
+constexpr int kShortLineRows = 64;
+int ShortLineRows();
+#ifdef VGT_HIP_TESTING
+void SetShortLineRows(int rows);
+#endif
+hipError_t LaunchPassYShortRecords(const ClassRecord* records, int32_t* out32, const SdfParams& p, hipStream_t stream);
+hipError_t LaunchPassXShortFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, const SdfParams& p,
+                                         int64_t outer_begin, int64_t outer_count, hipStream_t stream);
 // For callers that pipeline parts of a grid: the Y pass treats X slices independently (call LaunchPassY with nx =
 // slices of a contiguous part), and the X pass can be launched over a range of Y positions (full-grid pointers and
 // extents in `p`; outer_count < 0: the whole axis).  LinePassesTakeRanges: whether `variant` supports that for `p`.
