@@ -1516,7 +1516,9 @@ hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch sc
 hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, SweepScratch scratch, const SdfParams& p,
                                    hipStream_t stream)
 {
+#ifndef VGT_HOST_EMULATION  // (the CPU emulation runs the sweeps on every length)
   if (p.ny <= ShortLineRows()) return LaunchPassYShortRecords(records, out32, p, stream);
+#endif
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);
   return LaunchSweep<ClassRecord, int32_t, false>(records, out32, scratch.ptr, scratch.bytes, nullptr, g, outer_count,
