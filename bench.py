@@ -438,6 +438,45 @@ def batched_workloads(ctx, torch, capi, device, res, steps=5, warmup=2):
     return out
 
 
+def slab_run_check(torch, dist, capi, ctx, runner, sdf, minmax, full_shape, local_shape, z_offset, rank, world, device,
+                   dist_name, salt_p, res):
+    """N > 1 (and --force-slab): what the line's numbers were measured ON is checked in the run itself, after the timed
+    region.  (1) Every rank's summaries arrived intact: rank r's own checksum of what it sent, all-gathered, against the
+    checksum of block r of the gathered buffer.  (2) Rank 0 extracts the WHOLE grid alone with the plain one-GPU
+    pipeline (when its free memory allows: config 5 needs ~57 GB) and compares its slab of the distributed run -- whose
+    values depend on every other rank's summaries -- and the reduced extrema with it, bit for bit."""
+    out = {"backend": dist.get_backend(), "world_size_seen_by_the_collectives": dist.get_world_size()}
+    own = runner.summary.view(torch.int32).to(torch.int64).sum().reshape(1)
+    sums = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sums, own)
+    got = runner.gathered.view(torch.int32).to(torch.int64).reshape(world, -1).sum(dim=1)
+    out["summaries_of_all_ranks_intact"] = bool(torch.equal(sums, got))
+    if rank == 0:
+        need = float(np.prod(full_shape)) * 8 + capi.sdf_workspace_bytes(full_shape, 0) + 4 * 2 ** 30
+        free = torch.cuda.mem_get_info()[0]
+        if free < need:
+            out["rank0_slab_vs_single_gpu"] = "skipped: %.0f GiB free, %.0f needed" % (free / 2 ** 30, need / 2 ** 30)
+        else:
+            occ_full = device_occupancy(torch, full_shape, dist_name, 42, device, 0, full_shape, salt_p)
+            sdf_full = torch.empty(full_shape, dtype=torch.float32, device=device)
+            nbytes = capi.sdf_workspace_bytes(full_shape, 0)
+            ws_full = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            mm_full = torch.zeros(2, dtype=torch.float32, device=device)
+            ctx.sdf_dev(occ_full.data_ptr(), full_shape, res, sdf_full.data_ptr(), ws_full.data_ptr(), nbytes, mm_full.data_ptr())
+            torch.cuda.synchronize()
+            same = True
+            for x0 in range(0, full_shape[0], 64):  # (in pieces: the comparison's temporaries stay small)
+                a = sdf[x0:x0 + 64].view(torch.int32)
+                b = sdf_full[x0:x0 + 64, :, z_offset:z_offset + local_shape[2]].view(torch.int32)
+                same = same and bool(torch.equal(a, b))
+            out["rank0_slab_vs_single_gpu"] = {"bit_equal": same, "voxels_compared": int(np.prod(local_shape)),
+                                               "extrema_equal": bool(torch.equal(minmax, mm_full))}
+            del occ_full, sdf_full, ws_full
+            torch.cuda.empty_cache()
+    dist.barrier()
+    return out
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: run this script under torch.distributed.run with N ranks.
     Nothing in this (parent) process has initialised the GPU; the child is a subprocess, not an exec."""
@@ -573,6 +612,11 @@ def main():
         dist.all_reduce(pt, op=dist.ReduceOp.MAX)
         phase_ms = {k: round(float(v), 4) for k, v in zip(multi_gpu.SlabSdf.PHASES, pt.cpu().numpy())}
 
+    run_check = None
+    if dist_on:
+        run_check = slab_run_check(torch, dist, capi, ctx, runner, sdf, minmax, full_shape, local_shape, z_offset, rank,
+                                   world, device, args.dist, args.salt_p, res)
+
     total_vox = float(np.prod(full_shape))
     ms_per_step = elapsed / args.steps * 1e3
     value = total_vox / (elapsed / args.steps) / 1e6
@@ -609,7 +653,8 @@ def main():
         if dist_on:
             line["phase_ms"] = phase_ms
             line["exchange"] = {"collective": "all_gather_into_tensor", "record_bytes_per_line": 4,
-                                "bytes_received_per_rank": runner.exchange_bytes_received}
+                                "bytes_received_per_rank": runner.exchange_bytes_received,
+                                "ranks": world, "in_run_check": run_check}
             if not args.size:
                 line["same_workload_one_gpu"] = one_gpu_reference(workload_key)
         if headline and not args.no_secondary:

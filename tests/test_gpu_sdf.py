@@ -96,15 +96,17 @@ def test_random_grids_vs_oracle(ctx, oracle, shape):
 
 
 SHORT_SHAPES = [(1, 1, 1), (2, 7, 5), (8, 8, 8), (9, 16, 64), (17, 24, 65), (25, 33, 130), (32, 48, 40), (49, 63, 7),
-                (64, 64, 64), (63, 65, 66), (65, 64, 3), (40, 40, 40), (64, 200, 20), (300, 48, 70)]
+                (64, 64, 64), (63, 65, 66), (65, 64, 3), (40, 40, 40), (64, 200, 20), (300, 48, 70), (100, 128, 64),
+                (128, 96, 130), (97, 127, 5), (129, 128, 9)]
 
 
 @pytest.mark.parametrize("shape", SHORT_SHAPES)
 def test_short_line_kernels_and_sweeps_agree(vctx, oracle, shape):
     """Lines of at most 64 rows take the short-line kernels (csrc/edt_short_kernels.hip: whole line in registers,
     exhaustive search), longer ones the sweeps.  The testing library can move the limit: every shape here is extracted
-    with the limit at 64 (short kernels wherever an axis allows), at 0 (sweeps only) and at 24 (mixed), and all three
-    must equal the oracle bit for bit -- extents around every instantiation's size (8, 16, 24, 32, 48, 64)."""
+    with the limit at 64 (the product's setting: short kernels up to 64 rows, up to 128 when the launch has few items),
+    at 128 (every length up to 128 whatever the item count), at 0 (sweeps only) and at 24 (mixed), and all four must
+    equal the oracle bit for bit -- extents around every instantiation's size (8, 16, 24, 32, 48, 64, 96, 128)."""
     rng = np.random.default_rng(sum(shape))
     vctx.set_edt_variant(0)
     try:
@@ -112,7 +114,7 @@ def test_short_line_kernels_and_sweeps_agree(vctx, oracle, shape):
             occ = synthetic.make_occupancy(shape, kind, seed=int(rng.integers(1, 1000)))
             for uif, vb in ((True, False), (False, True)):
                 want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0213, uif, vb)
-                for rows in (64, 0, 24):
+                for rows in (64, 128, 0, 24):
                     vctx.set_short_line_rows(rows)
                     got, lo, hi = vctx.sdf_from_occupancy(occ, 0.0213, uif, vb)
                     assert bits_equal(got, want), (shape, kind, uif, vb, rows)

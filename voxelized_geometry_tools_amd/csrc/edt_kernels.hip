@@ -787,6 +787,8 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                                hipStream_t stream)
 {
   // (short lines: the default pipeline only -- the cross-check variant 3 keeps the sweeps on every length)
+  // (The X pass keeps the sweeps beyond 64 rows even when a launch has few items: measured equal at 80 - 128 rows,
+  // profiles/r5/short_vs_sweep.txt -- its rows pay for the final conversion either way.  The Y pass gains a third there.)
   if (variant == EdtVariant::kDefault && p.nx <= ShortLineRows())
     return LaunchPassXShortFinalizeRange(in32, sdf, minmax_enc, p, 0, -1, stream);
   if (IsSweepVariant(variant))
@@ -842,7 +844,10 @@ hipError_t LaunchPassXFinalizeRange(const int32_t* in32, float* sdf, uint32_t* m
 #ifdef VGT_HIP_TESTING
 std::atomic<int> g_short_line_rows{kShortLineRows};
 int ShortLineRows() { return g_short_line_rows.load(); }
-void SetShortLineRows(int rows) { g_short_line_rows.store(rows < 0 ? 0 : (rows > kShortLineRows ? kShortLineRows : rows)); }
+void SetShortLineRows(int rows)
+{
+  g_short_line_rows.store(rows < 0 ? 0 : (rows > kShortLineRowsFewItems ? kShortLineRowsFewItems : rows));
+}
 #else
 int ShortLineRows() { return kShortLineRows; }
 #endif

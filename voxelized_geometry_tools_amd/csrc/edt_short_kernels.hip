@@ -1,4 +1,5 @@
-// Line passes (Y and X) of the exact signed EDT for SHORT lines (at most 64 rows) on gfx950: the whole line in registers,
+// Line passes (Y and X) of the exact signed EDT for SHORT lines (at most 64 rows; 128 when a launch has few items) on
+// gfx950: the whole line in registers,
 // the 1-D transform by exhaustive search.
 //
 // Why a second formulation.  The lane-per-line sweeps (edt_sweep_kernels.hip) walk a line row by row, twice, through a
@@ -22,6 +23,8 @@
 #include "edt_device.hpp"
 #include "edt_line_geom.hpp"
 
+#include <type_traits>
+
 namespace vgt
 {
 namespace
@@ -34,18 +37,44 @@ __device__ __forceinline__ uint32_t AbsDiffPlusOne(uint32_t a, uint32_t b_unifor
   return (max(a, b_uniform) - min(a, b_uniform)) + 1u;
 }
 
+// One bit per row of a lane's line: a 64-bit word for lines of at most 64 rows, 128 bits beyond.
+template <int NMAX>
+struct RowBits
+{
+  using Word = typename std::conditional<(NMAX <= 64), uint64_t, unsigned __int128>::type;
+};
+__device__ __forceinline__ int HighestBit(uint64_t v) { return 63 - __clzll(static_cast<long long>(v)); }  // v != 0
+__device__ __forceinline__ int LowestBit(uint64_t v) { return __ffsll(static_cast<long long>(v)) - 1; }
+__device__ __forceinline__ int HighestBit(unsigned __int128 v)
+{
+  const uint64_t hi = static_cast<uint64_t>(v >> 64);
+  return hi ? 64 + HighestBit(hi) : HighestBit(static_cast<uint64_t>(v));
+}
+__device__ __forceinline__ int LowestBit(unsigned __int128 v)
+{
+  const uint64_t lo = static_cast<uint64_t>(v);
+  return lo ? LowestBit(lo) : 64 + LowestBit(static_cast<uint64_t>(v >> 64));
+}
+template <typename Word>
+__device__ __forceinline__ Word LowRows(int n)  // bits [0, n)
+{
+  constexpr int kBits = static_cast<int>(sizeof(Word)) * 8;
+  return (n >= kBits) ? ~static_cast<Word>(0) : ((static_cast<Word>(1) << n) - static_cast<Word>(1));
+}
+
 // Squared distance from row q to the nearest row whose class differs from q's, rows [0, n) of a line whose class bits
 // are `cls` (bit r = row r is filled); kFarRows^2 when the line holds one class only.
-__device__ __forceinline__ uint32_t OtherClassCandidate(uint64_t cls, int q, int n)
+template <typename Word>
+__device__ __forceinline__ uint32_t OtherClassCandidate(Word cls, int q, int n)
 {
-  const uint64_t rows = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-  const uint64_t mine = (cls >> q) & 1ull;
-  const uint64_t other = (mine ? ~cls : cls) & rows;
-  const uint64_t below = other & ((1ull << q) - 1ull);
-  const uint64_t above = (q >= 63) ? 0ull : (other >> (q + 1));
+  constexpr int kBits = static_cast<int>(sizeof(Word)) * 8;
+  const bool mine = ((cls >> q) & static_cast<Word>(1)) != 0;
+  const Word other = (mine ? ~cls : cls) & LowRows<Word>(n);
+  const Word below = other & LowRows<Word>(q);
+  const Word above = (q >= kBits - 1) ? static_cast<Word>(0) : (other >> (q + 1));
   int d = kFarRows;
-  if (below) d = q - (63 - __clzll(static_cast<long long>(below)));
-  if (above) d = min(d, __ffsll(static_cast<long long>(above)));
+  if (below != 0) d = q - HighestBit(below);
+  if (above != 0) d = min(d, LowestBit(above) + 1);
   return static_cast<uint32_t>(d) * static_cast<uint32_t>(d);
 }
 
@@ -106,7 +135,8 @@ template <int NMAX, bool kFinal>
 __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __restrict__ in_raw, void* __restrict__ out_raw,
                                                                 uint32_t* __restrict__ minmax_enc, const SweepGeom g)
 {
-  static_assert(NMAX % 4 == 0 && NMAX <= 64, "the line's class bits are one 64-bit word");
+  static_assert(NMAX % 4 == 0 && NMAX <= 128, "the line's class bits are one or two 64-bit words");
+  using Word = typename RowBits<NMAX>::Word;
   const int lane = threadIdx.x;
   const int n = g.n;
   // g.groups waves share an item, each taking a contiguous share of its rows (every wave holds the whole line): a few
@@ -124,7 +154,7 @@ __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __r
   // lanes beyond the grid repeat the grid's last line: same input, same result, stored to the same address
   const int zl = min(lane, g.nz - 1 - z0);
   int32_t F[NMAX];
-  uint64_t cls = 0;  // bit r: row r of this lane's line is filled
+  Word cls = 0;  // bit r: row r of this lane's line is filled
   if constexpr (!kFinal)
   {
     // ---- rows from class records: one vector load brings the records of rows 0..63 (lane l holds row l's; rows past
@@ -132,7 +162,9 @@ __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __r
     // along Z is the smallest distance across the transitions around it (vgt_internal.hpp, ClassRecord) ----
     const ClassRecord* records = static_cast<const ClassRecord*>(in_raw) + static_cast<int64_t>(item) * n;
     using Raw = uint32_t __attribute__((ext_vector_type(4)));
-    const Raw blk = *(reinterpret_cast<const Raw*>(records) + lane);
+    // (lines of more than 64 rows: a second block)
+    const Raw blk0 = *(reinterpret_cast<const Raw*>(records) + lane);
+    const Raw blk1 = (NMAX > 64) ? *(reinterpret_cast<const Raw*>(records) + 64 + lane) : blk0;
     const uint32_t xq = 2u * static_cast<uint32_t>(zl) + (kRecordBias - 1u);
 #pragma unroll
     for (int r = 0; r < NMAX; r++)
@@ -140,18 +172,20 @@ __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __r
       F[r] = kNoSite;
       if (r < n)
       {
-        const uint32_t mask_lo = __builtin_amdgcn_readlane(blk.x, r), above2 = __builtin_amdgcn_readlane(blk.w, r);
+        const Raw& blk = (r < 64) ? blk0 : blk1;
+        const int kLaneOfRow = r & 63;
+        const uint32_t mask_lo = __builtin_amdgcn_readlane(blk.x, kLaneOfRow), above2 = __builtin_amdgcn_readlane(blk.w, kLaneOfRow);
         if (above2 == kRecordNoSite)
         {
           // pass 1's mark: the whole Z line holds one class (most rows of a sparse scene) -- no lane has a site in this
           // row, and every lane has the line's class
-          if (mask_lo & 1u) cls |= 1ull << r;
+          if (mask_lo & 1u) cls |= static_cast<Word>(1) << r;
           continue;
         }
-        const uint32_t mask_hi = __builtin_amdgcn_readlane(blk.y, r), below2 = __builtin_amdgcn_readlane(blk.z, r);
+        const uint32_t mask_hi = __builtin_amdgcn_readlane(blk.y, kLaneOfRow), below2 = __builtin_amdgcn_readlane(blk.z, kLaneOfRow);
         const uint64_t m = (static_cast<uint64_t>(mask_hi) << 32) | mask_lo;
         // (bits past the end of the Z line repeat its last voxel, so bit `lane` is the class of voxel zl)
-        if (__builtin_amdgcn_inverse_ballot_w64(m)) cls |= 1ull << r;
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) cls |= static_cast<Word>(1) << r;
         uint32_t f2 = min(AbsDiffPlusOne(xq, below2), AbsDiffPlusOne(xq, above2));
         uint64_t own = (m ^ (m >> 1)) & 0x7fffffffffffffffull;  // the word's own transitions (wave-uniform)
         while (own != 0ull)
@@ -179,12 +213,12 @@ __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __r
     {
       const uint32_t value = (r < n) ? v[r] : static_cast<uint32_t>(kNoSite);
       F[r] = static_cast<int32_t>(min(value & 0x7fffffffu, static_cast<uint32_t>(kNoSite)));
-      cls |= static_cast<uint64_t>(value >> 31) << r;
+      cls |= static_cast<Word>(value >> 31) << r;
     }
   }
   // does any lane's line change class?  (most waves of a sparse scene: no -- the candidates are then skipped)
-  const uint64_t rows_mask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-  const bool mixed = ((cls & rows_mask) != 0ull) && ((cls & rows_mask) != rows_mask);
+  const Word rows_mask = LowRows<Word>(n);
+  const bool mixed = ((cls & rows_mask) != 0) && ((cls & rows_mask) != rows_mask);
   const bool classes = __builtin_amdgcn_ballot_w64(mixed) != 0ull;
 
   float lo_value = INFINITY, hi_value = -INFINITY;
@@ -193,7 +227,7 @@ __global__ __launch_bounds__(kWaveSize) void ShortLinePassKernel(const void* __r
   {
     uint32_t best = EnvelopeStep<NMAX>(F, q);
     if (classes) best = min(best, OtherClassCandidate(cls, q, n));
-    const uint32_t sign = static_cast<uint32_t>((cls >> q) & 1ull) << 31;
+    const uint32_t sign = static_cast<uint32_t>((cls >> q) & static_cast<Word>(1)) << 31;
     if constexpr (!kFinal)
     {
       const uint32_t d2 = (best >= static_cast<uint32_t>(kNoSite)) ? static_cast<uint32_t>(kInf32) : best;
@@ -226,7 +260,7 @@ hipError_t LaunchShort(const void* in, void* out, uint32_t* minmax_enc, SweepGeo
   g.zsegs = (g.nz + kWaveSize - 1) / kWaveSize;
   const int64_t items = outer_count * g.zsegs;
   if (items <= 0) return hipSuccess;
-  if (items > 0x7fffffffLL || g.n > kShortLineRows) return hipErrorInvalidValue;
+  if (items > 0x7fffffffLL || g.n > kShortLineRowsFewItems) return hipErrorInvalidValue;
   g.items = static_cast<int>(items);
   g.outers = static_cast<int>(outer_count);
   if (g.batch_outers <= 0)
@@ -236,7 +270,7 @@ hipError_t LaunchShort(const void* in, void* out, uint32_t* minmax_enc, SweepGeo
   }
   // waves per item: as many as it takes to put about two waves on every SIMD, at most one per 8 rows
   int64_t parts = 1;
-  while (parts < 8 && items * parts * 2 <= 2048 && g.n >= 16 * parts) parts *= 2;
+  while (parts < 16 && items * parts * 2 <= 2048 && g.n >= 16 * parts) parts *= 2;
   g.groups = static_cast<int>(parts);
   const dim3 grid(static_cast<unsigned>(items * parts)), block(kWaveSize);
   if (g.n <= 8)
@@ -249,8 +283,12 @@ hipError_t LaunchShort(const void* in, void* out, uint32_t* minmax_enc, SweepGeo
     hipLaunchKernelGGL((ShortLinePassKernel<32, kFinal>), grid, block, 0, stream, in, out, minmax_enc, g);
   else if (g.n <= 48)
     hipLaunchKernelGGL((ShortLinePassKernel<48, kFinal>), grid, block, 0, stream, in, out, minmax_enc, g);
-  else
+  else if (g.n <= 64)
     hipLaunchKernelGGL((ShortLinePassKernel<64, kFinal>), grid, block, 0, stream, in, out, minmax_enc, g);
+  else if (g.n <= 96)
+    hipLaunchKernelGGL((ShortLinePassKernel<96, kFinal>), grid, block, 0, stream, in, out, minmax_enc, g);
+  else
+    hipLaunchKernelGGL((ShortLinePassKernel<128, kFinal>), grid, block, 0, stream, in, out, minmax_enc, g);
   return hipGetLastError();
 }
 }  // namespace

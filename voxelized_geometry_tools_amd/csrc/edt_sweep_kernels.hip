@@ -1517,7 +1517,7 @@ hipError_t LaunchPassYSweepRecords(const ClassRecord* records, int32_t* out32, S
                                    hipStream_t stream)
 {
 #ifndef VGT_HOST_EMULATION  // (the CPU emulation runs the sweeps on every length)
-  if (p.ny <= ShortLineRows()) return LaunchPassYShortRecords(records, out32, p, stream);
+  if (p.ny <= ShortLineLimit(p.nx * ((p.nz + kWaveSize - 1) / kWaveSize))) return LaunchPassYShortRecords(records, out32, p, stream);
 #endif
   int64_t outer_count = 0;
   const SweepGeom g = SweepGeometry(p, 1, &outer_count);

@@ -165,7 +165,17 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
 // exhaustive search) instead of the sweeps; same encodings, same results.  ShortLineRows() is the limit in force:
 // kShortLineRows, or what a testing build was told (vgt_hip_testing_set_short_line_rows; 0 = sweeps for every length).
 constexpr int kShortLineRows = 64;
+// ... and lines of up to kShortLineRowsFewItems rows when the launch has so few items (at most kFewLineItems bundles of
+// 64 lines) that the sweeps would leave most of the chip idle: the search costs O(rows^2) but splits over the waves.
+constexpr int kShortLineRowsFewItems = 128;
+constexpr int64_t kFewLineItems = 1024;
 int ShortLineRows();
+inline int ShortLineLimit(int64_t items)
+{
+  const int rows = ShortLineRows();
+  if (rows != kShortLineRows) return rows;  // (a testing build was told: that limit, whatever the item count)
+  return items <= kFewLineItems ? kShortLineRowsFewItems : kShortLineRows;
+}
 #ifdef VGT_HIP_TESTING
 void SetShortLineRows(int rows);
 #endif
