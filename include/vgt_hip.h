@@ -261,6 +261,10 @@ int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels);
 /* Lines of at most `rows` rows (0 - 64; the product library: always 64) take the short-line kernels
  * (csrc/edt_short_kernels.hip) instead of the sweeps: lets the tests and benches run either formulation on any length. */
 int vgt_hip_testing_set_short_line_rows(int rows);
+/* Non-zero: sweep launches of at most two rounds of items hand over the lower halves of their second sweeps to workgroups
+ * that have run out of items (csrc/edt_sweep_kernels.hip, kSteal).  Exact, but measured slower than without
+ * (profiles/r5/experiments.md): off by default and absent from the product library. */
+int vgt_hip_testing_set_sweep_hand_over(int on);
 /* Pass 1 alone, for a test of the record format itself (csrc/vgt_internal.hpp, ClassRecord): the class records of a
  * device-resident occupancy grid, [x][64-voxel word][y] x 4 uint32 (mask_lo, mask_hi, below2, above2), into records_dev
  * (vgt_hip_testing_class_record_bytes bytes); summary_dev (optional): the 4-byte slab summaries per line, in which case the

@@ -82,7 +82,10 @@ def test_abi_version_and_workspace_size(lib):
     n = 64 * 64 * 64
     slots, words = 64, 2
     narrow = ((64 + 4 + 7) // 8 + 1) * 64 * 8 * 4
-    scratch = 1024 + slots * (narrow + words * 64 * 8) + 256
+    # (the scratch's head: 8 work counters + the hand-over protocol's words, 4096 task records and 16 offer queues;
+    # per slot one more row of 64 x 8 bytes behind the sign words: the lanes' stack depths)
+    head = ((8 + 3 * 16) * 128 + 4096 * 16 + 16 * 4096 * 4 + 255) // 256 * 256
+    scratch = head + slots * (narrow + (words + 1) * 64 * 8) + 256
     records = (64 * 1 * 64 + 256) * 16
     assert capi.sdf_workspace_bytes((64, 64, 64)) == records + n * 4 + 256 + scratch
     for variant in (1, 2, 3):

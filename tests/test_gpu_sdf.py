@@ -123,6 +123,33 @@ def test_short_line_kernels_and_sweeps_agree(vctx, oracle, shape):
         vctx.set_short_line_rows(64)
 
 
+HAND_OVER_SHAPES = [(200, 150, 70), (129, 300, 64), (512, 130, 40), (128, 128, 128), (260, 1100, 20), (1100, 140, 65)]
+
+
+@pytest.mark.parametrize("shape", HAND_OVER_SHAPES)
+def test_sweep_hand_over_on_and_off(vctx, oracle, shape):
+    """The testing library can make sweep launches of at most two rounds of items hand the lower half of an item's second
+    sweep to workgroups that have run out of items (csrc/edt_sweep_kernels.hip, kSteal): another wave finds its place in
+    the finished stack by bisection and evaluates rows [0, n / 2).  Measured slower than without and therefore not in the
+    product (profiles/r5/experiments.md) -- but built to be exact: every launch of these grids is such a launch (lines of
+    128 rows and more, fewer items than workgroup slots; 1100-row lines take 64-bit stack entries), and with the hand-over
+    on and off the result is the oracle's field."""
+    vctx.set_edt_variant(0)
+    try:
+        for kind, seed in (("spheres", 3), ("salt", 4), ("unknown_mix", 5), ("single", 0)):
+            occ = synthetic.make_occupancy(shape, kind, seed=seed)
+            for uif, vb in ((True, False), (False, True)):
+                want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0171, uif, vb)
+                for on in (True, False):
+                    vctx.set_sweep_hand_over(on)
+                    for _ in range(2 if on else 1):  # (who helps whom differs from run to run)
+                        got, lo, hi = vctx.sdf_from_occupancy(occ, 0.0171, uif, vb)
+                        assert bits_equal(got, want), (shape, kind, uif, vb, on)
+                        assert (lo, hi) == (wlo, whi), (shape, kind, on)
+    finally:
+        vctx.set_sweep_hand_over(False)
+
+
 def test_degenerate_grids(ctx, oracle):
     for kind in ("empty", "full", "single"):
         occ = synthetic.occupancy_degenerate((48, 20, 70), kind)

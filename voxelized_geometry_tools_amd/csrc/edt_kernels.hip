@@ -848,8 +848,12 @@ void SetShortLineRows(int rows)
 {
   g_short_line_rows.store(rows < 0 ? 0 : (rows > kShortLineRowsFewItems ? kShortLineRowsFewItems : rows));
 }
+std::atomic<bool> g_sweep_hand_over{false};
+bool SweepHandOver() { return g_sweep_hand_over.load(); }
+void SetSweepHandOver(bool on) { g_sweep_hand_over.store(on); }
 #else
 int ShortLineRows() { return kShortLineRows; }
+bool SweepHandOver() { return false; }
 #endif
 
 hipError_t LaunchInitMinMax(uint32_t* minmax_enc, hipStream_t stream, int64_t count)

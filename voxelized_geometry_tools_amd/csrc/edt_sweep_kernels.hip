@@ -69,6 +69,11 @@ namespace
 #ifndef VGT_SWEEP_EXP
 #define VGT_SWEEP_EXP 0
 #endif
+#ifndef VGT_STEAL_EXP
+// diagnostic builds of the hand-over: 1 = nobody helps (offers are made and withdrawn), 2 = helpers wait but never claim,
+// 4 = helpers claim and drop the task, 8 = helpers do the set-up only (4 and 8: wrong fields, timing only)
+#define VGT_STEAL_EXP 0
+#endif
 constexpr int kBand = VGT_SWEEP_BAND;    // rows held in registers at a time: 8, 16 or 32
 constexpr int kWord = 32;                // rows per sign word
 #ifndef VGT_SWEEP_RING_WIDE
@@ -84,6 +89,20 @@ constexpr int kWord = 32;                // rows per sign word
 #endif
 constexpr int kSweepGroups = VGT_SWEEP_GROUPS;  // work counters (= XCDs of an MI355X)
 constexpr int kCounterStride = 32;              // ints between two counters (128 bytes)
+// ---- Handing over the lower half of an item's second sweep (launches of at most two rounds of items; see SweepPassKernel)
+// The head of the scratch buffer: the work counters, then one `resolved` count, then per workgroup a task record.
+constexpr int kStealMinRows = 128;              // shorter lines are not worth a hand-over
+constexpr int kMaxSweepSlots = 4096;
+constexpr int kMaxXcc = 16;
+struct StealTask
+{
+  int state;   // kTaskNone -> kTaskOpen (the owner has published it) -> kTaskOwner / kTaskHelper (claimed)
+  int item;    // the item whose rows [0, split) are on offer
+  int flags;   // bit 0: class changes on some line of the wave, bit 1: some line without any site; bits 8..: the owner's XCC
+  int pad;
+};
+[[maybe_unused]] constexpr int kTaskNone = 0;
+constexpr int kTaskOpen = 1, kTaskOwner = 2, kTaskHelper = 3;
 template <bool kPacked>
 struct RingShape
 {
@@ -436,8 +455,56 @@ __device__ __forceinline__ void WaveMinMax(float lo_value, float hi_value, uint3
 #endif
 }
 
+// The hand-over protocol's words are shared by the workgroups of ONE XCC only, so they live in that XCC's L2: read-modify-
+// write atomics without the agent-scope bit execute there (global atomics never execute in a CU's L1).  They are READ the
+// same way, by an atomic add of zero that returns the word (written out: the compiler may turn an idempotent
+// read-modify-write into a load).  What was measured on the way (profiles/r5/experiments.md, 512^3, a 0.23 ms pass):
+// agent-scope loads go to memory and serialise there, 5.9 ms with every idle workgroup polling; loads below agent scope
+// are served by the CU's L1 for ever (a hang), and behind an L1 invalidate they were still stale often enough to send the
+// helpers' compare-and-swaps into a hot loop (10 ms); atomic reads by ALL idle workgroups serialise on the word (2.9 ms).
+// Hence: atomic reads, and only every eighth workgroup waits for offers (the others look once and leave).
+__device__ __forceinline__ int XccLoad([[maybe_unused]] const int* p)
+{
+#ifdef VGT_HOST_EMULATION
+  return *p;
+#else
+  int v;
+  const int zero = 0;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
+  return v;
+#endif
+}
+__device__ __forceinline__ int XccAdd(int* p, int v)
+{
+#ifdef VGT_HOST_EMULATION
+  const int old = *p;
+  *p += v;
+  return old;
+#else
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ bool XccCas(int* p, int expected, int desired)
+{
+#ifdef VGT_HOST_EMULATION
+  if (*p != expected) return false;
+  *p = desired;
+  return true;
+#else
+  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
-template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
+// kSteal (testing library only; measured slower, see LaunchSweep): launches of at most two rounds of items (a pass then
+// lasts as long as its slowest items, and items differ 3x in duration: profiles/r5/item_durations.txt).  A workgroup that is on its LAST item flushes the stack to the scratch buffer
+// after sweep 1 and offers the lower half of sweep 2 -- rows [0, split) -- to workgroups that have run out of items: a
+// helper on the same XCC (same L2: the flushed stack needs no cross-L2 coherence) finds, per lane, the stack entry that
+// owns row split - 1 by bisection, takes the chunks around it into its own ring and evaluates downwards from there while
+// the owner evaluates rows [split, n); an offer nobody has taken when the owner reaches row `split` is withdrawn and the
+// owner carries on.  Same code, same arithmetic, same results whoever evaluates a row.
+template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain, bool kSteal>
 __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
                                                                             OutT* __restrict__ out,
                                                                             unsigned char* __restrict__ spill,
@@ -468,8 +535,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const int64_t rstride = g.row_stride;
   // The workgroup (one wave) owns one slot of the scratch buffer -- spilled stack entries and sign words -- for all
   // the lines it works on, so the scratch is sized by the number of workgroups in flight, not by the grid.
-  unsigned char* const wave_spill = spill + static_cast<int64_t>(blockIdx.x) * g.chunks * (kWaveSize * kChunkBytes);
-  uint2* const wave_info = word_info + static_cast<int64_t>(blockIdx.x) * g.nwords * kWaveSize;
+  unsigned char* const own_spill = spill + static_cast<int64_t>(blockIdx.x) * g.chunks * (kWaveSize * kChunkBytes);
+  uint2* const own_info = word_info + static_cast<int64_t>(blockIdx.x) * (g.nwords + 1) * kWaveSize;
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
   float lo_value = INFINITY, hi_value = -INFINITY;
@@ -477,25 +544,130 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #ifdef VGT_HOST_EMULATION
   int emulated_round = 0;
 #endif
+  // ---- kSteal: the hand-over of lower halves (see the comment above the kernel).  Behind the work counters: the count of
+  // workgroups whose offer is settled (made and claimed by someone, or never made), the open offers per XCC, the tasks ----
+  [[maybe_unused]] int* const steal_busy = work_counter + kSweepGroups * kCounterStride;  // [XCC]: workgroups at work
+  [[maybe_unused]] int* const steal_head = steal_busy + kMaxXcc * kCounterStride;  // [XCC], one cache line apart:
+  [[maybe_unused]] int* const steal_tail = steal_head + kMaxXcc * kCounterStride;  // offers taken from / put into the queue
+  [[maybe_unused]] StealTask* const steal_tasks = reinterpret_cast<StealTask*>(steal_tail + kMaxXcc * kCounterStride);
+  [[maybe_unused]] int* const steal_queue = reinterpret_cast<int*>(steal_tasks + kMaxSweepSlots);  // [XCC][kMaxSweepSlots]
+  [[maybe_unused]] const int steal_split = (n / 2) & ~(kWord - 1);  // rows [0, split) are handed over: whole sign words
+  [[maybe_unused]] int my_xcc = 0;
+  [[maybe_unused]] int next_item = -1;    // fetched ahead to learn whether the item at work is the last one
+  [[maybe_unused]] bool settled = false;  // this workgroup no longer counts as "at work" (or will not once its offer is claimed)
+#ifndef VGT_HOST_EMULATION
+  if constexpr (kSteal)
+  {
+    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;  // hwreg(HW_REG_XCC_ID, 0, 4)
+    if (lane == 0) XccAdd(steal_busy + my_xcc * kCounterStride, 1);
+  }
+#endif
+  [[maybe_unused]] auto fetch_item = [&]() -> int {
+    int fetched = 0;
+#ifndef VGT_HOST_EMULATION
+    // Workgroups with the same blockIdx modulo 8 share an XCD and its L2 (the dispatcher deals them round robin): with
+    // g.groups = 8 there is one counter per such group, dealing whole rows of the grid -- the segments of one contiguous
+    // row are then written through one L2 at about the same time instead of through eight.  A speed choice only.
+    const int group = static_cast<int>(blockIdx.x) % g.groups;
+    if (lane == 0) fetched = atomicAdd(work_counter + group * kCounterStride, 1);
+    fetched = __builtin_amdgcn_readfirstlane(fetched);
+    const int dealt = fetched / g.zsegs;
+    fetched = (dealt * g.groups + group) * g.zsegs + (fetched - dealt * g.zsegs);
+#endif
+    return fetched;
+  };
+  // An offer of this XCC, claimed for this workgroup (its index), or -1 when none can come any more: no workgroup of this
+  // XCC is at work.  (Workgroups that the dispatcher has not started yet are not counted: a helper that leaves early
+  // loses nothing but the chance to help -- an offer nobody takes is withdrawn by its owner.)  Offers queue up per XCC,
+  // and helpers draw TICKETS: ticket k waits for the k-th offer of the XCC, on a word of its own.  (A first version let
+  // every helper compare-and-swap the queue's head: with hundreds of helpers per XCC that is a quadratic number of atomics
+  // on one word, and a 0.23 ms pass took 3 ms.)
+  [[maybe_unused]] auto claim_offer = [&]() -> int {
+    int result = -1;
+#ifndef VGT_HOST_EMULATION
+    if (VGT_STEAL_EXP & 1) return -1;
+    if (lane == 0)
+    {
+      int* const busy = steal_busy + my_xcc * kCounterStride;
+      int* const queue = steal_queue + my_xcc * kMaxSweepSlots;
+      for (;;)
+      {
+        const int ticket = XccAdd(steal_head + my_xcc * kCounterStride, 1);
+        if (ticket >= kMaxSweepSlots) break;
+        int entry = 0;
+        int naps = 1;
+        for (int look = 0;; look++)
+        {
+          entry = XccLoad(queue + ticket);
+          if (entry != 0) break;
+          // (the count of workgroups at work is one word for everybody: looked at every fourth time)
+          if ((look & 3) == 0 && XccLoad(busy) <= 0) break;
+          for (int nap = 0; nap < naps; nap++) __builtin_amdgcn_s_sleep(127);  // 4 us at first, up to 32 us
+          if (naps < 8) naps *= 2;
+        }
+        if (entry == 0) break;  // nobody is at work: no offer will come
+        const int task = entry - 1;
+        if (!(VGT_STEAL_EXP & 2) && XccCas(&steal_tasks[task].state, kTaskOpen, kTaskHelper))
+        {
+          XccAdd(busy, -1);  // (the owner is settled: it will not offer again)
+          result = task;
+          break;
+        }
+        // (withdrawn: its owner got to the lower half first -- the next ticket)
+      }
+    }
+    result = __builtin_amdgcn_readfirstlane(result);
+#endif
+    return result;
+  };
   for (;;)
   {
   // ---- next unit of work: 64 neighbouring lines of one outer index ----
   int item = 0;
+  [[maybe_unused]] bool helping = false;   // kSteal: the lower half of another workgroup's item
+  [[maybe_unused]] int helped_flags = 0;
+  unsigned char* wave_spill = own_spill;
+  uint2* wave_info = own_info;
 #ifdef VGT_HOST_EMULATION
   item = static_cast<int>(blockIdx.x + gridDim.x * emulated_round++);  // (lanes run one after the other: fixed deal)
 #else
-  // Workgroups with the same blockIdx modulo 8 share an XCD and its L2 (the dispatcher deals them round robin): with
-  // g.groups = 8 there is one counter per such group, dealing whole rows of the grid -- the segments of one contiguous
-  // row are then written through one L2 at about the same time instead of through eight.  A speed choice only.
-  const int group = static_cast<int>(blockIdx.x) % g.groups;
-  if (lane == 0) item = atomicAdd(work_counter + group * kCounterStride, 1);
-  item = __builtin_amdgcn_readfirstlane(item);
+  if constexpr (kSteal)
   {
-    const int dealt = item / g.zsegs;
-    item = (dealt * g.groups + group) * g.zsegs + (item - dealt * g.zsegs);
+    if (next_item >= 0)
+    {
+      item = next_item;
+      next_item = -1;
+    }
+    else
+      item = fetch_item();
   }
+  else
+    item = fetch_item();
 #endif
-  if (item >= g.items) break;
+  if (item >= g.items)
+  {
+    if constexpr (!kSteal)
+      break;
+    else
+    {
+      if (!settled)
+      {
+        // (no offer of this workgroup is or will be open: it never had an item, or its last one made none)
+        settled = true;
+        if (lane == 0) XccAdd(steal_busy + my_xcc * kCounterStride, -1);
+      }
+      const int task = claim_offer();
+      if (task < 0) break;
+      if (VGT_STEAL_EXP & 4) continue;  // (diagnostic: claimed and dropped -- wrong fields, timing only)
+      helping = true;
+      item = __builtin_amdgcn_readfirstlane(XccLoad(&steal_tasks[task].item));
+      helped_flags = __builtin_amdgcn_readfirstlane(XccLoad(&steal_tasks[task].flags));
+      // the owner's slot of the scratch buffer: its flushed stack and its sign words, read only from here on
+      wave_spill = spill + static_cast<int64_t>(task) * g.chunks * (kWaveSize * kChunkBytes);
+      wave_info = word_info + static_cast<int64_t>(task) * (g.nwords + 1) * kWaveSize;
+      asm volatile("" ::: "memory");
+    }
+  }
 #ifdef VGT_SWEEP_TIMING
   const unsigned long long item_begin = wall_clock64();
   if (lane == 0) atomicMin(&g_sweep_exit[kFinal ? 1 : 0][0], item_begin);
@@ -625,6 +797,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Sweep 1: build the envelope.
   // =====================================================================================================
   uint32_t any_transition = 0;
+  if (!helping)  // (kSteal: a helper takes over a finished stack)
   {
     // every kChunk rows: the ring must have room for kChunk pushes
     auto check_ring = [&]() {
@@ -993,8 +1166,16 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // =====================================================================================================
   // Sweep 2: evaluate, last row first.
   // =====================================================================================================
-  const bool classes = (VGT_SWEEP_EXP & 2) ? false : (__builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull);
-  const bool any_empty = __builtin_amdgcn_ballot_w64(D == (4u << kShift)) != 0ull;  // a line without any site
+  bool classes = (VGT_SWEEP_EXP & 2) ? false : (__builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull);
+  bool any_empty = __builtin_amdgcn_ballot_w64(D == (4u << kShift)) != 0ull;  // a line without any site
+  if constexpr (kSteal)
+  {
+    if (helping)
+    {
+      classes = (helped_flags & 1) != 0;
+      any_empty = (helped_flags & 2) != 0;
+    }
+  }
 #ifdef VGT_SWEEP_STATS
   stat_phase = 2;
   if (lane == 0)
@@ -1009,6 +1190,52 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // general evaluation runs.)
   bool all_empty = !classes && __builtin_amdgcn_ballot_w64(D != (4u << kShift)) == 0ull;
   if constexpr (kFinal && !kPlain) all_empty = all_empty && !g.add_virtual_border;
+  [[maybe_unused]] bool offered = false;  // kSteal: rows [0, steal_split) of this item are on offer
+  if constexpr (kSteal)
+  {
+    if (helping) all_empty = false;  // (items that take the fill path make no offer)
+#ifndef VGT_HOST_EMULATION
+    if (!helping && !all_empty && n >= kStealMinRows)
+    {
+      next_item = fetch_item();
+      if (next_item >= g.items)
+      {
+        // The item at work is this workgroup's last one: the whole stack goes to the scratch buffer -- the ring's
+        // entries [lo, depth) join the chunks spilled earlier; the ring itself stays as it is -- with each lane's depth
+        // behind the sign words, and the lower half of the evaluation is offered to workgroups that have run out of items.
+        for (uint32_t first = L; __builtin_amdgcn_ballot_w64(first < D) != 0ull;)
+        {
+          if (first < D)
+          {
+            Entry buf[kChunk];
+            Entry* const slots = chunk_in_ring(first);
+#pragma unroll
+            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, first, j);
+            StoreChunk(spill_ptr(first), buf);
+            first += kChunkSlots;
+          }
+        }
+        StorePair(wave_info + static_cast<int64_t>(g.nwords) * kWaveSize + lane, D, 0u);
+        // (every store of this item -- spilled chunks, sign words, the flush -- has reached the L2 before the offer opens)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+        {
+          // (plain stores reach the L2 -- the L1 is write-through -- and are waited for before the offer opens)
+          StealTask* const mine = steal_tasks + blockIdx.x;
+          mine->item = item;
+          mine->flags = (classes ? 1 : 0) | (any_empty ? 2 : 0) | (my_xcc << 8);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          mine->state = kTaskOpen;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const int place = XccAdd(steal_tail + my_xcc * kCounterStride, 1);
+          steal_queue[my_xcc * kMaxSweepSlots + place] = static_cast<int>(blockIdx.x) + 1;
+        }
+        offered = true;
+        settled = true;  // (whoever claims the offer counts it)
+      }
+    }
+#endif
+  }
   if (all_empty && !(VGT_SWEEP_EXP & 32))
   {
     const int nwords = g.nwords;
@@ -1072,6 +1299,52 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     };
     constexpr int kStep = (kChunk < 8) ? 8 : kChunk;  // rows between two refill steps
 
+    if constexpr (kSteal)
+    {
+      if (helping)
+      {
+        // The stack as the owner left it, entries [0, depth) in its slot of the scratch buffer.  The entry that owns row
+        // split - 1: along a hull the members' values at a row fall, then rise -- bisection on "is the next one better".
+        const int q = steal_split - 1;
+        auto entry_at = [&](int index) -> Entry {
+          const uint32_t chunk_first = static_cast<uint32_t>(index / kChunk) * kChunkSlots;
+          return reinterpret_cast<const Entry*>(wave_spill + (chunk_first + lane_chunk))[index % kChunk];
+        };
+        const uint32_t depth_scaled = LoadPair(wave_info + static_cast<int64_t>(g.nwords) * kWaveSize + lane).x;
+        int lo_index = 3, hi_index = static_cast<int>(depth_scaled >> kShift) - 1;
+        while (__builtin_amdgcn_ballot_w64(lo_index < hi_index) != 0ull)
+        {
+          if (lo_index < hi_index)
+          {
+            const int mid = (lo_index + hi_index) >> 1;
+            const Entry a = entry_at(mid), b = entry_at(mid + 1);
+            const int32_t va = C::G(a) - 2 * q * C::Row(a), vb = C::G(b) - 2 * q * C::Row(b);
+            if (vb < va)
+              lo_index = mid + 1;
+            else
+              hi_index = mid;
+          }
+        }
+        // entries [lo, depth) with depth = owner's index + 1 and lo = the start of the owner's chunk: that chunk goes into
+        // the ring, everything below comes through the usual refills
+        D = static_cast<uint32_t>(lo_index + 1) << kShift;
+        L = static_cast<uint32_t>(lo_index / kChunk) * kChunkSlots;
+        {
+          const Entry* src = spill_ptr(L);
+          Entry* const slots = chunk_in_ring(L);
+#pragma unroll
+          for (int j = 0; j < kChunk; j++) chunk_slot(slots, L, j) = src[j];
+        }
+        const Entry top = ring_ref(D - kSlot);
+        Gt = C::G(top);
+        rt = C::Row(top);
+        if (D - 2 * kSlot < L) refill_now();
+        const Entry second = ring_ref(D - 2 * kSlot);
+        A = rt - C::Row(second);
+        nB = C::G(second) - Gt;
+        e3 = C::Unknown();
+      }
+    }
     if (C::IsUnknown(e3))  // (sweep 1 loads the third entry lazily)
     {
       if (D - 3 * kSlot < L) refill_now();
@@ -1117,9 +1390,58 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     uint32_t xdn_word = 0, xup_word = 0;
     VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));  // row being evaluated
     const int last_band = (n - 1) / kBand * kBand;
-    for (int r0 = last_band; r0 >= 0; r0 -= kBand)
+    int first_band = last_band;
+    if constexpr (kSteal)
+    {
+      if (helping)
+      {
+        // A helper begins at the top of the sign word below row `split`, as if it had just left the word above: that word,
+        // the word at work and the one below it in the three registers, and the distance from row `split` to the nearest
+        // row of the other class above it -- which the owner's walk would have carried down -- from the words above.
+        const int word_above = steal_split / kWord;
+        first_band = steal_split - kBand;
+        row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(steal_split - 1) * rstride));
+        info = LoadPair(wave_info + static_cast<int64_t>(word_above) * kWaveSize + lane);
+        info_below = LoadPair(wave_info + static_cast<int64_t>(word_above - 1) * kWaveSize + lane);
+        if (word_above >= 2) info_next = LoadPair(wave_info + static_cast<int64_t>(word_above - 2) * kWaveSize + lane);
+        if (classes)
+        {
+          const uint32_t mine = 0u - (info.x & 1u);  // class of row `split`, spread over a word
+          bool found = false;
+          for (int w = word_above; w < nwords; w++)
+          {
+            if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;
+            const uint32_t sw = LoadPair(wave_info + static_cast<int64_t>(w) * kWaveSize + lane).x;
+            const uint32_t other = (sw ^ mine) & LowBits(min(kWord, n - w * kWord));
+            if (!found && other != 0u)
+            {
+              dn = w * kWord + (__ffs(static_cast<int>(other)) - 1) - steal_split;
+              found = true;
+            }
+          }
+        }
+      }
+    }
+    for (int r0 = first_band; r0 >= 0; r0 -= kBand)
     {
       __builtin_assume(r0 >= 0 && r0 < 16384);
+      if constexpr (kSteal)
+      {
+        if ((VGT_STEAL_EXP & 8) && helping) break;  // (diagnostic: set-up only)
+#ifndef VGT_HOST_EMULATION
+        if (offered && r0 == steal_split - kBand)
+        {
+          // rows [split, n) are done.  An offer nobody has taken is withdrawn: the owner carries on.
+          int mine = 0;
+          if (lane == 0)
+          {
+            mine = XccCas(&steal_tasks[blockIdx.x].state, kTaskOpen, kTaskOwner) ? 1 : 0;
+            if (mine) XccAdd(steal_busy + my_xcc * kCounterStride, -1);
+          }
+          if (!__builtin_amdgcn_readfirstlane(mine)) break;
+        }
+#endif
+      }
       const int sub = r0 & (kWord - 1);
       if (sub + kBand == kWord || r0 == last_band)
       {
@@ -1386,8 +1708,15 @@ constexpr int64_t kSweepSlots = 3;  // (the CPU test wants slots that are used a
 #define VGT_SWEEP_SLOTS 4096
 #endif
 constexpr int64_t kSweepSlots = VGT_SWEEP_SLOTS;
+static_assert(kSweepSlots <= kMaxSweepSlots, "one task record per workgroup");
 #endif
-constexpr size_t kCounterBytes = kSweepGroups * kCounterStride * sizeof(int);  // the work counters, each on its own cache line
+// Head of the scratch buffer: the work counters, each on its own cache line, then the hand-over protocol's words (one
+// workgroups at work and the offer queues' heads and tails per XCC, one task record per workgroup, the queues), cleared
+// before every launch.
+constexpr size_t kCounterBytes = ((kSweepGroups + 3 * kMaxXcc) * kCounterStride * sizeof(int) +
+                                  kMaxSweepSlots * sizeof(StealTask) + kMaxXcc * kMaxSweepSlots * sizeof(int) + 255) /
+                                 256 * 256;
+static_assert(sizeof(StealTask) == 16, "layout");
 
 int64_t SpillChunks(int64_t n, int chunk) { return (n + 4 + chunk - 1) / chunk + 1; }
 
@@ -1404,7 +1733,8 @@ size_t SlotScratchBytes(int64_t n, bool packed)
   const int64_t nwords = (n + kWord - 1) / kWord;
   const size_t spill = packed ? SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t)
                               : SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
-  return spill + static_cast<size_t>(nwords) * kWaveSize * sizeof(uint2);
+  // (+ one row: each lane's stack depth, for a hand-over)
+  return spill + static_cast<size_t>(nwords + 1) * kWaveSize * sizeof(uint2);
 }
 
 // Scratch of one pass: the work counters and the slots of the workgroups in flight, for the entry kind the extents call
@@ -1456,25 +1786,56 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
   uint2* info = reinterpret_cast<uint2*>(bytes + kCounterBytes + spill_bytes);
 #ifdef VGT_HOST_EMULATION
   *counter = 0;
-#else
-  const hipError_t err = hipMemsetAsync(counter, 0, kCounterBytes, stream);
-  if (err != hipSuccess) return err;
 #endif
   const dim3 grid(static_cast<unsigned>(slots)), block(kWaveSize);
   // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
   const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
-  if (packed && general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, !kFinal>), grid, block, 0, stream, in, out,
-                       spill, info, minmax_enc, counter, g);
-  else if (packed)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, true, true>), grid, block, 0, stream, in, out, spill,
-                       info, minmax_enc, counter, g);
-  else if (general)
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, !kFinal>), grid, block, 0, stream, in, out,
-                       spill, info, minmax_enc, counter, g);
+  // Launches of at most two rounds of items hand over lower halves (kSteal): the pass lasts as long as its slowest items.
+  // MEASURED SLOWER (profiles/r5/experiments.md: 512^3 Y +27 %, X +17 %; the 8-rank slab shape +-0): the slots that fast
+  // items leave idle are not spare capacity -- the waves still at work speed up on the emptier chip, and helpers take that
+  // away from the slowest items.  Built, parity-tested (tests/test_gpu_sdf.py::test_sweep_hand_over_on_and_off) and kept
+  // in the testing library only, off unless vgt_hip_testing_set_sweep_hand_over turns it on.
+#if defined(VGT_HIP_TESTING) && !defined(VGT_HOST_EMULATION)
+  const bool steal = items <= 2 * slots && g.n >= kStealMinRows && SweepHandOver();
+#else
+  [[maybe_unused]] const bool steal = false;
+#endif
+#ifndef VGT_HOST_EMULATION
+  {
+    // the work counters (and, for a hand-over launch, the protocol's words behind them) start at zero
+    const hipError_t err =
+        hipMemsetAsync(counter, 0, steal ? kCounterBytes : kSweepGroups * kCounterStride * sizeof(int), stream);
+    if (err != hipSuccess) return err;
+  }
+#endif
+#define VGT_LAUNCH_SWEEP(PACKED, PLAIN, STEAL)                                                                      \
+  hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, PACKED, PLAIN, STEAL>), grid, block, 0, stream, in, out, \
+                     spill, info, minmax_enc, counter, g)
+#if defined(VGT_HIP_TESTING) && !defined(VGT_HOST_EMULATION)
+  if (steal)
+  {
+    if (packed && general)
+      VGT_LAUNCH_SWEEP(true, !kFinal, true);
+    else if (packed)
+      VGT_LAUNCH_SWEEP(true, true, true);
+    else if (general)
+      VGT_LAUNCH_SWEEP(false, !kFinal, true);
+    else
+      VGT_LAUNCH_SWEEP(false, true, true);
+  }
   else
-    hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, false, true>), grid, block, 0, stream, in, out, spill,
-                       info, minmax_enc, counter, g);
+#endif
+  {
+    if (packed && general)
+      VGT_LAUNCH_SWEEP(true, !kFinal, false);
+    else if (packed)
+      VGT_LAUNCH_SWEEP(true, true, false);
+    else if (general)
+      VGT_LAUNCH_SWEEP(false, !kFinal, false);
+    else
+      VGT_LAUNCH_SWEEP(false, true, false);
+  }
+#undef VGT_LAUNCH_SWEEP
   return hipGetLastError();
 }
 

@@ -170,6 +170,9 @@ constexpr int kShortLineRows = 64;
 constexpr int kShortLineRowsFewItems = 128;
 constexpr int64_t kFewLineItems = 1024;
 int ShortLineRows();
+// Whether sweep launches of at most two rounds of items hand over lower halves of their second sweeps: never in the
+// product (measured slower, edt_sweep_kernels.hip), in a testing build when vgt_hip_testing_set_sweep_hand_over says so.
+bool SweepHandOver();
 inline int ShortLineLimit(int64_t items)
 {
   const int rows = ShortLineRows();
@@ -178,6 +181,7 @@ inline int ShortLineLimit(int64_t items)
 }
 #ifdef VGT_HIP_TESTING
 void SetShortLineRows(int rows);
+void SetSweepHandOver(bool on);
 #endif
 hipError_t LaunchPassYShortRecords(const ClassRecord* records, int32_t* out32, const SdfParams& p, hipStream_t stream);
 hipError_t LaunchPassXShortFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, const SdfParams& p,
