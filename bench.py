@@ -95,14 +95,19 @@ def device_occupancy(torch, shape, dist, seed, device, z_offset=0, full_shape=No
 def profiled_traffic(kernel, default_workload, timed_kernel_ms):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, tools/collect_profiles.sh): counters cannot be read from inside this process.  The file
-    names the commit, the kernel and the kernel's duration it was collected with; the value is only
-    reported when the kernel timed in THIS run is within 5 % of that duration (else null)."""
+    names the commit, a hash of the EDT sources, the kernel and the kernel's duration it was collected with; the value is
+    only reported when this tree's EDT sources hash to the same value AND the kernel timed in THIS run is within 5 % of
+    that duration (else null)."""
     if not default_workload:
         return None, None
     path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_current.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
+        from voxelized_geometry_tools_amd import synthetic
+        if doc.get("sources_sha256") != synthetic.kernel_sources_sha256("edt"):
+            return None, ("profiles/pmc_hbm_traffic_current.json was collected on other EDT sources (commit %s): "
+                          "collect it again (tools/collect_profiles.sh)" % doc.get("commit", "?"))
         entry = doc["kernels"][kernel]
         recorded_ms = float(entry["kernel_ns"]) * 1e-6
         if recorded_ms <= 0 or abs(timed_kernel_ms - recorded_ms) > 0.05 * recorded_ms:

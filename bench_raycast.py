@@ -33,6 +33,11 @@ def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells):
     try:
         with open(path) as fh:
             doc = json.load(fh)
+        from voxelized_geometry_tools_amd import synthetic
+        if doc.get("sources_sha256") != synthetic.kernel_sources_sha256("voxelizer"):
+            out["counters_source"] = ("profiles/raycast_atomic_current.json was collected on another voxelizer_kernels.hip "
+                                      "(commit %s): collect it again" % doc.get("commit", "?"))
+            return out
         entry = doc["clouds"][cloud_key]
         rate = float(doc["scattered_atomic_rate_G_per_s"])
         recorded_ms = float(entry["raycast_kernel_ms"])

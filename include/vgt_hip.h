@@ -265,6 +265,10 @@ int vgt_hip_testing_set_short_line_rows(int rows);
  * that have run out of items (csrc/edt_sweep_kernels.hip, kSteal).  Exact, but measured slower than without
  * (profiles/r5/experiments.md): off by default and absent from the product library. */
 int vgt_hip_testing_set_sweep_hand_over(int on);
+/* Non-zero: the X pass (32-bit stack entries, lines of 768 - 1024 rows) sweeps every 32nd row first and uses that hull as
+ * a filter in front of the sweep proper (csrc/edt_sweep_kernels.hip, kCoarse).  Exact; measured -4 % on the 1024^3 headline
+ * and +6 % on dense scenes and one-round launches (profiles/r5/experiments.md): off by default, absent from the product. */
+int vgt_hip_testing_set_sweep_coarse_hull(int on);
 /* Pass 1 alone, for a test of the record format itself (csrc/vgt_internal.hpp, ClassRecord): the class records of a
  * device-resident occupancy grid, [x][64-voxel word][y] x 4 uint32 (mask_lo, mask_hi, below2, above2), into records_dev
  * (vgt_hip_testing_class_record_bytes bytes); summary_dev (optional): the 4-byte slab summaries per line, in which case the

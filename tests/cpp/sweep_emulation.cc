@@ -22,6 +22,9 @@ inline void BlockMinMax(uint32_t lo, uint32_t hi, uint32_t* minmax_enc)
   minmax_enc[0] = std::min(minmax_enc[0], lo);
   minmax_enc[1] = std::max(minmax_enc[1], hi);
 }
+// (edt_kernels.hip defines these for the libraries; here the test flips the coarse hull of the X pass on and off)
+bool g_emulated_coarse_hull = true;
+bool SweepCoarseHull() { return g_emulated_coarse_hull; }
 }  // namespace vgt
 #include "../../voxelized_geometry_tools_amd/csrc/edt_sweep_kernels.hip"
 
@@ -242,6 +245,19 @@ void CheckX(const Case& c, std::mt19937& rng)
           case 1: v = 1 + rng() % std::max<int64_t>(1, max_f); break;
           case 2: v = 1 + static_cast<int64_t>(x - nx / 2) * (x - nx / 2) % std::max<int64_t>(1, max_f); break;
           case 3: v = std::max<int64_t>(1, max_f - static_cast<int64_t>(x) * x / 4); break;
+          case 4:
+          {
+            // a distance-like field, as the X pass meets on sparse scenes: the squared distance to the nearest of a few
+            // sites of the line's plane, each (x - sx)^2 + offset -- smooth, locally convex, popped by sites far away
+            v = INT64_MAX;
+            for (int site = 0; site < 5; site++)
+            {
+              const int64_t sx = (static_cast<int64_t>(y) * 7919 + z * 104729 + site * 31337) % nx;
+              const int64_t offset = ((y * 13 + z * 7 + site * 101) % 97) * (max_f / 200 + 1);
+              v = std::min(v, (x - sx) * (x - sx) / 3 + offset + 1);
+            }
+            break;
+          }
           default: v = 1; break;
         }
         v = std::min<int64_t>(std::max<int64_t>(v, 1), std::max<int64_t>(max_f, 1));
@@ -344,12 +360,20 @@ int main(int argc, char** argv)
         {1024, 2, 67, 1, 30, 1, false},  {700, 2, 5, 2, 100, 0, true},   {1500, 1, 3, 0, 100, 1, false},
         {2050, 1, 2, 3, 100, 0, false},  {97, 3, 66, 1, 60, 20, true},   {64, 2, 64, 0, 0, 5, false},
         {513, 1, 3, 3, 100, 0, false},   {999, 1, 2, 0, 100, 100, true}, {1024, 3, 3, 3, 100, 0, false},
-        {64, 2, 64, 0, 0, 5, true},
+        {64, 2, 64, 0, 0, 5, true},       {256, 2, 9, 1, 100, 0, false},  {257, 1, 64, 2, 100, 3, true},
+        {600, 2, 3, 1, 20, 1, false},     {1000, 1, 5, 3, 100, 0, true},  {1024, 1, 64, 2, 100, 0, false},
+        {1024, 90, 2, 4, 100, 0, false},  {800, 60, 3, 4, 97, 1, true},   {770, 50, 2, 4, 100, 2, false},
+        {1000, 2, 64, 1, 100, 1, false},
     };
-    for (const Case& c : x_cases)
+    // (every X case with the coarse hull in front of the sweep -- lines of 768 - 1024 rows take it -- and without)
+    for (const bool coarse_hull : {true, false})
     {
-      CheckX(c, rng);
-      cases++;
+      vgt::g_emulated_coarse_hull = coarse_hull;
+      for (const Case& c : x_cases)
+      {
+        CheckX(c, rng);
+        cases++;
+      }
     }
   }
   std::printf("%d cases, %d mismatches (band %d; 32-bit entries: ring %d, chunk %d; 64-bit entries: ring %d, chunk %d)\n", cases,

@@ -150,6 +150,31 @@ def test_sweep_hand_over_on_and_off(vctx, oracle, shape):
         vctx.set_sweep_hand_over(False)
 
 
+COARSE_HULL_SHAPES = [(768, 9, 70), (769, 40, 64), (800, 33, 5), (1000, 20, 66), (1024, 12, 130), (1023, 300, 20)]
+
+
+@pytest.mark.parametrize("shape", COARSE_HULL_SHAPES)
+def test_coarse_hull_on_and_off(vctx, oracle, shape):
+    """The X pass of lines of 768 - 1024 rows sweeps every 32nd row first and uses that hull as a filter in front of the
+    sweep proper (csrc/edt_sweep_kernels.hip, kCoarse): rows strictly above the chord between two subsample vertices never
+    touch the stack.  Testing library only (measured: not worth it, profiles/r5/experiments.md) but exact by construction;
+    here against the oracle with the filter on and off, on smooth scenes -- where it removes most rows -- and noisy ones --
+    where it removes few."""
+    vctx.set_edt_variant(0)
+    try:
+        for kind, seed in (("spheres", 11), ("salt", 12), ("unknown_mix", 13), ("single", 0), ("full", 0)):
+            occ = synthetic.make_occupancy(shape, kind, seed=seed)
+            for uif, vb in ((True, False), (False, True)):
+                want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0331, uif, vb)
+                for on in (True, False):
+                    vctx.set_sweep_coarse_hull(on)
+                    got, lo, hi = vctx.sdf_from_occupancy(occ, 0.0331, uif, vb)
+                    assert bits_equal(got, want), (shape, kind, uif, vb, on)
+                    assert (lo, hi) == (wlo, whi), (shape, kind, on)
+    finally:
+        vctx.set_sweep_coarse_hull(False)
+
+
 def test_degenerate_grids(ctx, oracle):
     for kind in ("empty", "full", "single"):
         occ = synthetic.occupancy_degenerate((48, 20, 70), kind)

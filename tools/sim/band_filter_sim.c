@@ -76,7 +76,7 @@ static void line_transform(const int32_t* F, int n, int32_t* out, Pt* st)
 }
 
 #define BAND 16
-#define NF 6  // s1, s2, s4, s8, hull, hull32
+#define NF 10  // s1, s2, s4, s8, hull, hull32, coarse hull of every 8th / 16th / 32nd / 64th row + s1
 int main(int argc, char** argv)
 {
   const int n = argc > 1 ? atoi(argv[1]) : 1024;
@@ -153,11 +153,13 @@ int main(int argc, char** argv)
   memset(hist_iter, 0, sizeof(hist_iter));
   double wave_bands = 0, lane_bands = 0, sites = 0, wave_any_site_rows = 0;
   double full_stack_push = 0;  // rows that the real sweep pushes (after the s1 filter and the push test)
+  double coarse_push[4] = {0}, coarse_depth[4] = {0}, anyrow[NF] = {0}, lines = 0;
 #pragma omp parallel
   {
     double l_surv[NF] = {0}, l_iter[NF] = {0}, l_hist[NF][2 * BAND + 3];
     memset(l_hist, 0, sizeof(l_hist));
     double l_wb = 0, l_lb = 0, l_sites = 0, l_any = 0, l_push = 0;
+    double l_coarse_push[4] = {0}, l_coarse_depth[4] = {0}, l_anyrow[NF] = {0}, l_lines = 0;
     int64_t* G = malloc(8 * (n + 2) * 64);
     uint8_t* keep = malloc((size_t)NF * n * 64);
     Pt* st = malloc(sizeof(Pt) * (n + 4));
@@ -181,6 +183,7 @@ int main(int argc, char** argv)
         g[-1] = (int64_t)NOSITE + 1;  // row -1: no site (G(-1) = NOSITE + 1)
         g[n] = (int64_t)NOSITE + (int64_t)n * n;
         uint8_t* kp = keep + (size_t)lane * n;
+        l_lines++;
         for (int q = 0; q < n; q++)
         {
           const int is_site = g[q] - (int64_t)q * q < NOSITE;
@@ -214,6 +217,41 @@ int main(int argc, char** argv)
             for (int i = 0; i < depth; i++)
               if (st[i].r >= r0 && st[i].r < r0 + band) kp[(size_t)lvl * 64 * n + st[i].r] = 1;
           }
+        // A GLOBAL filter: the lower hull of a subsample of the line's rows (every 8th / 16th row) lies on or above the
+        // line's hull, so a row strictly above the subsample hull's chord over it is no vertex.  (Rows of the subsample
+        // that are vertices of its hull survive; everything is combined with the s1 test.)
+        for (int lvl = 6, step = 8; lvl <= 9; lvl++, step *= 2)
+        {
+          int depth = 0;
+          for (int q = 0; q < n; q += step)
+          {
+            if (g[q] - (int64_t)q * q >= NOSITE) continue;
+            while (depth >= 2)
+            {
+              const Pt a = st[depth - 2], b = st[depth - 1];
+              if ((b.G - a.G) * (q - b.r) >= (g[q] - b.G) * (b.r - a.r)) depth--; else break;
+            }
+            st[depth].G = g[q]; st[depth].r = q; depth++;
+            l_coarse_push[lvl - 6]++;
+          }
+          l_coarse_depth[lvl - 6] += depth;
+          int k = 0;
+          for (int q = 0; q < n; q++)
+          {
+            int keepq = kp[q];  // s1
+            if (keepq && depth >= 2)
+            {
+              while (k + 2 < depth && st[k + 1].r <= q) k++;
+              const Pt a = st[k], b = st[k + 1];
+              if (q > a.r && q < b.r)
+              {
+                // on or above the chord a..b ?
+                if ((g[q] - a.G) * (b.r - a.r) >= (b.G - a.G) * (q - a.r)) keepq = 0;
+              }
+            }
+            kp[(size_t)lvl * 64 * n + q] = keepq;
+          }
+        }
         // the real sweep's pushes (s1 filter + "beats the top before the last row"), for reference
         {
           int depth = 0;
@@ -250,6 +288,13 @@ int main(int argc, char** argv)
           l_hist[f][mx]++;
         }
         l_lb += 64;
+        for (int f = 0; f < NF; f++)
+          for (int q = r0; q < r0 + BAND && q < n; q++)
+          {
+            int any = 0;
+            for (int lane = 0; lane < 64; lane++) any |= keep[(size_t)f * 64 * n + (size_t)lane * n + q];
+            l_anyrow[f] += any;
+          }
         for (int q = r0; q < r0 + BAND && q < n; q++)
         {
           int any = 0;
@@ -265,11 +310,14 @@ int main(int argc, char** argv)
         surv[f] += l_surv[f]; wave_iter[f] += l_iter[f];
         for (int i = 0; i < 2 * BAND + 3; i++) hist_iter[f][i] += l_hist[f][i];
       }
+      for (int i = 0; i < 4; i++) { coarse_push[i] += l_coarse_push[i]; coarse_depth[i] += l_coarse_depth[i]; }
+      for (int f = 0; f < NF; f++) anyrow[f] += l_anyrow[f];
+      lines += l_lines;
       wave_bands += l_wb; lane_bands += l_lb; sites += l_sites; wave_any_site_rows += l_any; full_stack_push += l_push;
     }
     free(G); free(keep); free(st);
   }
-  const char* names[NF] = {"s1", "s1+s2", "s1+s2+s4", "s1..s8", "band hull", "32-row hull"};
+  const char* names[NF] = {"s1", "s1+s2", "s1+s2+s4", "s1..s8", "band hull", "32-row hull", "coarse/8 + s1", "coarse/16 + s1", "coarse/32 + s1", "coarse/64 + s1"};
   printf("X pass, per lane and %d-row band: sites %.2f, real pushes %.2f; wave rows with a surviving site (s1): %.2f of %d\n",
          BAND, sites / lane_bands, full_stack_push / lane_bands, wave_any_site_rows / wave_bands, BAND);
   for (int f = 0; f < NF; f++)
@@ -279,7 +327,11 @@ int main(int argc, char** argv)
            surv[f] / (bands * 64), wave_iter[f] / bands, wave_iter[f] / wave_bands);
     for (int i = 0; i < 2 * BAND + 3; i++)
       if (hist_iter[f][i] > 0) printf(" %d:%.3f", i, hist_iter[f][i] / bands);
+    printf(" | wave-rows with a survivor: %.2f of 16", anyrow[f] / wave_bands);
     printf("\n");
   }
+  for (int i = 0; i < 4; i++)
+    printf("coarse hull of every %dth row: %.1f vertices per line on average, %.1f rows fed to its sweep\n", 8 << i,
+           coarse_depth[i] / lines, coarse_push[i] / lines);
   return 0;
 }

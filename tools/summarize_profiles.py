@@ -12,6 +12,10 @@ EXPECTED = {"PassZClassRecords": "4 GiB read (float occupancy) + 0.25 GiB write 
             "PassXFinalize": "4 GiB read (int32) + 4 GiB write (float)"}
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from voxelized_geometry_tools_amd import synthetic  # noqa: E402
+
+
 def classify(name):
     if "vgt::" not in name:
         return None
@@ -39,6 +43,7 @@ def main():
     summary = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 "
                           "--warmup 1 --no-cpu-baseline (1024^3 D1 spheres), separate passes",
                "commit": commit,
+               "sources_sha256": synthetic.kernel_sources_sha256("edt"),
                "note": "MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes of a "
                        "coalesced streaming read (128-B requests tallied at 64 B), WRITE_SIZE is exact.  "
                        "'fetch_bytes_corrected' doubles the raw value: pass 1 and the X pass read one 256-B row segment "
@@ -129,6 +134,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         current = {"commit": commit,
+                   "sources_sha256": synthetic.kernel_sources_sha256("voxelizer"),
                    "command": "rocprofv3 --pmc TCC_ATOMIC(_sum) --kernel-trace -- python3 bench_raycast.py --no-check; "
                               "tools/microbench/scattered_atomics",
                    "scattered_atomic_rate_G_per_s": micro.get("scattered_G_atomics_per_s"),

@@ -17,7 +17,7 @@ from voxelized_geometry_tools_amd import capi
 
 NAMES = ["sweep 1: waiting for the band's rows (loads drained at the top of a band)", "sweep 1: ring checks (spills, refills)",
          "sweep 1: the rows", "sweep 2: refill steps", "sweep 2: the rows (refill steps included)", "items, whole",
-         "the first band's loads", "-"]
+         "the first band's loads", "the coarse hull's first sweep (X pass, kCoarse)"]
 
 
 def main():

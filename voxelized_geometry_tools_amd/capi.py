@@ -115,6 +115,7 @@ TESTING_SIGNATURES = {
     "vgt_hip_testing_set_host_pipeline_min_voxels": (_int, [ctypes.c_int64]),
     "vgt_hip_testing_set_short_line_rows": (_int, [_int]),
     "vgt_hip_testing_set_sweep_hand_over": (_int, [_int]),
+    "vgt_hip_testing_set_sweep_coarse_hull": (_int, [_int]),
     "vgt_hip_testing_class_record_bytes": (_sz, [_i64, _i64, _i64]),
     "vgt_hip_testing_class_records_dev": (_int, [_p, _p, _i64, _i64, _i64, _int, _i64, _p, _p]),
 }
@@ -329,6 +330,10 @@ class Context:
     def set_sweep_hand_over(self, on):
         """Testing library only: whether short sweep launches hand over lower halves of their second sweeps."""
         check(self._lib.vgt_hip_testing_set_sweep_hand_over(int(bool(on))))
+
+    def set_sweep_coarse_hull(self, on):
+        """Testing library only: whether the X pass builds a coarse hull in front of its sweep."""
+        check(self._lib.vgt_hip_testing_set_sweep_coarse_hull(int(bool(on))))
 
     def set_host_pipeline_min_voxels(self, min_voxels):
         """Testing library only (process-wide there): smallest grid the host-pointer SDF entry points pipeline."""

@@ -851,7 +851,11 @@ void SetShortLineRows(int rows)
 std::atomic<bool> g_sweep_hand_over{false};
 bool SweepHandOver() { return g_sweep_hand_over.load(); }
 void SetSweepHandOver(bool on) { g_sweep_hand_over.store(on); }
+std::atomic<bool> g_sweep_coarse_hull{kSweepCoarseHullDefault};
+bool SweepCoarseHull() { return g_sweep_coarse_hull.load(); }
+void SetSweepCoarseHull(bool on) { g_sweep_coarse_hull.store(on); }
 #else
+bool SweepCoarseHull() { return kSweepCoarseHullDefault; }
 int ShortLineRows() { return kShortLineRows; }
 bool SweepHandOver() { return false; }
 #endif

@@ -92,6 +92,11 @@ constexpr int kCounterStride = 32;              // ints between two counters (12
 // ---- Handing over the lower half of an item's second sweep (launches of at most two rounds of items; see SweepPassKernel)
 // The head of the scratch buffer: the work counters, then one `resolved` count, then per workgroup a task record.
 constexpr int kStealMinRows = 128;              // shorter lines are not worth a hand-over
+#ifndef VGT_COARSE_STRIDE
+#define VGT_COARSE_STRIDE 32
+#endif
+constexpr int kCoarseStride = VGT_COARSE_STRIDE;  // every how many rows the coarse hull takes one (a multiple of kBand)
+constexpr int kCoarseMinRows = 768;                // shorter lines: not worth the first sweep (512 rows: +-0, 256: +3 %)
 constexpr int kMaxSweepSlots = 4096;
 constexpr int kMaxXcc = 16;
 struct StealTask
@@ -504,10 +509,19 @@ __device__ __forceinline__ bool XccCas(int* p, int expected, int desired)
 // owns row split - 1 by bisection, takes the chunks around it into its own ring and evaluates downwards from there while
 // the owner evaluates rows [split, n); an offer nobody has taken when the owner reaches row `split` is withdrawn and the
 // owner carries on.  Same code, same arithmetic, same results whoever evaluates a row.
-template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain, bool kSteal>
+// kCoarse (X pass, 32-bit entries; testing library only -- measured, see LaunchSweep): a COARSE HULL in front of the sweep.  On a sparse scene the X pass pushes 6.7 sites per
+// lane and 16 rows of which 2 stay -- the others are popped by sites far away, which no local test sees coming
+// (tools/sim/band_filter_sim.c).  So the line is swept twice: first every kCoarseStride-th row alone, through the same
+// stack code; the hull of that subsample (a dozen vertices per line on average) goes to the scratch, the stack starts
+// again, and in the sweep proper a row strictly above the chord between the two subsample vertices around it never
+// touches the stack -- it lies above a segment between two real sites, so it is no vertex of the line's hull, whatever
+// else the line holds.  In the simulation the rows on which ANY lane of a wave still needs the push / pop code fall from
+// 14.2 to 5.0 of 16 (D1, every 32nd row).
+template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain, bool kSteal, bool kCoarse>
 __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
                                                                             OutT* __restrict__ out,
                                                                             unsigned char* __restrict__ spill,
+                                                                            unsigned char* __restrict__ coarse,
                                                                             uint2* __restrict__ word_info,
                                                                             uint32_t* __restrict__ minmax_enc,
                                                                             int* __restrict__ work_counter,
@@ -518,6 +532,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // the Y pass reads class records (the default pipeline) or int16 distances along Z (the cross-check pipelines)
   constexpr bool kRecords = std::is_same<InT, ClassRecord>::value;
   static_assert(!(kRecords && kFinal), "records feed the Y pass");
+  static_assert(!kCoarse || (kFinal && kPacked && !kSteal), "the coarse hull is built for the X pass with 32-bit entries");
   constexpr int kRing = RingShape<kPacked>::kRing;
   constexpr int kChunk = RingShape<kPacked>::kChunk;
   constexpr int32_t kLimit = C::kSentinelG;  // values at or above: no site
@@ -537,6 +552,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // the lines it works on, so the scratch is sized by the number of workgroups in flight, not by the grid.
   unsigned char* const own_spill = spill + static_cast<int64_t>(blockIdx.x) * g.chunks * (kWaveSize * kChunkBytes);
   uint2* const own_info = word_info + static_cast<int64_t>(blockIdx.x) * (g.nwords + 1) * kWaveSize;
+  // (kCoarse: this slot's part of the coarse hulls' area, laid out like the spill area: chunks of kChunk entries per lane)
+  [[maybe_unused]] unsigned char* const own_coarse =
+      kCoarse ? coarse + static_cast<int64_t>(blockIdx.x) * g.coarse_chunks * (kWaveSize * kChunkBytes) : nullptr;
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
   float lo_value = INFINITY, hi_value = -INFINITY;
@@ -1108,11 +1126,155 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       // successor -- that is every row but the ends.
       // (with "no site" as a huge hull point the test needs no flags: next to such a neighbour the site is kept, and a row
       // that is no site itself is dropped here or rejected by site())
+      // ---- kCoarse: the first sweep, over every kCoarseStride-th row, and what the sweep proper keeps of it ----
+      // cha / chb: the subsample hull's vertices around the band at work, as they lie in the scratch (chb: the next one
+      // ahead; "unknown" = none), chc: the one after chb, fetched a band or more before it is needed, ch_next its index.
+      [[maybe_unused]] Entry cha = C::Unknown(), chb = C::Unknown(), chc = C::Unknown();
+      [[maybe_unused]] int ch_next = 0;
+      [[maybe_unused]] bool coarse_synced = false;  // the coarse area's stores have been waited for (before the first load from it)
+      [[maybe_unused]] bool coarse_active = kCoarse;  // the filter is in use (not on lines it does nothing for)
+      [[maybe_unused]] auto coarse_entry = [&](int index) -> Entry {
+        const uint32_t chunk_first = static_cast<uint32_t>(index / kChunk) * kChunkSlots;
+        return reinterpret_cast<const Entry*>(own_coarse + (chunk_first + lane_chunk))[index % kChunk];
+      };
+      if constexpr (kCoarse)
+      {
+        static_assert(kCoarseStride % kBand == 0, "a band never holds two vertices of the subsample's hull");
+        VGT_PHASE_MARK(phase_coarse_a);
+        // (the first sweep spills into the coarse area, where its result is to lie anyway)
+        wave_spill = own_coarse;
+        constexpr int kBatch = 2 * kBand;  // subsample rows in flight at a time: one memory latency for a 1024-row line
+        for (int s0 = 0; s0 < n; s0 += kBatch * kCoarseStride)
+        {
+          int32_t sub[kBatch];
+          {
+            // (rows past the line's end repeat the last subsample row and are not used)
+            const int last_sub = (n - 1) / kCoarseStride * kCoarseStride;
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+            {
+              const int q = min(s0 + k * kCoarseStride, last_sub);
+              const VGT_GLOBAL InT* row_in = UniformPointer(GlobalPointer(wave_in + static_cast<int64_t>(q) * rstride));
+              sub[k] = static_cast<int32_t>(*LaneAddress(row_in, lane_bytes));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < kBatch; k++)
+          {
+            const int q = s0 + k * kCoarseStride;
+            if (q < n)
+            {
+              if (k % kChunk == 0) check_ring();
+              int32_t G_sub;
+              decode(sub[k], q, G_sub);
+              site(q, G_sub, true);
+            }
+          }
+        }
+        // The subsample hull's first two vertices (entries 4 and 5: behind the sentinels) straight from the ring, where they
+        // still are unless the first sweep spilled (33 rows and the sentinels: rare) -- no round trip through memory at
+        // the start of the sweep proper.
+        const int coarse_depth = static_cast<int>(D >> kShift);
+        const bool in_ring = L == 0u;
+        // Where (nearly) every row of the subsample is a vertex of its hull the line is convex at that scale -- noise on top
+        // of row^2, or the smooth far field of a single obstacle -- and the rows in between are vertices too: the filter
+        // would remove nothing and is not consulted (a dense scene: X pass +9 % with it, profiles/r5/experiments.md).
+        {
+          const int subsample_rows = (n + kCoarseStride - 1) / kCoarseStride;
+          const uint64_t useful = __builtin_amdgcn_ballot_w64(4 * (coarse_depth - 4) <= 3 * subsample_rows);
+          coarse_active = __builtin_popcountll(useful) >= kWaveSize / 2;
+        }
+        if (coarse_depth > 4 && in_ring) chb = ring_ref(4u << kShift);
+        if (coarse_depth > 5 && in_ring) chc = ring_ref(5u << kShift);
+        ch_next = 5;
+        // the whole stack into the coarse area (the ring's entries join the chunks spilled on the way), "unknown" behind it
+        for (uint32_t first = L; __builtin_amdgcn_ballot_w64(first < D) != 0ull;)
+        {
+          if (first < D)
+          {
+            Entry buf[kChunk];
+            Entry* const slots = chunk_in_ring(first);
+#pragma unroll
+            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, first, j);
+            StoreChunk(spill_ptr(first), buf);
+            first += kChunkSlots;
+          }
+        }
+        {
+          const uint32_t chunk_first = static_cast<uint32_t>(coarse_depth / kChunk) * kChunkSlots;
+          reinterpret_cast<Entry*>(own_coarse + (chunk_first + lane_chunk))[coarse_depth % kChunk] = C::Unknown();
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_ring) != 0ull, 0))
+        {
+          VGT_COLD_PATH();
+#ifndef VGT_HOST_EMULATION
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (read back by the same lanes)
+#endif
+          if (!in_ring)
+          {
+            chb = coarse_entry(4);
+            if (!C::IsUnknown(chb)) chc = coarse_entry(5);
+          }
+          coarse_synced = true;
+        }
+        // the stack starts again
+        wave_spill = own_spill;
+        D = 4u << kShift;
+        L = 0;
+        Gt = C::kSentinelG;
+        nB = 1;
+        rt = 0;
+        A = 0;
+        e3 = C::Pack(C::kSentinelG + 2, 0);
+        pf_count = 0;
+        ring_ref(0u << kShift) = C::Pack(0, 0);
+        ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 2, 0);
+        ring_ref(2u << kShift) = C::Pack(C::kSentinelG + 1, 0);
+        ring_ref(3u << kShift) = C::Pack(C::kSentinelG, 0);
+        VGT_PHASE_MARK(phase_coarse_b);
+        VGT_PHASE_ADD(7, phase_coarse_a, phase_coarse_b);
+      }
       int32_t G_prev = kNoSiteG, G_cur = 0;
       decode(nxt[0], 0, G_cur);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
+        // (kCoarse) the chord over this band: from the vertex at or below its first row to the next one, which lies beyond
+        // its last row; no chord (width 0: the test below then never fires) before the first and behind the last vertex
+        [[maybe_unused]] int32_t chord_G = 0, chord_dG = 0;
+        [[maybe_unused]] int chord_row = 0, chord_width = 0;
+        if constexpr (kCoarse)
+        {
+          const bool arrived = static_cast<int>(!C::IsUnknown(chb)) & static_cast<int>(r0 >= C::Row(chb));
+          if (__builtin_amdgcn_ballot_w64(arrived) != 0ull)
+          {
+#ifndef VGT_HOST_EMULATION
+            if (!coarse_synced)
+            {
+              // (the first load from the coarse area: its stores -- issued a first sweep ago -- are waited for here, once)
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              coarse_synced = true;
+            }
+#endif
+            if (arrived)
+            {
+              cha = chb;
+              chb = chc;
+              if (!C::IsUnknown(chc))
+              {
+                ch_next++;
+                chc = coarse_entry(ch_next);
+              }
+            }
+          }
+          if (static_cast<int>(!C::IsUnknown(cha)) & static_cast<int>(!C::IsUnknown(chb)))
+          {
+            chord_G = C::G(cha);
+            chord_row = C::Row(cha);
+            chord_dG = C::G(chb) - chord_G;
+            chord_width = C::Row(chb) - chord_row;
+          }
+        }
         int32_t cur[kBand];
         VGT_PHASE_MARK(phase_top_a);
         VGT_PHASE_DRAIN();
@@ -1122,8 +1284,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
         for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
         if (r0 + kBand < n) load_band(nxt, r0 + kBand);
         uint32_t bits = 0;  // sign bits of this band
-        auto rows = [&](auto guarded) {
+        auto rows = [&](auto guarded, auto filtered) {
           constexpr bool kGuard = decltype(guarded)::value;
+          constexpr bool kFiltered = decltype(filtered)::value;  // (kCoarse) the chord of the subsample's hull is consulted
 #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
@@ -1145,17 +1308,40 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               int32_t G_next = kNoSiteG + (q + 1) * (q + 1);  // (past the last row: no site)
               // (every row of a full band but its last has a successor: no test)
               if ((!kGuard && k + 1 < kBand) || q + 1 < n) decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
-              site(q, G_cur, G_cur - G_prev < G_next - G_cur);
+              if constexpr (kFiltered)
+              {
+                // strictly above the chord of the subsample's hull over this row: no vertex of the line's hull
+                const bool above = static_cast<int64_t>(G_cur - chord_G) * chord_width -
+                                       static_cast<int64_t>(chord_dG) * (q - chord_row) > 0;
+                site(q, G_cur, static_cast<int>(G_cur - G_prev < G_next - G_cur) & static_cast<int>(!above));
+              }
+              else
+                site(q, G_cur, G_cur - G_prev < G_next - G_cur);
               G_prev = G_cur;
               G_cur = G_next;
             }
           }
         };
         VGT_PHASE_MARK(phase_rows_a);
-        if (r0 + kBand <= n)
-          rows(std::false_type{});
+        if constexpr (kCoarse)
+        {
+          // (A test of whole bands -- the band's smallest hull point against the chord's largest value over it -- in front of
+          // the per-row tests was measured too: it skips most bands of a sparse scene and is slower all the same, 2.41
+          // against 2.37 ms; profiles/r5/experiments.md.)
+          if (r0 + kBand > n)
+            rows(std::true_type{}, std::true_type{});
+          else if (coarse_active)
+            rows(std::false_type{}, std::true_type{});
+          else
+            rows(std::false_type{}, std::false_type{});
+        }
         else
-          rows(std::true_type{});
+        {
+          if (r0 + kBand <= n)
+            rows(std::false_type{}, std::false_type{});
+          else
+            rows(std::true_type{}, std::false_type{});
+        }
         VGT_PHASE_MARK(phase_rows_b);
         VGT_PHASE_ADD(2, phase_rows_a, phase_rows_b);
         band_done(r0, __builtin_bitreverse32(bits));  // (row k of the band: bit kBand - 1 - k -> bit 32 - kBand + k)
@@ -1726,6 +1912,15 @@ bool PackedEntries(int64_t n, int64_t max_input)
   return n <= 1024 && max_input + (n - 1) * (n - 1) < Codec<true>::kSentinelG;
 }
 
+// Chunks per lane and bytes per slot of the coarse hulls' area (32-bit entries, lines of kCoarseMinRows rows and more):
+// the subsample's hull at full depth, the sentinels, the "unknown" behind it.
+int64_t CoarseChunks(int64_t n) { return (n / kCoarseStride + 1 + 5 + RingShape<true>::kChunk - 1) / RingShape<true>::kChunk + 1; }
+size_t CoarseAreaBytes(int64_t n, bool packed)
+{
+  if (!packed || n < kCoarseMinRows) return 0;
+  return static_cast<size_t>(CoarseChunks(n)) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t);
+}
+
 // Scratch of one slot: the spill chunks of its 64 lines (every entry of a full-depth stack) and one (sign word, carry) pair
 // per 32 rows and lane.
 size_t SlotScratchBytes(int64_t n, bool packed)
@@ -1734,7 +1929,7 @@ size_t SlotScratchBytes(int64_t n, bool packed)
   const size_t spill = packed ? SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t)
                               : SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
   // (+ one row: each lane's stack depth, for a hand-over)
-  return spill + static_cast<size_t>(nwords + 1) * kWaveSize * sizeof(uint2);
+  return spill + static_cast<size_t>(nwords + 1) * kWaveSize * sizeof(uint2) + CoarseAreaBytes(n, packed);
 }
 
 // Scratch of one pass: the work counters and the slots of the workgroups in flight, for the entry kind the extents call
@@ -1784,6 +1979,10 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
   const size_t spill_bytes =
       static_cast<size_t>(slots) * g.chunks * kWaveSize * chunk * (packed ? sizeof(uint32_t) : sizeof(uint2));
   uint2* info = reinterpret_cast<uint2*>(bytes + kCounterBytes + spill_bytes);
+  // (behind the sign words: the coarse hulls' area of the slots, when the extents give it any)
+  unsigned char* coarse_area = reinterpret_cast<unsigned char*>(info) +
+                               static_cast<size_t>(slots) * (g.nwords + 1) * kWaveSize * sizeof(uint2);
+  g.coarse_chunks = static_cast<int>(CoarseChunks(g.n));
 #ifdef VGT_HOST_EMULATION
   *counter = 0;
 #endif
@@ -1808,9 +2007,37 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
     if (err != hipSuccess) return err;
   }
 #endif
-#define VGT_LAUNCH_SWEEP(PACKED, PLAIN, STEAL)                                                                      \
-  hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, PACKED, PLAIN, STEAL>), grid, block, 0, stream, in, out, \
-                     spill, info, minmax_enc, counter, g)
+  // The X pass with 32-bit entries on lines of kCoarseMinRows rows and more: a coarse hull in front of the sweep.
+  // MEASURED (profiles/r5/experiments.md): it removes 71 % of sweep 1's pops, 47 % of its pushes and 97 % of its
+  // synchronous refills on the 1024^3 headline -- and 4 % of the pass's time, while dense scenes and one-round launches
+  // lose 6 %: the pass is not bound by what the filter removes.  Built, parity-tested
+  // (tests/test_gpu_sdf.py::test_coarse_hull_on_and_off, the CPU emulation) and kept in the testing library only, off unless
+  // vgt_hip_testing_set_sweep_coarse_hull turns it on (diagnostic builds: -DVGT_SWEEP_COARSE_DEFAULT=1).
+#if (defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION) || VGT_SWEEP_COARSE_DEFAULT)
+  const bool coarse_hull = kFinal && packed && !steal && g.n >= kCoarseMinRows && SweepCoarseHull() &&
+                           CoarseAreaBytes(g.n, packed) > 0;
+#else
+  const bool coarse_hull = false;
+#endif
+#define VGT_LAUNCH_SWEEP_COARSE(PACKED, PLAIN, STEAL, COARSE)                                                         \
+  hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, PACKED, PLAIN, STEAL, COARSE>), grid, block, 0, stream, in, \
+                     out, spill, coarse_area, info, minmax_enc, counter, g)
+#define VGT_LAUNCH_SWEEP(PACKED, PLAIN, STEAL) VGT_LAUNCH_SWEEP_COARSE(PACKED, PLAIN, STEAL, false)
+#if (defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION) || VGT_SWEEP_COARSE_DEFAULT)
+  if constexpr (kFinal)
+  {
+    if (coarse_hull)
+    {
+      if (general)
+        VGT_LAUNCH_SWEEP_COARSE(true, false, false, true);
+      else
+        VGT_LAUNCH_SWEEP_COARSE(true, true, false, true);
+      return hipGetLastError();
+    }
+  }
+#else
+  (void)coarse_hull;
+#endif
 #if defined(VGT_HIP_TESTING) && !defined(VGT_HOST_EMULATION)
   if (steal)
   {
@@ -1836,6 +2063,7 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
       VGT_LAUNCH_SWEEP(false, true, false);
   }
 #undef VGT_LAUNCH_SWEEP
+#undef VGT_LAUNCH_SWEEP_COARSE
   return hipGetLastError();
 }
 

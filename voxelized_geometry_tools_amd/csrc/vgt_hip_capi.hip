@@ -980,6 +980,12 @@ int vgt_hip_testing_set_sweep_hand_over(int on)
   return VGT_HIP_OK;
 }
 
+int vgt_hip_testing_set_sweep_coarse_hull(int on)
+{
+  vgt::SetSweepCoarseHull(on != 0);
+  return VGT_HIP_OK;
+}
+
 size_t vgt_hip_testing_class_record_bytes(int64_t nx, int64_t ny, int64_t nz)
 {
   if (nx <= 0 || ny <= 0 || nz <= 0) return 0;

@@ -173,6 +173,14 @@ int ShortLineRows();
 // Whether sweep launches of at most two rounds of items hand over lower halves of their second sweeps: never in the
 // product (measured slower, edt_sweep_kernels.hip), in a testing build when vgt_hip_testing_set_sweep_hand_over says so.
 bool SweepHandOver();
+// Whether the X pass builds a coarse hull in front of its sweep (edt_sweep_kernels.hip, kCoarse): never in the product
+// (measured: -4 % on the 1024^3 headline, +6 % on dense scenes and on one-round launches; profiles/r5/experiments.md), in a
+// testing build when vgt_hip_testing_set_sweep_coarse_hull says so.
+bool SweepCoarseHull();
+#ifndef VGT_SWEEP_COARSE_DEFAULT
+#define VGT_SWEEP_COARSE_DEFAULT 0
+#endif
+constexpr bool kSweepCoarseHullDefault = VGT_SWEEP_COARSE_DEFAULT != 0;
 inline int ShortLineLimit(int64_t items)
 {
   const int rows = ShortLineRows();
@@ -182,6 +190,7 @@ inline int ShortLineLimit(int64_t items)
 #ifdef VGT_HIP_TESTING
 void SetShortLineRows(int rows);
 void SetSweepHandOver(bool on);
+void SetSweepCoarseHull(bool on);
 #endif
 hipError_t LaunchPassYShortRecords(const ClassRecord* records, int32_t* out32, const SdfParams& p, hipStream_t stream);
 hipError_t LaunchPassXShortFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, const SdfParams& p,

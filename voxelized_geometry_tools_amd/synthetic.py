@@ -137,3 +137,21 @@ def translation_xform(tx, ty, tz):
     m = np.eye(4, dtype=np.float64)
     m[:3, 3] = (tx, ty, tz)
     return m.T.reshape(16).copy()  # column-major flattening
+
+
+def kernel_sources_sha256(group="edt"):
+    """sha256 over the HIP sources a profile belongs to (csrc/edt_* + the shared headers, or the voxelizer's), in name
+    order: profiles/*_current.json record it when they are collected and bench.py reports their numbers only for a tree
+    whose sources still hash to it (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    patterns = {"edt": ["edt_*.hip", "edt_*.hpp", "vgt_internal.hpp"],
+                "voxelizer": ["voxelizer_kernels.hip"]}[group]
+    files = sorted(f for pat in patterns for f in glob.glob(os.path.join(csrc, pat)))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
