@@ -96,7 +96,7 @@ def profiled_traffic(kernel, default_workload, timed_kernel_ms):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, tools/collect_profiles.sh): counters cannot be read from inside this process.  The file
     names the commit, a hash of the EDT sources, the kernel and the kernel's duration it was collected with; the value is
-    only reported when this tree's EDT sources hash to the same value AND the kernel timed in THIS run is within 5 % of
+    only reported when this tree's EDT sources hash to the same value AND the kernel timed in THIS run is within 10 % of
     that duration (else null)."""
     if not default_workload:
         return None, None
@@ -110,7 +110,9 @@ def profiled_traffic(kernel, default_workload, timed_kernel_ms):
                           "collect it again (tools/collect_profiles.sh)" % doc.get("commit", "?"))
         entry = doc["kernels"][kernel]
         recorded_ms = float(entry["kernel_ns"]) * 1e-6
-        if recorded_ms <= 0 or abs(timed_kernel_ms - recorded_ms) > 0.05 * recorded_ms:
+        # (the hash says it is this build; the duration only guards against a box at another clock / memory level, and the
+        # profiler's own run is a few per cent slower than an unprofiled one)
+        if recorded_ms <= 0 or abs(timed_kernel_ms - recorded_ms) > 0.10 * recorded_ms:
             return None, "profiles/pmc_hbm_traffic_current.json is for a %.3f ms kernel (commit %s): not this build" % (
                 recorded_ms, doc.get("commit", "?"))
         return round(entry["hbm_bytes"] / 1e9, 3), (
