@@ -98,10 +98,6 @@ __device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracki
 constexpr int kTableSlotsPerThread = 16;  // slots = 16 x workgroup size (4096 slots = 32 KiB of LDS at 256 threads)
 constexpr int kTableProbes = 6;
 constexpr int kWalkSegment = 96;        // steps between flushes
-#ifndef VGT_RAY_COMBINED_STEPS
-#define VGT_RAY_COMBINED_STEPS 24
-#endif
-constexpr int kCombinedSteps = VGT_RAY_COMBINED_STEPS;  // first steps of a walk whose table inserts are combined per wave
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
 struct VisitTable
@@ -118,8 +114,8 @@ struct VisitTable
       counts[s] = 0u;
     }
   }
-  // `visits` seen-free visits of `cell` (cell < 2^32 - 1)
-  __device__ __forceinline__ void Add(uint32_t cell, int32_t* __restrict__ tracking, uint32_t visits = 1u)
+  // seen-free visit of `cell` (cell < 2^32 - 1)
+  __device__ __forceinline__ void Add(uint32_t cell, int32_t* __restrict__ tracking)
   {
     uint32_t slot = (cell * 2654435761u) >> shift;
 #pragma unroll 1
@@ -129,32 +125,12 @@ struct VisitTable
       if (key == kEmptyKey) key = atomicCAS(&keys[slot], kEmptyKey, cell);
       if (key == cell || key == kEmptyKey)
       {
-        atomicAdd(&counts[slot], visits);
+        atomicAdd(&counts[slot], 1u);
         return;
       }
       slot = (slot + 1u) & static_cast<uint32_t>(slots - 1);
     }
-    atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], static_cast<int32_t>(visits));
-  }
-  // The same for the first steps of a walk, where the rays of a wave -- neighbours in direction, all leaving from one
-  // point -- are still in a handful of cells: 64 LDS atomics on one word take 64 turns, so the wave combines equal cells
-  // first (the leader of each group adds the group's size; after kMaxRounds groups the rest go one by one).
-  __device__ __forceinline__ void AddCombined(uint32_t cell, int32_t* __restrict__ tracking)
-  {
-    uint64_t pending = __ballot(1);
-    const int lane = static_cast<int>(__lane_id());
-    bool mine = true;
-    for (int round = 0; round < kMaxRounds && pending; round++)
-    {
-      const int leader = __ffsll(static_cast<long long>(pending)) - 1;
-      const uint32_t group = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cell), leader));
-      const bool member = mine && (cell == group);
-      const uint64_t same = __ballot(member);
-      if (lane == leader) Add(group, tracking, static_cast<uint32_t>(__popcll(same)));
-      if (member) mine = false;
-      pending &= ~same;
-    }
-    if (mine) Add(cell, tracking);
+    atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
   }
   __device__ __forceinline__ void Flush(int32_t* __restrict__ tracking)
   {
@@ -420,18 +396,7 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
         }
         const int64_t cell = CellIndex(cur, g.counts);
         if constexpr (kTable)
-        {
-#ifndef VGT_RAY_EXP
-#define VGT_RAY_EXP 0  // diagnostic builds (timing only, wrong counts): 1 = no table inserts in the first steps, 2 = none at all
-#endif
-          if ((VGT_RAY_EXP & 2) || ((VGT_RAY_EXP & 1) && walked < kCombinedSteps))
-          {
-          }
-          else if (walked < kCombinedSteps)  // (`walked` is the same for every lane still in the loop)
-            table.AddCombined(static_cast<uint32_t>(cell), tracking);
-          else
-            table.Add(static_cast<uint32_t>(cell), tracking);
-        }
+          table.Add(static_cast<uint32_t>(cell), tracking);
         else if (walked < kAggregatedSteps)  // `walked` is the same for every lane still in the loop
           AggregatedIncrement(tracking, cell * 2);
         else
