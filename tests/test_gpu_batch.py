@@ -35,8 +35,11 @@ def _mixed_batch(shape, batch, seed):
     return grids
 
 
+# (short-line kernels on both axes, on one, on none: lines of more than 64 rows take the sweeps, whose X pass deals
+# (grid, y, segment) items and keeps extrema per grid)
 BATCH_CASES = [((64, 64, 64), 7), ((13, 17, 40), 5), ((9, 70, 130), 3), ((1, 1, 5), 4), ((40, 40, 40), 64),
-               ((3, 5, 64), 2), ((1, 70, 1), 3), ((24, 8, 200), 1)]
+               ((3, 5, 64), 2), ((1, 70, 1), 3), ((24, 8, 200), 1), ((70, 9, 130), 3), ((130, 66, 65), 2),
+               ((300, 20, 33), 5), ((65, 129, 20), 4)]
 
 
 @pytest.mark.parametrize("shape,batch", BATCH_CASES)
@@ -148,6 +151,18 @@ def test_object_batch_on_the_fixture_grids(ctx, sdf_tagged_cases, dtype):
             single = cells.sdf(float(case["res"]), [int(oid)])
             assert bits_equal(batched[int(oid)][0], single[0]) and batched[int(oid)][1:] == single[1:], (name, oid)
         cells.close()
+
+
+def test_batch_limits(ctx):
+    """batch * nx * ny must stay below 2^28 lines for the device entry point (the host one cuts the batch itself)."""
+    import torch
+    shape = (512, 512, 1)
+    batch = 1024          # 2^28 lines exactly: refused
+    occ = torch.zeros(8, dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError):
+        ctx.sdf_batch_dev(occ.data_ptr(), batch, shape, 0.1, occ.data_ptr(), occ.data_ptr(), 1 << 40, None)
+    with pytest.raises(ValueError):
+        ctx.sdf_batch_dev(occ.data_ptr(), 0, shape, 0.1, occ.data_ptr(), occ.data_ptr(), 1 << 40, None)
 
 
 def test_batch_argument_errors(ctx):
