@@ -359,6 +359,11 @@ def secondary_workloads(ctx, torch, capi, device, res, steps=3, warmup=1):
     return out
 
 
+def synthetic_occupancy(shape):
+    from voxelized_geometry_tools_amd import synthetic
+    return synthetic.make_occupancy(shape, "spheres", seed=42)
+
+
 def batched_workloads(ctx, torch, capi, device, res, steps=5, warmup=2):
     """Many small grids in one call (vgt_hip_sdf_batch_dev) against the same grids one call each, device-resident, and
     the per-object fields of a tagged map (vgt_hip_cells_object_sdfs, host buffers in and out) against one
@@ -410,6 +415,22 @@ def batched_workloads(ctx, torch, capi, device, res, steps=5, warmup=2):
         del grids, fields, ws, mm, reference
     except Exception as exc:
         out["batch 64 x 64^3 D1 spheres"] = {"error": repr(exc)}
+    try:
+        # the reference's own use: one small map through the host-pointer entry point (example/tutorial.cpp extracts
+        # the field of a 40^3 map; its tests use 4 x 8 x 12): upload, three passes, download, blocking
+        rows = {}
+        for edge in (16, 40, 64):
+            occ_host = np.ascontiguousarray(synthetic_occupancy((edge,) * 3))
+            out_host = np.empty_like(occ_host)
+            for _ in range(3):
+                ctx.sdf_from_occupancy(occ_host, res, out=out_host)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                ctx.sdf_from_occupancy(occ_host, res, out=out_host)
+            rows["%d^3" % edge] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        out["one small map through the host entry point (ms per blocking call)"] = rows
+    except Exception as exc:
+        out["one small map through the host entry point (ms per blocking call)"] = {"error": repr(exc)}
     try:
         shape, objects = (128, 128, 128), 32
         rng = np.random.default_rng(42)
