@@ -206,7 +206,7 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
  * workspace holds the class records of pass 1 (0.25 bytes per voxel), the int32 intermediate field (4 bytes per voxel)
  * and the line passes' scratch, which grows with the axis lengths, not with the volume (the spilled stack entries and
  * sign words of the at most 4096 waves in flight: 1.1 GB for a 1024^3 grid, 4.4 GB at 2048 x 2048 x 1024; the launches
- * use as many workgroups as the scratch they are given holds).  5.7 GB in all at 1024^3. */
+ * use as many workgroups as the scratch they are given holds).  5.8 GB in all at 1024^3. */
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant);
 int vgt_hip_sdf_dev(vgt_hip_ctx* ctx, const float* occupancy_dev, int64_t nx, int64_t ny,
                     int64_t nz, double resolution, int unknown_is_filled,
