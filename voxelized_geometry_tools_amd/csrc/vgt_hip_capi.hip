@@ -40,6 +40,7 @@ struct vgt_hip_ctx
 {
   int device = -1;
   int threads_per_block = 256;
+  int raycast_threads = 0;       // 0: the raycast kernels choose their own workgroup sizes (no HIP_THREADS_PER_BLOCK given)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::mutex mutex;              // serialises enqueues + the staging buffer
@@ -825,6 +826,7 @@ int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx)
                    std::to_string(count) + " devices";
     return VGT_HIP_ERR_UNAVAILABLE;
   }
+  const int raycast_threads = threads_per_block > 0 ? threads_per_block : 0;
   if (threads_per_block <= 0) threads_per_block = 256;
   if (threads_per_block > 1024 || (threads_per_block % 64) != 0)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT,
@@ -834,6 +836,7 @@ int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx)
   if (!ctx) return Fail(VGT_HIP_ERR_RUNTIME, "out of host memory");
   ctx->device = device;
   ctx->threads_per_block = threads_per_block;
+  ctx->raycast_threads = raycast_threads;
   hipError_t err = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&ctx->minmax_out), 256);
   if (err != hipSuccess)
@@ -1130,7 +1133,7 @@ int vgt_hip_raycast_points_f32_dev(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_
     VGT_TRY_HIP(hipMalloc(&ctx->ray_scratch, scratch_bytes + scratch_bytes / 4), "allocate raycast scratch");
     ctx->ray_scratch_bytes = scratch_bytes + scratch_bytes / 4;
   }
-  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, 3, g, tracking, ctx->threads_per_block,
+  VGT_TRY_HIP(vgt::LaunchRaycastF32(points_xyz_dev, num_points, 3, g, tracking, ctx->raycast_threads,
                                     ctx->ray_scratch, ctx->ray_scratch_bytes, ctx->stream),
               "Failed to dispatch raycast kernel");
   return VGT_HIP_OK;
@@ -1162,7 +1165,7 @@ int vgt_hip_raycast_points_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(float);
-  const int threads = ctx->threads_per_block;
+  const int threads = ctx->raycast_threads;
   const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
   return UploadAndRun(ctx, points_xyz_host, bytes, scratch_bytes,
                       [&](const void* points_dev, void* scratch, hipStream_t stream) {
@@ -1203,7 +1206,7 @@ int vgt_hip_raycast_pointcloud2_f32(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * static_cast<size_t>(point_step);
-  const int threads = ctx->threads_per_block;
+  const int threads = ctx->raycast_threads;
   const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
   return UploadAndRun(ctx, cloud_data_host, bytes, scratch_bytes,
                       [&](const void* cloud_dev, void* scratch, hipStream_t stream) {
@@ -1240,7 +1243,7 @@ int vgt_hip_raycast_points_f64(vgt_hip_ctx* ctx, vgt_hip_grids* grids, size_t gr
   g.counts[2] = num_z_voxels;
   int32_t* tracking = static_cast<int32_t*>(vgt_hip_tracking_grids_dev_ptr(grids, grid_index));
   const size_t bytes = static_cast<size_t>(num_points) * 3 * sizeof(double);
-  const int threads = ctx->threads_per_block;
+  const int threads = ctx->raycast_threads;
   const size_t scratch_bytes = vgt::RaycastScratchBytes(num_points);
   return UploadAndRun(ctx, points_xyz_host, bytes, scratch_bytes,
                       [&](const void* points_dev, void* scratch, hipStream_t stream) {

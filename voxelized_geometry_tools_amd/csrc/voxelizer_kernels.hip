@@ -11,18 +11,22 @@
 // reference can index: 64-bit cell indices (the reference's int32 index overflows at 2^30
 // cells), tracking counters addressed as (cell*2 + {0 free, 1 filled}).
 //
-// Accumulation.  The kernel is bound by scattered global atomics (about 25 G increments/s chip-wide,
-// profiles/r1/bench_raycast_config3.json), not by the walk.  All rays of a call leave from one point,
-// so rays of similar direction visit the same voxels for a long stretch: large clouds are first
-// ordered by direction (a counting sort over cube-map bins, Morton order inside a face), so that a
-// workgroup's rays form a narrow cone, and the workgroup counts its seen-free visits in an LDS hash
-// table (cell -> count) that it flushes with ONE global atomic per distinct cell at the end of every
-// segment of the walk.  Integer additions commute, so the tracking counts are bit-identical to the
-// one-atomic-per-visit formulation; a visit that finds no slot within a few probes (wide cones far
-// from the sensor, incoherent clouds) simply goes to global memory directly.
+// The walk.  A ray's DDA state is kept as counters (cell index moved by a per-axis delta, steps left per axis, steps
+// left in all) so that a step is a few compares and selects: no three-way branch, no 64-bit index arithmetic.
+//
+// Accumulation.  All rays of a call leave from one point, so rays of similar direction visit the same voxels for a long
+// stretch: large clouds are first ordered by direction (a counting sort over cube-map bins, Morton order inside a face),
+// so that a workgroup's rays form a narrow cone, and the workgroup counts its seen-free visits in an LDS table (cell ->
+// count) that it flushes with ONE global atomic per distinct cell every few steps of the walk.  Integer additions
+// commute, so the tracking counts are bit-identical to the one-atomic-per-visit formulation; a visit that finds its
+// slot taken by another cell simply goes to global memory directly.  What the kernel costs, in the order it was
+// found (profiles/r5/experiments.md, "Raycaster"): the walk's instructions; the flush's scattered atomics, which the L2
+// retires by the 128-byte line (hence a table whose slot order is address order); lanes of a wave on ONE LDS address,
+// which the LDS serves one after the other (hence a wave's lanes spread over the workgroup's cone).
 #include "vgt_internal.hpp"
 
 #include <cmath>
+#include <type_traits>
 
 namespace vgt
 {
@@ -95,17 +99,64 @@ __device__ __forceinline__ void AggregatedIncrement(int32_t* __restrict__ tracki
 }
 
 // ---- per-workgroup accumulation table (see the header) ----
-constexpr int kTableSlotsPerThread = 16;  // slots = 16 x workgroup size (4096 slots = 32 KiB of LDS at 256 threads)
-constexpr int kTableProbes = 6;
-constexpr int kWalkSegment = 96;        // steps between flushes
+// Tuned on config 3 (profiles/r5/experiments.md, "Raycaster"): 512 rays per workgroup, 8 slots per ray (4096 slots = a
+// 16 x 16 x 16 window, 32 KiB of LDS), a flush every 16 steps.
+constexpr int kTableThreads = 512;        // workgroup size of the table kernel unless the caller fixes one
+constexpr int kPlainThreads = 256;        // ... of the kernel without the table
+constexpr int kTableSlotsPerThread = 8;
+constexpr int kWalkSegment = 16;          // steps between flushes
 constexpr uint32_t kEmptyKey = 0xffffffffu;
 
+// (LDS pointers carry their address space, so that the two places a visit can go -- the table or global memory -- stay two
+// instructions, ds_add and global_atomic_add, instead of one flat atomic on a selected address)
+using LdsWord = __attribute__((address_space(3))) uint32_t;
+typedef uint32_t WordPair __attribute__((ext_vector_type(2)));
+using LdsPair = __attribute__((address_space(3))) WordPair;
+
+__device__ __forceinline__ void LdsCount(LdsWord* word, uint32_t by)
+{
+  __hip_atomic_fetch_add(word, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t LdsClaim(LdsWord* word, uint32_t expected, uint32_t desired)
+{
+  __hip_atomic_compare_exchange_strong(word, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+  return expected;  // the word's value before the exchange
+}
+
+// The table is DIRECT-MAPPED BY POSITION: the slot of voxel (x, y, z) is (x mod 2^bx, y mod 2^by, z mod 2^bz), z
+// fastest -- a window of 16 x 16 x 16 voxels for 4096 slots that the workgroup's cone moves through, a voxel that maps
+// onto a slot held by another voxel going to global memory directly.  What this buys is the ORDER of the flush: 64
+// consecutive slots are four z-rows of 16 voxels, so one wave instruction of the flush touches a handful of 128-byte
+// lines of the tracking grid (a hashed table's flush touches 64; tools/sim/raycast_table_sim.c counts 5.3 M line
+// transactions per 1 M-point cloud against 18.7 M, and the L2 retires scattered atomics by the line).
 struct VisitTable
 {
-  uint32_t* keys;
-  uint32_t* counts;
-  int slots;   // power of two
-  int shift;   // 32 - log2(slots)
+  LdsWord* keys;
+  LdsWord* counts;
+  int slots;            // power of two
+  uint32_t mask[3];     // the slot index's field of each axis
+  __device__ __forceinline__ VisitTable(uint32_t* words, int table_slots)
+      : keys((LdsWord*)words), counts((LdsWord*)words + table_slots), slots(table_slots)
+  {
+    const int bits = 31 - __clz(table_slots);
+    const int bx = bits / 3, by = (bits + 1) / 3, bz = (bits + 2) / 3;
+    mask[0] = ((1u << bx) - 1u) << (by + bz);
+    mask[1] = ((1u << by) - 1u) << bz;
+    mask[2] = (1u << bz) - 1u;
+  }
+  __device__ __forceinline__ uint32_t Slot(const int32_t idx[3]) const
+  {
+    const uint32_t unit0 = mask[0] & (0u - mask[0]), unit1 = mask[1] & (0u - mask[1]);
+    return ((static_cast<uint32_t>(idx[0]) * unit0) & mask[0]) | ((static_cast<uint32_t>(idx[1]) * unit1) & mask[1]) |
+           (static_cast<uint32_t>(idx[2]) & mask[2]);
+  }
+  // what a step of `direction` (+1 / -1) along `axis` adds to the slot index, inside the axis' field: one unit, or the
+  // whole field (= -1 modulo the field's size)
+  __device__ __forceinline__ uint32_t SlotStep(int axis, int32_t direction) const
+  {
+    return direction > 0 ? (mask[axis] & (0u - mask[axis])) : mask[axis];
+  }
   __device__ __forceinline__ void Clear()
   {
     for (int s = threadIdx.x; s < slots; s += blockDim.x)
@@ -114,23 +165,63 @@ struct VisitTable
       counts[s] = 0u;
     }
   }
-  // seen-free visit of `cell` (cell < 2^32 - 1)
-  __device__ __forceinline__ void Add(uint32_t cell, int32_t* __restrict__ tracking)
+  // A seen-free visit of `cell` (cell < 2^32 - 1) is recorded in two halves with a step of the walk between them, so
+  // that the wave never waits for the LDS: Lookup() asks for the key of the cell's slot and sends off the claim a lane
+  // still owes from its PREVIOUS visit; Record(), a DDA step later, counts the visit if the slot holds the cell, or -- a
+  // first visit -- remembers the empty slot as the lane's owed claim, or -- the slot is another cell's -- sends the
+  // visit to global memory.  A claim is a compare-and-swap (empty -> cell) whose answer settles it: the slot now
+  // holds the cell (count it there) or another lane's cell won the slot (global).
+  struct Owed
   {
-    uint32_t slot = (cell * 2654435761u) >> shift;
-#pragma unroll 1
-    for (int probe = 0; probe < kTableProbes; probe++)
+    uint32_t cell;
+    uint32_t slot;  // kNoSlot: nothing owed
+  };
+  static constexpr uint32_t kNoSlot = 0xffffffffu;
+  struct Pending
+  {
+    uint32_t key;      // the slot's key as read
+    uint32_t claimed;  // answer of the owed claim
+  };
+  __device__ __forceinline__ Pending Lookup(uint32_t slot, const Owed& owed) const
+  {
+    Pending p;
+    p.key = keys[slot];
+    p.claimed = 0u;
+    if (owed.slot != kNoSlot) p.claimed = LdsClaim(keys + owed.slot, kEmptyKey, owed.cell);
+    return p;
+  }
+  __device__ __forceinline__ void Settle(Owed& owed, uint32_t claimed, int32_t* __restrict__ tracking)
+  {
+    if (owed.slot != kNoSlot)
     {
-      uint32_t key = keys[slot];
-      if (key == kEmptyKey) key = atomicCAS(&keys[slot], kEmptyKey, cell);
-      if (key == cell || key == kEmptyKey)
-      {
-        atomicAdd(&counts[slot], 1u);
-        return;
-      }
-      slot = (slot + 1u) & static_cast<uint32_t>(slots - 1);
+      const bool mine = claimed == kEmptyKey || claimed == owed.cell;
+      if (mine) LdsCount(counts + owed.slot, 1u);
+      if (!mine) atomicAdd(&tracking[static_cast<int64_t>(owed.cell) * 2], 1);
+      owed.slot = kNoSlot;
     }
-    atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
+  }
+  __device__ __forceinline__ void Record(uint32_t cell, uint32_t slot, const Pending& p, Owed& owed,
+                                         int32_t* __restrict__ tracking)
+  {
+    Settle(owed, p.claimed, tracking);
+    if (p.key == cell)
+      LdsCount(counts + slot, 1u);
+    else if (p.key == kEmptyKey)
+    {
+      owed.cell = cell;
+      owed.slot = slot;
+    }
+    else
+      atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
+  }
+  // before a flush: the claim still owed is made and settled on the spot
+  __device__ __forceinline__ void SettleNow(Owed& owed, int32_t* __restrict__ tracking)
+  {
+    if (owed.slot != kNoSlot)
+    {
+      const uint32_t claimed = LdsClaim(keys + owed.slot, kEmptyKey, owed.cell);
+      Settle(owed, claimed, tracking);
+    }
   }
   __device__ __forceinline__ void Flush(int32_t* __restrict__ tracking)
   {
@@ -288,16 +379,33 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
                               int32_t* __restrict__ tracking, int table_slots)
 {
   extern __shared__ uint32_t table_words[];  // kTable: 2 * table_slots words
-  VisitTable table{table_words, table_words + table_slots, table_slots, 32 - (31 - __clz(table_slots))};
+  VisitTable table(table_words, table_slots);
   if constexpr (kTable) table.Clear();
 
-  const int64_t slot = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  bool walking = slot < num_points;
-  int32_t cur[3] = {0, 0, 0}, end[3] = {0, 0, 0}, step[3] = {0, 0, 0};
-  Real t[3] = {Real(0), Real(0), Real(0)}, dt[3] = {Real(0), Real(0), Real(0)};
+  // Walk state.  The reference walks (cur, end, step) and tests cur against end and the grid every step
+  // (cuda_voxelization_helpers.cu:283-352); the same walk is kept here as counters, so that a step is a handful of
+  // selects instead of three-way branches and a 64-bit index computation:
+  //   cell     linear index of cur, moved by delta[a] = step[a] * stride[a]
+  //   lim[a]   steps axis a may still take: min(|end[a] - cur[a]|, steps to the grid's face).  Choosing an axis whose
+  //            lim is 0 ends the walk: either cur[a] == end[a] (the reference's break) or the step leaves the grid
+  //            (the reference steps, fails InGrid at the top of the next iteration and visits nothing more)
+  //   total    sum over axes of |end[a] - cur[a]|: 0 <=> cur == end (the reference's test before every visit)
+  // The first voxel is tested against the grid once; after that only the stepped axis can leave it.
+  using Index = std::conditional_t<kTable, uint32_t, uint64_t>;  // kTable: num_cells < 2^32 - 1
+  // With the table, wave w of the workgroup takes rays w, w + waves, w + 2 waves ... of the workgroup's share of the
+  // direction-sorted cloud: the same cone per workgroup, but a wave's lanes are spread over all of it, so that fewer of
+  // them stand in the same voxel at the same step (the LDS serves lanes on one address one after the other).
+  const unsigned waves = blockDim.x / 64u;
+  const int64_t ray_slot = static_cast<int64_t>(blockIdx.x) * blockDim.x +
+                           (kTable ? (threadIdx.x % 64u) * waves + threadIdx.x / 64u : threadIdx.x);
+  bool walking = ray_slot < num_points;
+  Index cell = 0, total = 0, delta0 = 0, delta1 = 0, delta2 = 0;
+  uint32_t lim0 = 0, lim1 = 0, lim2 = 0;
+  uint32_t slot = 0, slot_step0 = 0, slot_step1 = 0, slot_step2 = 0;  // kTable: the cell's place in the table
+  Real t0 = Real(0), t1 = Real(0), t2 = Real(0), dt0 = Real(0), dt1 = Real(0), dt2 = Real(0);
   if (walking)
   {
-    const int64_t i = order ? static_cast<int64_t>(order[slot]) : slot;
+    const int64_t i = order ? static_cast<int64_t>(order[ray_slot]) : ray_slot;
     const Real px = points[point_stride * i + 0];
     const Real py = points[point_stride * i + 1];
     const Real pz = points[point_stride * i + 2];
@@ -358,25 +466,59 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
       if (walking)
       {
         const Real half = g.voxel_size * Real(0.5);
+        int32_t cur[3], end[3];
+        Real t[3], dt[3];
+        uint32_t lim[3];
+        int64_t move[3];
+        uint64_t remaining = 0;
+        const int64_t stride[3] = {static_cast<int64_t>(g.counts[1]) * g.counts[2], g.counts[2], 1};
         for (int a = 0; a < 3; a++)
         {
           cur[a] = static_cast<int32_t>(floor(first[a] * g.inverse_voxel_size));
           end[a] = static_cast<int32_t>(floor(last[a] * g.inverse_voxel_size));
-          const int32_t diff = end[a] - cur[a];
-          step[a] = (diff > 0) - (diff < 0);
+          const int64_t diff = static_cast<int64_t>(end[a]) - cur[a];
+          const int32_t step = (diff > 0) - (diff < 0);
           const Real centre = (static_cast<Real>(cur[a]) + Real(0.5)) * g.voxel_size;
           t[a] = AxisT<Real>(first[a], ray[a], centre - half, centre + half);
           dt[a] = fabs(g.voxel_size / ray[a]);
+          const uint64_t apart = static_cast<uint64_t>(diff < 0 ? -diff : diff);  // < 2^32
+          remaining += apart;
+          // (meaningful only when cur is inside the grid, which is tested below)
+          const uint32_t room = static_cast<uint32_t>(step > 0 ? g.counts[a] - 1 - cur[a] : cur[a]);
+          lim[a] = static_cast<uint32_t>(apart < room ? apart : room);
+          move[a] = step * stride[a];
         }
         // the end voxel is recorded first: seen-free if the ray was clipped, seen-filled otherwise
         if (InGrid(end, g.counts))
           atomicAdd(&tracking[CellIndex(end, g.counts) * 2 + (clipped ? 0 : 1)], 1);
+        walking = remaining != 0 && InGrid(cur, g.counts);
+        if (walking)
+        {
+          // (a walk inside the grid takes fewer steps than the grid has cells, so clamping `total` changes nothing)
+          const uint64_t most = static_cast<uint64_t>(~Index(0));
+          total = static_cast<Index>(remaining < most ? remaining : most);
+          cell = static_cast<Index>(CellIndex(cur, g.counts));
+          delta0 = static_cast<Index>(move[0]);  // two's complement: cell + delta wraps to the right index
+          delta1 = static_cast<Index>(move[1]);
+          delta2 = static_cast<Index>(move[2]);
+          lim0 = lim[0], lim1 = lim[1], lim2 = lim[2];
+          if constexpr (kTable)
+          {
+            slot = table.Slot(cur);
+            slot_step0 = table.SlotStep(0, static_cast<int32_t>(move[0] > 0) - static_cast<int32_t>(move[0] < 0));
+            slot_step1 = table.SlotStep(1, static_cast<int32_t>(move[1] > 0) - static_cast<int32_t>(move[1] < 0));
+            slot_step2 = table.SlotStep(2, static_cast<int32_t>(move[2] > 0) - static_cast<int32_t>(move[2] < 0));
+          }
+          t0 = t[0], t1 = t[1], t2 = t[2];
+          dt0 = dt[0], dt1 = dt[1], dt2 = dt[2];
+        }
       }
     }
   }
 
   // The walk, in segments of kWalkSegment steps; with the table, the workgroup flushes it between segments.
   int walked = 0;
+  VisitTable::Owed owed{0u, VisitTable::kNoSlot};
   for (;;)
   {
     if constexpr (kTable)
@@ -389,58 +531,54 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
     {
       for (int s = 0; s < kWalkSegment; s++, walked++)
       {
-        if ((cur[0] == end[0] && cur[1] == end[1] && cur[2] == end[2]) || !InGrid(cur, g.counts))
+        const Index here = cell;
+        const uint32_t here_slot = slot;
+        VisitTable::Pending lookup{};
+        if constexpr (kTable)
+        {
+          lookup = table.Lookup(here_slot, owed);
+          __builtin_amdgcn_sched_barrier(0);  // the step below is what the wave does while the LDS answers
+        }
+        else if (walked < kAggregatedSteps)  // `walked` is the same for every lane still in the loop
+          AggregatedIncrement(tracking, static_cast<int64_t>(cell) * 2);
+        else
+          atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
+        // the axis whose boundary comes first (cuda_voxelization_helpers.cu:300-352: X if t.x is the least or tied
+        // least, else Y if t.y is, else Z)
+        const bool ax = (t0 <= t1) & (t0 <= t2);
+        const bool ay = !ax & (t1 <= t0) & (t1 <= t2);
+        const bool az = !(ax | ay);
+        const uint32_t lim = ax ? lim0 : (ay ? lim1 : lim2);
+        lim0 -= ax ? 1u : 0u;
+        lim1 -= ay ? 1u : 0u;
+        lim2 -= az ? 1u : 0u;
+        t0 = ax ? t0 + dt0 : t0;
+        t1 = ay ? t1 + dt1 : t1;
+        t2 = az ? t2 + dt2 : t2;
+        cell += ax ? delta0 : (ay ? delta1 : delta2);
+        total -= 1;
+        bool stop = lim == 0u || total == 0;
+        if constexpr (kTable)
+        {
+          const uint32_t field = ax ? table.mask[0] : (ay ? table.mask[1] : table.mask[2]);
+          const uint32_t moved = slot + (ax ? slot_step0 : (ay ? slot_step1 : slot_step2));
+          slot = (moved & field) | (slot & ~field);
+          // (the step's results are pinned here, or the compiler sinks the step below the LDS answers it should cover)
+          uint32_t lim_here = lim;
+          asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(lim0), "+v"(lim1), "+v"(lim2), "+v"(cell), "+v"(total),
+                       "+v"(lim_here), "+v"(slot)::"memory");
+          stop = lim_here == 0u || total == 0;
+          __builtin_amdgcn_sched_barrier(0);
+          table.Record(static_cast<uint32_t>(here), here_slot, lookup, owed, tracking);
+        }
+        if (stop)
         {
           walking = false;
           break;
         }
-        const int64_t cell = CellIndex(cur, g.counts);
-        if constexpr (kTable)
-          table.Add(static_cast<uint32_t>(cell), tracking);
-        else if (walked < kAggregatedSteps)  // `walked` is the same for every lane still in the loop
-          AggregatedIncrement(tracking, cell * 2);
-        else
-          atomicAdd(&tracking[cell * 2], 1);
-        int a;
-        if (t[0] <= t[1] && t[0] <= t[2])
-          a = 0;
-        else if (t[1] <= t[0] && t[1] <= t[2])
-          a = 1;
-        else
-          a = 2;
-        // select without dynamically indexing the register arrays
-        if (a == 0)
-        {
-          if (cur[0] == end[0])
-          {
-            walking = false;
-            break;
-          }
-          cur[0] += step[0];
-          t[0] += dt[0];
-        }
-        else if (a == 1)
-        {
-          if (cur[1] == end[1])
-          {
-            walking = false;
-            break;
-          }
-          cur[1] += step[1];
-          t[1] += dt[1];
-        }
-        else
-        {
-          if (cur[2] == end[2])
-          {
-            walking = false;
-            break;
-          }
-          cur[2] += step[2];
-          t[2] += dt[2];
-        }
       }
     }
+    if constexpr (kTable) table.SettleNow(owed, tracking);
     if constexpr (kTable)
     {
       __syncthreads();
@@ -506,7 +644,9 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
                          int threads_per_block, void* scratch_dev, size_t scratch_bytes, hipStream_t stream)
 {
   if (num_points <= 0) return hipSuccess;
-  const int64_t blocks = (num_points + threads_per_block - 1) / threads_per_block;
+  // threads_per_block <= 0: the caller leaves the workgroup size to the kernels (HIP_THREADS_PER_BLOCK not given)
+  const int table_threads = threads_per_block > 0 ? threads_per_block : kTableThreads;
+  const int plain_threads = threads_per_block > 0 ? threads_per_block : kPlainThreads;
   const int64_t num_cells = static_cast<int64_t>(g.counts[0]) * g.counts[1] * g.counts[2];
   const size_t need = RaycastScratchBytes(num_points);
   // Large clouds: order by direction and count visits per workgroup in LDS.  Needs the scratch, 32-bit
@@ -515,7 +655,7 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   // refusal, e.g. a large HIP_THREADS_PER_BLOCK, falls back to the plain kernel below instead of failing the call)
   constexpr size_t kScatterLds = static_cast<size_t>(kSortBins) * sizeof(uint32_t);
   int table_slots = 1024;
-  while (table_slots < kTableSlotsPerThread * threads_per_block) table_slots <<= 1;
+  while (table_slots < kTableSlotsPerThread * table_threads) table_slots <<= 1;
   const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
   bool sorted_path = need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL &&
                      num_cells < 0xffffffffLL;
@@ -545,11 +685,13 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
                        bin_total);
     hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(256), kScatterLds, stream, bins, num_points, table,
                        num_chunks, bin_total, order);
-    hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block),
+    const int64_t blocks = (num_points + table_threads - 1) / table_threads;
+    hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(table_threads),
                        table_lds, stream, points_dev, num_points, point_stride, order, g, tracking_dev, table_slots);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((RaycastKernel<Real, false>), dim3(static_cast<unsigned>(blocks)), dim3(threads_per_block), 0,
+  const int64_t blocks = (num_points + plain_threads - 1) / plain_threads;
+  hipLaunchKernelGGL((RaycastKernel<Real, false>), dim3(static_cast<unsigned>(blocks)), dim3(plain_threads), 0,
                      stream, points_dev, num_points, point_stride, static_cast<const uint32_t*>(nullptr), g,
                      tracking_dev, 0);
   return hipGetLastError();
