@@ -10,7 +10,7 @@ import sys
 def main(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    names = ("RaycastKernel", "DirectionBinKernel", "BinOffsetsKernel", "ScatterOrderKernel")
+    names = ("RaycastKernel", "DirectionBinKernel", "ScatterOrderKernel", "fillBuffer")
     per = {n: [] for n in names}
     for r in rows:
         for n in names:

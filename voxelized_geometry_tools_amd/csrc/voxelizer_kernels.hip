@@ -239,15 +239,17 @@ struct VisitTable
 };
 
 // ---- ordering of a cloud by ray direction (counting sort, see the header) ----
-// Bins: 6 cube-map faces x 64 x 64 cells, Morton order inside a face (a workgroup's 256 consecutive rays then
-// span a compact patch of neighbouring cells).  The sort keeps every atomic in LDS: each workgroup counts a chunk of
-// kSortChunk rays per bin in an LDS histogram and publishes it as column `workgroup` of a [bin][workgroup]
-// table; a prefix over each bin's row gives the workgroup's offset inside the bin and the bin's total; the
-// workgroups then scan the 24576 bin totals in LDS and place their rays with LDS atomics on those bases.
-constexpr int kFaceBits = 6;
-constexpr int kSortBins = 6 << (2 * kFaceBits);               // 24576
-constexpr int kSortChunk = 16384;                             // rays per workgroup of the counting / placing kernels
-constexpr int64_t kSortMinPoints = 32768;                     // smaller clouds: three extra launches cost more than they save
+// Bins: 6 cube-map faces x 32 x 32 cells, Morton order inside a face (a workgroup's consecutive rays then span a compact
+// patch of neighbouring cells).  Two kernels over chunks of kSortChunk rays: the first bins the rays, counts its chunk per
+// bin in LDS and adds the counts to the bins' totals; the second scans the totals (every workgroup for itself, in LDS),
+// takes its chunk's share of every bin with one atomic on the bin's cursor, and places its rays with LDS atomics.  The
+// order of rays inside a bin is whatever the atomics make it: it decides which rays share a workgroup, never a count.
+constexpr int kFaceBits = 5;
+constexpr int kSortBins = 6 << (2 * kFaceBits);               // 6144
+constexpr int kSortChunk = 4096;                              // rays per workgroup of the two kernels
+constexpr int kSortThreads = 256;
+constexpr int64_t kSortMinPoints = 32768;                     // smaller clouds: the extra launches cost more than they save
+static_assert(kSortBins % kSortThreads == 0 && kSortBins < 65536 && kSortChunk < 65536, "16-bit bins and counts");
 __device__ __forceinline__ uint32_t SpreadBits(uint32_t x)    // 0b..cba -> 0b..0c0b0a
 {
   x &= 0xffffu;
@@ -291,64 +293,84 @@ __device__ __forceinline__ uint32_t DirectionBin(const Real* __restrict__ points
   return (face << (2 * kFaceBits)) | SpreadBits(static_cast<uint32_t>(iu)) | (SpreadBits(static_cast<uint32_t>(iv)) << 1);
 }
 
-template <typename Real>
-__global__ __launch_bounds__(256) void DirectionBinKernel(const Real* __restrict__ points, int64_t num_points,
-                                                         int64_t point_stride,
-                                                         const typename RaycastTraits<Real>::Grid g,
-                                                         uint16_t* __restrict__ bins, uint32_t* __restrict__ table,
-                                                         int num_chunks)
+// (two 16-bit counters per word: a chunk holds kSortChunk rays, so a counter cannot overflow)
+__device__ __forceinline__ void CountBin(uint32_t* histogram, uint32_t bin)
 {
-  // two 16-bit counters per word (a chunk holds kSortChunk = 16384 rays, so a counter cannot overflow)
+  atomicAdd(&histogram[bin >> 1], 1u << ((bin & 1u) * 16u));
+}
+__device__ __forceinline__ uint32_t BinCount(const uint32_t* histogram, int bin)
+{
+  return (histogram[bin >> 1] >> ((bin & 1) * 16)) & 0xffffu;
+}
+
+// bin_total must be zero on entry.
+template <typename Real>
+__global__ __launch_bounds__(kSortThreads) void DirectionBinKernel(const Real* __restrict__ points, int64_t num_points,
+                                                                  int64_t point_stride,
+                                                                  const typename RaycastTraits<Real>::Grid g,
+                                                                  uint16_t* __restrict__ bins,
+                                                                  uint32_t* __restrict__ bin_total)
+{
   __shared__ uint32_t histogram[kSortBins / 2];
-  for (int b = threadIdx.x; b < kSortBins / 2; b += blockDim.x) histogram[b] = 0u;
+  for (int b = threadIdx.x; b < kSortBins / 2; b += kSortThreads) histogram[b] = 0u;
   __syncthreads();
   const int64_t first = static_cast<int64_t>(blockIdx.x) * kSortChunk;
   const int64_t last = min(first + kSortChunk, num_points);
-  for (int64_t i = first + threadIdx.x; i < last; i += blockDim.x)
+  // (constant trip counts, so that the loads of several rays are in flight together)
+#pragma unroll 4
+  for (int k = 0; k < kSortChunk / kSortThreads; k++)
   {
-    const uint32_t bin = DirectionBin<Real>(points, point_stride, i, g.xform);
-    bins[i] = static_cast<uint16_t>(bin);
-    atomicAdd(&histogram[bin >> 1], 1u << ((bin & 1u) * 16u));
+    const int64_t i = first + k * kSortThreads + threadIdx.x;
+    if (i < last)
+    {
+      const uint32_t bin = DirectionBin<Real>(points, point_stride, i, g.xform);
+      bins[i] = static_cast<uint16_t>(bin);
+      CountBin(histogram, bin);
+    }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < kSortBins; b += blockDim.x)
-    table[static_cast<int64_t>(b) * num_chunks + blockIdx.x] = (histogram[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
-}
-
-// table[bin][chunk] counts -> exclusive prefix over the chunks of each bin, in place, and the bin's total.
-__global__ __launch_bounds__(256) void BinOffsetsKernel(uint32_t* __restrict__ table, int num_chunks,
-                                                       uint32_t* __restrict__ bin_total)
-{
-  const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bin >= kSortBins) return;
-  uint32_t* row = table + static_cast<int64_t>(bin) * num_chunks;
-  uint32_t running = 0;
-  for (int c = 0; c < num_chunks; c++)
+#pragma unroll
+  for (int k = 0; k < kSortBins / kSortThreads; k++)
   {
-    const uint32_t count = row[c];
-    row[c] = running;
-    running += count;
+    const int b = k * kSortThreads + threadIdx.x;
+    const uint32_t count = BinCount(histogram, b);
+    if (count) atomicAdd(&bin_total[b], count);
   }
-  bin_total[bin] = running;
 }
 
-__global__ __launch_bounds__(256) void ScatterOrderKernel(const uint16_t* __restrict__ bins, int64_t num_points,
-                                                         const uint32_t* __restrict__ table, int num_chunks,
-                                                         const uint32_t* __restrict__ bin_total,
-                                                         uint32_t* __restrict__ order)
+// cursor must be zero on entry; bin_total complete.
+__global__ __launch_bounds__(kSortThreads) void ScatterOrderKernel(const uint16_t* __restrict__ bins, int64_t num_points,
+                                                                  const uint32_t* __restrict__ bin_total,
+                                                                  uint32_t* __restrict__ cursor,
+                                                                  uint32_t* __restrict__ order)
 {
-  extern __shared__ uint32_t next[];  // kSortBins words (dynamic: 96 KiB)
-  __shared__ uint32_t partial[256];
-  // first output position of every bin: exclusive scan of the bin totals (every workgroup recomputes it),
-  // plus this chunk's offset inside the bin
-  constexpr int kPerThread = kSortBins / 256;  // 96
-  static_assert(kSortBins % 256 == 0, "bins per thread");
+  __shared__ uint32_t next[kSortBins];           // the bins' totals, then their first positions, then this chunk's
+  __shared__ uint32_t histogram[kSortBins / 2];  // this chunk's count per bin
+  __shared__ uint32_t partial[kSortThreads];
+  constexpr int kPerThread = kSortBins / kSortThreads;  // 24
+  for (int b = threadIdx.x; b < kSortBins; b += kSortThreads) next[b] = bin_total[b];
+  for (int b = threadIdx.x; b < kSortBins / 2; b += kSortThreads) histogram[b] = 0u;
+  __syncthreads();
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kSortChunk;
+  const int64_t last = min(first + kSortChunk, num_points);
+  constexpr int kRaysPerThread = kSortChunk / kSortThreads;  // 16
+  uint32_t my_bin[kRaysPerThread];
+#pragma unroll
+  for (int k = 0; k < kRaysPerThread; k++)
+  {
+    const int64_t i = first + k * kSortThreads + threadIdx.x;
+    my_bin[k] = i < last ? bins[i] : 0xffffffffu;
+  }
+#pragma unroll
+  for (int k = 0; k < kRaysPerThread; k++)
+    if (my_bin[k] != 0xffffffffu) CountBin(histogram, my_bin[k]);
+  // exclusive scan of the totals: a thread's run of bins, then the runs' sums across the workgroup
   const int first_bin = threadIdx.x * kPerThread;
   uint32_t sum = 0;
-  for (int k = 0; k < kPerThread; k++) sum += bin_total[first_bin + k];
+  for (int k = 0; k < kPerThread; k++) sum += next[first_bin + k];
   partial[threadIdx.x] = sum;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1)
+  for (int d = 1; d < kSortThreads; d <<= 1)
   {
     const uint32_t add = (threadIdx.x >= static_cast<unsigned>(d)) ? partial[threadIdx.x - d] : 0u;
     __syncthreads();
@@ -358,15 +380,28 @@ __global__ __launch_bounds__(256) void ScatterOrderKernel(const uint16_t* __rest
   uint32_t running = partial[threadIdx.x] - sum;
   for (int k = 0; k < kPerThread; k++)
   {
-    const int b = first_bin + k;
-    next[b] = running + table[static_cast<int64_t>(b) * num_chunks + blockIdx.x];
-    running += bin_total[b];
+    const uint32_t total = next[first_bin + k];
+    next[first_bin + k] = running;
+    running += total;
   }
   __syncthreads();
-  const int64_t first = static_cast<int64_t>(blockIdx.x) * kSortChunk;
-  const int64_t last = min(first + kSortChunk, num_points);
-  for (int64_t i = first + threadIdx.x; i < last; i += blockDim.x)
-    order[atomicAdd(&next[bins[i]], 1u)] = static_cast<uint32_t>(i);
+  // this chunk's place inside every bin it has rays in
+  // (all of a thread's atomics are sent before the first answer is used)
+  uint32_t before[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; k++)
+  {
+    const int b = k * kSortThreads + threadIdx.x;
+    const uint32_t count = BinCount(histogram, b);
+    before[k] = count ? atomicAdd(&cursor[b], count) : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < kPerThread; k++) next[k * kSortThreads + threadIdx.x] += before[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kRaysPerThread; k++)
+    if (my_bin[k] != 0xffffffffu)
+      order[atomicAdd(&next[my_bin[k]], 1u)] = static_cast<uint32_t>(first + k * kSortThreads + threadIdx.x);
 }
 
 // kTable: seen-free visits go through the workgroup's LDS table (needs num_cells < 2^32 - 1); `order`
@@ -625,14 +660,12 @@ __global__ void FilterKernel(const int32_t* __restrict__ tracking, int64_t num_c
 }
 }  // namespace
 
-// Device scratch for one raycast call of `num_points` points: bin histogram + per-point bins + the
-// direction-sorted permutation.
+// Device scratch for one raycast call of `num_points` points: the bins' totals and cursors, the direction-sorted
+// permutation, the per-point bins.
 size_t RaycastScratchBytes(int64_t num_points)
 {
   if (num_points < kSortMinPoints) return 0;
-  const size_t chunks = static_cast<size_t>((num_points + kSortChunk - 1) / kSortChunk);
-  // [bin][chunk] table + permutation (uint32 each) + per-point bins (uint16), 256-byte aligned pieces
-  return (static_cast<size_t>(kSortBins) * (chunks + 1) + static_cast<size_t>(num_points)) * sizeof(uint32_t) +
+  return (2 * static_cast<size_t>(kSortBins) + static_cast<size_t>(num_points) + 64) * sizeof(uint32_t) +
          static_cast<size_t>(num_points) * sizeof(uint16_t) + 1024;
 }
 
@@ -651,9 +684,8 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   const size_t need = RaycastScratchBytes(num_points);
   // Large clouds: order by direction and count visits per workgroup in LDS.  Needs the scratch, 32-bit
   // point and cell indices.
-  // (the LDS the two kernels of that path ask for must be granted -- checked BEFORE anything is launched, so that a
-  // refusal, e.g. a large HIP_THREADS_PER_BLOCK, falls back to the plain kernel below instead of failing the call)
-  constexpr size_t kScatterLds = static_cast<size_t>(kSortBins) * sizeof(uint32_t);
+  // (the LDS the table kernel asks for must be granted -- checked BEFORE anything is launched, so that a refusal, e.g. a
+  // large HIP_THREADS_PER_BLOCK, falls back to the plain kernel below instead of failing the call)
   int table_slots = 1024;
   while (table_slots < kTableSlotsPerThread * table_threads) table_slots <<= 1;
   const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
@@ -661,11 +693,9 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
                      num_cells < 0xffffffffLL;
   if (sorted_path)
   {
-    const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(ScatterOrderKernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kScatterLds));
-    const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
-    if (a != hipSuccess || b != hipSuccess)
+    const hipError_t granted = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
+    if (granted != hipSuccess)
     {
       (void)hipGetLastError();
       sorted_path = false;
@@ -674,17 +704,16 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   if (sorted_path)
   {
     const int num_chunks = static_cast<int>((num_points + kSortChunk - 1) / kSortChunk);
-    const int64_t entries = static_cast<int64_t>(kSortBins) * num_chunks;
-    uint32_t* table = static_cast<uint32_t*>(scratch_dev);
-    uint32_t* bin_total = table + ((entries + 63) / 64 * 64);
-    uint32_t* order = bin_total + kSortBins;
+    uint32_t* bin_total = static_cast<uint32_t*>(scratch_dev);
+    uint32_t* cursor = bin_total + kSortBins;
+    uint32_t* order = cursor + kSortBins;
     uint16_t* bins = reinterpret_cast<uint16_t*>(order + ((num_points + 63) / 64 * 64));
-    hipLaunchKernelGGL(DirectionBinKernel<Real>, dim3(num_chunks), dim3(256), 0, stream, points_dev, num_points,
-                       point_stride, g, bins, table, num_chunks);
-    hipLaunchKernelGGL(BinOffsetsKernel, dim3((kSortBins + 255) / 256), dim3(256), 0, stream, table, num_chunks,
-                       bin_total);
-    hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(256), kScatterLds, stream, bins, num_points, table,
-                       num_chunks, bin_total, order);
+    const hipError_t zeroed = hipMemsetAsync(bin_total, 0, 2 * static_cast<size_t>(kSortBins) * sizeof(uint32_t), stream);
+    if (zeroed != hipSuccess) return zeroed;
+    hipLaunchKernelGGL(DirectionBinKernel<Real>, dim3(num_chunks), dim3(kSortThreads), 0, stream, points_dev, num_points,
+                       point_stride, g, bins, bin_total);
+    hipLaunchKernelGGL(ScatterOrderKernel, dim3(num_chunks), dim3(kSortThreads), 0, stream, bins, num_points, bin_total,
+                       cursor, order);
     const int64_t blocks = (num_points + table_threads - 1) / table_threads;
     hipLaunchKernelGGL((RaycastKernel<Real, true>), dim3(static_cast<unsigned>(blocks)), dim3(table_threads),
                        table_lds, stream, points_dev, num_points, point_stride, order, g, tracking_dev, table_slots);
