@@ -444,3 +444,108 @@ def test_context_destroyed_before_its_handles():
     g2 = c2.tracking_grids(64, 1)
     c2.close()
     assert g2.handle is None
+
+
+def _rotation_xform(rng, translation):
+    """Column-major rigid transform with a random rotation (the grid frame tilted against the cloud's)."""
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    m = np.eye(4)
+    m[:3, :3] = q
+    m[:3, 3] = translation
+    return m.T.reshape(16).copy()
+
+
+@pytest.mark.parametrize("threads", [64, 128, 192, 256, 512, 1024])
+def test_table_kernel_at_every_workgroup_size(oracle, threads):
+    """HIP_THREADS_PER_BLOCK given: the table kernel runs at that size (its table, the re-deal of rays by walk length
+    and the flush all scale with it); 192 is not a power of two."""
+    c = capi.Context(0, threads)
+    counts = (100, 37, 250)     # no side a multiple of the table's 16-voxel window
+    vs = np.float32(0.03)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(n) * vs for n in counts]
+    pts = synthetic.raycast_cloud(90_000, seed=threads)
+    xf = synthetic.translation_xform(1.4, 0.5, 3.1).astype(np.float32)
+    grids = c.tracking_grids(int(np.prod(counts)), 1)
+    grids.raycast_f32(0, pts, 2.5, xf, vs, ivs, sizes, counts)
+    want = oracle.raycast_f32(pts, 2.5, xf, vs, ivs, sizes, counts)
+    assert np.array_equal(grids.retrieve(0, counts), want)
+    grids.close()
+    c.close()
+
+
+@pytest.mark.parametrize("case", ["rotated_inside", "rotated_outside", "far_sensor", "axis_aligned", "short_rays",
+                                  "flat_grid", "line_grid", "f64_rotated"])
+def test_walk_and_table_on_awkward_geometry(ctx, oracle, case):
+    """The counter form of the walk (steps left per axis, steps to the grid's face) and the position-mapped table on
+    geometry that exercises their edges: tilted frames, a sensor far outside (rays enter through a face, most miss),
+    rays along the axes (ties between the axes' boundary times, zero components), rays shorter than a voxel, grids one
+    voxel thick or one voxel wide (the table's window wraps in every step), and the double kernel (no re-deal)."""
+    rng = np.random.default_rng(11)
+    npts = 80_000
+    counts, vs, max_range = (90, 70, 110), np.float32(0.04), 3.0
+    pts = synthetic.raycast_cloud(npts, seed=3)
+    centre = [float(c) * float(vs) * 0.5 for c in counts]
+    xf = synthetic.translation_xform(*centre)
+    if case == "rotated_inside":
+        xf = _rotation_xform(rng, centre)
+    elif case in ("rotated_outside", "f64_rotated"):
+        xf = _rotation_xform(rng, [-0.7, centre[1] * 1.3, centre[2]])
+    elif case == "far_sensor":
+        xf = synthetic.translation_xform(-40.0, centre[1], centre[2])
+        pts = (pts * np.float32(14.0)).astype(np.float32)
+        max_range = 60.0
+    elif case == "axis_aligned":
+        axes = np.eye(3, dtype=np.float32)[rng.integers(0, 3, npts)] * rng.choice([-1.0, 1.0], (npts, 1)).astype(np.float32)
+        diag = rng.choice([-1.0, 0.0, 1.0], (npts, 3)).astype(np.float32)
+        pts = np.where(rng.random((npts, 1)) < 0.5, axes, diag) * rng.uniform(0.1, 4.0, (npts, 1)).astype(np.float32)
+        pts = pts.astype(np.float32)
+    elif case == "short_rays":
+        pts = (pts * np.float32(0.01)).astype(np.float32)
+    elif case == "flat_grid":
+        counts = (120, 1, 90)
+        centre = [float(c) * float(vs) * 0.5 for c in counts]
+        xf = synthetic.translation_xform(*centre)
+    elif case == "line_grid":
+        counts = (1, 1, 300)
+        centre = [float(c) * float(vs) * 0.5 for c in counts]
+        xf = synthetic.translation_xform(*centre)
+    ivs = np.float32(1.0) / vs
+    sizes = [np.float32(c) * vs for c in counts]
+    grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+    if case == "f64_rotated":
+        sizes64 = [float(c) * float(vs) for c in counts]
+        grids.raycast_f64(0, pts.astype(np.float64), max_range, xf.astype(np.float64), float(vs), 1.0 / float(vs), sizes64, counts)
+        want = oracle.raycast_f64(pts.astype(np.float64), max_range, xf.astype(np.float64), float(vs), 1.0 / float(vs), sizes64, counts)
+    else:
+        xf32 = xf.astype(np.float32)
+        grids.raycast_f32(0, pts, max_range, xf32, vs, ivs, sizes, counts)
+        want = oracle.raycast_f32(pts, max_range, xf32, vs, ivs, sizes, counts)
+    got = grids.retrieve(0, counts)
+    assert got.sum() == want.sum(), case
+    assert np.array_equal(got, want), case
+    grids.close()
+
+
+def test_random_scenes_counts_bit_exact(ctx, oracle):
+    """Twelve random scenes (grid shape, voxel size, sensor pose with rotation, range law, max range, cloud size on either
+    side of the sorted path's threshold): every tracking count against the oracle."""
+    rng = np.random.default_rng(2026)
+    for scene in range(12):
+        counts = tuple(int(v) for v in rng.integers(8, 140, 3))
+        vs = np.float32(rng.uniform(0.02, 0.09))
+        ivs = np.float32(1.0) / vs
+        sizes = [np.float32(c) * vs for c in counts]
+        npts = int(rng.choice([5_000, 40_000, 120_000]))
+        pts = synthetic.raycast_cloud(npts, seed=100 + scene)
+        pts = (pts * np.float32(rng.uniform(0.3, 2.0))).astype(np.float32)
+        where = [float(rng.uniform(-0.3, 1.3)) * float(s) for s in sizes]
+        xf = _rotation_xform(rng, where).astype(np.float32)
+        max_range = float(rng.uniform(0.5, 6.0))
+        grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+        grids.raycast_f32(0, pts, max_range, xf, vs, ivs, sizes, counts)
+        want = oracle.raycast_f32(pts, max_range, xf, vs, ivs, sizes, counts)
+        assert np.array_equal(grids.retrieve(0, counts), want), (scene, counts, npts)
+        grids.close()

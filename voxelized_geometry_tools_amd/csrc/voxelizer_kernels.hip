@@ -238,6 +238,53 @@ struct VisitTable
   }
 };
 
+// ---- rays of a workgroup dealt to its waves by the length of their walk ----
+// A wave runs until its longest ray is done, so a wave of mixed rays idles a third of its lanes (config 3: ranges
+// uniform in [0.5, 4] m, 155 steps on average, 250 for the longest of 64).  Before the walk the workgroup therefore
+// sorts its rays by the expected number of steps (a counting sort in LDS over kLengthBuckets buckets) and hands them
+// out in that order: wave 0 the shortest 64, the last wave the longest.  The rays' walk state changes lanes through
+// the LDS the table uses afterwards: 16 words per ray, which the table's 2 x 8 words per thread provide.  A wave's lanes
+// are then rays of like length from all over the workgroup's cone, which also keeps them off each other's LDS
+// addresses (see the header).
+constexpr int kLengthBuckets = 256;
+typedef uint32_t Word4 __attribute__((ext_vector_type(4)));
+using LdsWord4 = __attribute__((address_space(3))) Word4;
+
+// -> this thread's rank among the workgroup's threads by `bucket` (ties in arrival order).  `histogram` and `start`:
+// kLengthBuckets words each.
+__device__ __forceinline__ uint32_t RankInWorkgroup(uint32_t bucket, uint32_t* histogram, uint32_t* start)
+{
+  for (int b = threadIdx.x; b < kLengthBuckets; b += blockDim.x) histogram[b] = 0u;
+  __syncthreads();
+  const uint32_t arrival = atomicAdd(&histogram[bucket], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64u)
+  {
+    // wave 0: four buckets per lane, an exclusive scan across the lanes
+    constexpr int kPerLane = kLengthBuckets / 64;
+    uint32_t count[kPerLane], sum = 0u;
+    for (int k = 0; k < kPerLane; k++)
+    {
+      count[k] = histogram[threadIdx.x * kPerLane + k];
+      sum += count[k];
+    }
+    uint32_t inclusive = sum;
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t below = __shfl_up(inclusive, d, 64);
+      if (threadIdx.x >= static_cast<unsigned>(d)) inclusive += below;
+    }
+    uint32_t running = inclusive - sum;
+    for (int k = 0; k < kPerLane; k++)
+    {
+      start[threadIdx.x * kPerLane + k] = running;
+      running += count[k];
+    }
+  }
+  __syncthreads();
+  return start[bucket] + arrival;
+}
+
 // ---- ordering of a cloud by ray direction (counting sort, see the header) ----
 // Bins: 6 cube-map faces x 32 x 32 cells, Morton order inside a face (a workgroup's consecutive rays then span a compact
 // patch of neighbouring cells).  Two kernels over chunks of kSortChunk rays: the first bins the rays, counts its chunk per
@@ -415,7 +462,8 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
 {
   extern __shared__ uint32_t table_words[];  // kTable: 2 * table_slots words
   VisitTable table(table_words, table_slots);
-  if constexpr (kTable) table.Clear();
+  // (float rays only: a double ray's state does not fit the 16 words)
+  constexpr bool kLengthSort = kTable && std::is_same<Real, float>::value;
 
   // Walk state.  The reference walks (cur, end, step) and tests cur against end and the grid every step
   // (cuda_voxelization_helpers.cu:283-352); the same walk is kept here as counters, so that a step is a handful of
@@ -432,11 +480,12 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
   // them stand in the same voxel at the same step (the LDS serves lanes on one address one after the other).
   const unsigned waves = blockDim.x / 64u;
   const int64_t ray_slot = static_cast<int64_t>(blockIdx.x) * blockDim.x +
-                           (kTable ? (threadIdx.x % 64u) * waves + threadIdx.x / 64u : threadIdx.x);
+                           (kTable && !kLengthSort ? (threadIdx.x % 64u) * waves + threadIdx.x / 64u : threadIdx.x);
   bool walking = ray_slot < num_points;
   Index cell = 0, total = 0, delta0 = 0, delta1 = 0, delta2 = 0;
   uint32_t lim0 = 0, lim1 = 0, lim2 = 0;
   uint32_t slot = 0, slot_step0 = 0, slot_step1 = 0, slot_step2 = 0;  // kTable: the cell's place in the table
+  uint32_t expected_steps = 0;                                         // kLengthSort: the key of the re-deal
   Real t0 = Real(0), t1 = Real(0), t2 = Real(0), dt0 = Real(0), dt1 = Real(0), dt2 = Real(0);
   if (walking)
   {
@@ -546,10 +595,61 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
           }
           t0 = t[0], t1 = t[1], t2 = t[2];
           dt0 = dt[0], dt1 = dt[1], dt2 = dt[2];
+          if constexpr (kLengthSort)
+          {
+            // steps until the ray's end or the grid's face, whichever comes first: the parameter at which the walk
+            // crosses its last face inside the grid, then the crossings of every axis up to it
+            float leaves = INFINITY;
+            for (int a = 0; a < 3; a++)
+              if (move[a] != 0)
+                leaves = fminf(leaves, static_cast<float>(t[a]) +
+                                           static_cast<float>(move[a] > 0 ? g.counts[a] - 1 - cur[a] : cur[a]) *
+                                               static_cast<float>(dt[a]));
+            float steps = 0.0f;
+            for (int a = 0; a < 3; a++)
+              if (move[a] != 0)
+              {
+                const float crossings = (leaves - static_cast<float>(t[a])) / static_cast<float>(dt[a]) + 1.0f;
+                const float apart = static_cast<float>(end[a] > cur[a] ? end[a] - cur[a] : cur[a] - end[a]);
+                steps += fminf(fmaxf(crossings, 0.0f), apart);
+              }
+            expected_steps = static_cast<uint32_t>(fminf(steps, 1.0e6f)) + 1u;
+          }
         }
       }
     }
   }
+
+  if constexpr (kLengthSort)
+  {
+    __shared__ uint32_t length_histogram[kLengthBuckets], length_start[kLengthBuckets];
+    // (rays that do not walk at all: bucket 0)
+    const uint32_t bucket = walking ? min(static_cast<uint32_t>(kLengthBuckets - 1), 1u + (expected_steps >> 1)) : 0u;
+    const uint32_t rank = RankInWorkgroup(bucket, length_histogram, length_start);
+    // the walk state goes to the thread of that rank: four 128-bit words per ray, word w of all rays together
+    LdsWord4* exchange = (LdsWord4*)table_words;
+    const uint32_t directions = (static_cast<int32_t>(delta0) > 0 ? 1u : 0u) | (static_cast<int32_t>(delta1) > 0 ? 2u : 0u) |
+                                (static_cast<int32_t>(delta2) > 0 ? 4u : 0u) | (slot << 3);
+    exchange[0 * blockDim.x + rank] = Word4{static_cast<uint32_t>(cell), static_cast<uint32_t>(delta0),
+                                            static_cast<uint32_t>(delta1), static_cast<uint32_t>(delta2)};
+    exchange[1 * blockDim.x + rank] = Word4{lim0, lim1, lim2, walking ? static_cast<uint32_t>(total) : 0u};
+    exchange[2 * blockDim.x + rank] = Word4{__float_as_uint(t0), __float_as_uint(t1), __float_as_uint(t2), directions};
+    exchange[3 * blockDim.x + rank] = Word4{__float_as_uint(dt0), __float_as_uint(dt1), __float_as_uint(dt2), 0u};
+    __syncthreads();
+    const Word4 a = exchange[0 * blockDim.x + threadIdx.x], b = exchange[1 * blockDim.x + threadIdx.x];
+    const Word4 c = exchange[2 * blockDim.x + threadIdx.x], d = exchange[3 * blockDim.x + threadIdx.x];
+    __syncthreads();
+    cell = a.x, delta0 = a.y, delta1 = a.z, delta2 = a.w;
+    lim0 = b.x, lim1 = b.y, lim2 = b.z, total = b.w;
+    t0 = __uint_as_float(c.x), t1 = __uint_as_float(c.y), t2 = __uint_as_float(c.z);
+    dt0 = __uint_as_float(d.x), dt1 = __uint_as_float(d.y), dt2 = __uint_as_float(d.z);
+    slot = c.w >> 3;
+    slot_step0 = table.SlotStep(0, (c.w & 1u) ? 1 : -1);
+    slot_step1 = table.SlotStep(1, (c.w & 2u) ? 1 : -1);
+    slot_step2 = table.SlotStep(2, (c.w & 4u) ? 1 : -1);
+    walking = total != 0;
+  }
+  if constexpr (kTable) table.Clear();
 
   // The walk, in segments of kWalkSegment steps; with the table, the workgroup flushes it between segments.
   int walked = 0;
