@@ -20,15 +20,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells):
-    """The raycaster against the bound it has (atomic throughput, not streaming HBM): atomic requests that
-    reach the L2 per launch (committed rocprofv3 --pmc TCC_ATOMIC pass, profiles/raycast_atomic_current.json, reported only
-    while the kernel timed here is within 5 % of the duration it was collected at) over the chip's scattered-atomic rate
-    from the committed micro-benchmark (tools/microbench/scattered_atomics.hip), and the floor: one atomic per distinct
-    cell a cloud touches.  Counters cannot be read from inside this process."""
+def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells, points):
+    """The raycaster against its bounds.  SURVEY 8d prices the path at 12 B per point + 8 B per visit against HBM; what the
+    kernel actually sends to memory is one atomic per distinct cell a workgroup's table holds at a flush, so the second
+    yardstick is the L2's atomic rate: atomic requests per launch (committed rocprofv3 --pmc TCC_ATOMIC pass,
+    profiles/raycast_atomic_current.json, reported only for the sources it was collected on and while the call timed here
+    is within 5 % of the duration it was collected at) over the rates of the committed micro-benchmark
+    (tools/microbench/scattered_atomics.hip): uniformly random cells, and one 256-byte line per wave instruction.  The
+    table is flushed in address order, so the kernel is not held to the random rate; since round 5 it is the walk's
+    instruction issue that bounds it (profiles/r5/experiments.md, "Raycaster").  Counters cannot be read from inside
+    this process."""
+    algorithmic = 12.0 * points + 8.0 * visits
     out = {"visits": int(visits), "distinct_cells_touched": int(distinct_cells),
-           "note": "floor = one global atomic per distinct (cell, counter) touched; the workgroups' LDS tables merge visits of "
-                   "the SAME workgroup only, so cells shared by several workgroups cost one atomic each"}
+           "hbm": {"algorithmic_bytes": int(algorithmic), "achieved_GBps": round(algorithmic / (raycast_ms * 1e-3) / 1e9, 1),
+                   "peak_GBps": 8000.0, "frac": round(algorithmic / (raycast_ms * 1e-3) / 8e12, 4),
+                   "note": "SURVEY 8d: 12 B/point + 8 B/visit; the time is the whole call (direction sort + walk)"},
+           "note": "floor of the atomics = one per distinct (cell, counter) touched; the workgroups' LDS tables merge visits of "
+                   "the SAME workgroup between two flushes only"}
     path = os.path.join(ROOT, "profiles", "raycast_atomic_current.json")
     try:
         with open(path) as fh:
@@ -42,6 +50,7 @@ def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells):
         rate = float(doc["scattered_atomic_rate_G_per_s"])
         recorded_ms = float(entry["raycast_kernel_ms"])
         out["scattered_atomic_rate_G_per_s"] = rate
+        out["one_line_per_wave_atomic_rate_G_per_s"] = (doc.get("microbench") or {}).get("one_line_G_atomics_per_s")
         out["rate_source"] = doc.get("rate_source")
         if recorded_ms > 0 and abs(raycast_ms - recorded_ms) <= 0.05 * recorded_ms:
             atomics = float(entry["l2_atomics_per_launch"])
@@ -49,10 +58,10 @@ def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells):
                         "atomics_per_distinct_cell": round(atomics / max(distinct_cells, 1), 3),
                         "achieved_G_atomics_per_s": round(atomics / (raycast_ms * 1e-3) / 1e9, 2),
                         "frac_of_scattered_atomic_rate": round(atomics / (raycast_ms * 1e-3) / 1e9 / rate, 3),
-                        "counters_source": "profiles/raycast_atomic_current.json (commit %s, kernel %.3f ms)" % (
+                        "counters_source": "profiles/raycast_atomic_current.json (commit %s, call %.3f ms)" % (
                             doc.get("commit", "?"), recorded_ms)})
         else:
-            out["counters_source"] = "profiles/raycast_atomic_current.json is for a %.3f ms kernel (commit %s): not this build" % (
+            out["counters_source"] = "profiles/raycast_atomic_current.json is for a %.3f ms call (commit %s): not this build" % (
                 recorded_ms, doc.get("commit", "?"))
     except (OSError, KeyError, ValueError, TypeError):
         out["counters_source"] = None
@@ -120,7 +129,7 @@ def measure(points=1_000_000, grid=256, steps=10, warmup=3, check=True, threads_
                  # algorithmic bytes: 12 B/point + 8 B/visit (4-byte atomic RMW), SURVEY.md 8d
                  "achieved_GBps": round((12.0 * points + 8.0 * visits) / (ms * 1e-3) / 1e9, 1)}
         if points == 1_000_000 and grid == 256:
-            entry["atomic_roofline"] = atomic_roofline(name, ms, visits, distinct)
+            entry["atomic_roofline"] = atomic_roofline(name, ms, visits, distinct, points)
         if check:
             from oracle import oracle as O
             t0 = time.perf_counter()

@@ -11,6 +11,8 @@ OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo $COMMIT > $OUT/commit.txt
+# ONLY=raycast tools/collect_profiles.sh <tag> <commit>: the raycaster's part alone (after a change to voxelizer_kernels.hip)
+if [ "${ONLY:-all}" != raycast ]; then
 timeout 600 python3 bench.py > $OUT/bench1024.json 2> $OUT/bench1024.err
 timeout 300 python3 bench.py --dist salt --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_salt.json 2> /dev/null
 timeout 300 python3 bench.py --dist unknown_mix --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_unknown_mix.json 2> /dev/null
@@ -21,14 +23,17 @@ python3 -c "import json,sys; p=sys.argv[1]; d=json.load(open(p)); d['commit']=sy
 timeout 300 python3 bench.py --force-slab --steps 3 --warmup 1 > $OUT/bench_config5_one_gpu_slab_path.json 2> /dev/null
 timeout 300 python3 bench.py --variant 3 --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_variant3_int16_field_round3_pipeline.json 2> /dev/null
 timeout 300 python3 bench.py --variant 2 --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_variant2_tiled_envelope.json 2> /dev/null
-make -s -C tools/microbench scattered_atomics > /dev/null 2>&1 && tools/microbench/scattered_atomics > $OUT/microbench_scattered_atomics.json 2> /dev/null
-timeout 300 python3 bench_raycast.py > $OUT/bench_raycast_config3.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-raycast --no-secondary > $OUT/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-raycast --no-secondary > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-raycast --no-secondary > /dev/null 2>&1
-# raycaster: kernel stats and the L2's atomic / write request counters (whatever this rocprofv3 calls them)
+fi
+# raycaster: the bench line, the atomics micro-benchmark, kernel stats and the L2's atomic request counters (whatever this
+# rocprofv3 calls them)
+make -s -C tools/microbench scattered_atomics > /dev/null 2>&1 && tools/microbench/scattered_atomics > $OUT/microbench_scattered_atomics.json 2> /dev/null
+timeout 300 python3 bench_raycast.py > $OUT/bench_raycast_config3.json 2> /dev/null
+timeout 120 tests/cpp/bench_voxelize > $OUT/bench_voxelize_end_to_end.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raycast_stats -- python3 bench_raycast.py --no-check --steps 5 > /dev/null 2>&1
 rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*ATOMIC[A-Z0-9_]*" | sort -u > $OUT/available_atomic_counters.txt
 ATOMIC=$(grep -E "^TCC_(EA0_)?ATOMIC(_sum)?$|^TCC_ATOMIC_sum$|^TCC_EA0_ATOMIC_sum$" $OUT/available_atomic_counters.txt | head -2 | tr '\n' ' ')
