@@ -25,7 +25,7 @@ def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells, points):
     kernel actually sends to memory is one atomic per distinct cell a workgroup's table holds at a flush, so the second
     yardstick is the L2's atomic rate: atomic requests per launch (committed rocprofv3 --pmc TCC_ATOMIC pass,
     profiles/raycast_atomic_current.json, reported only for the sources it was collected on and while the call timed here
-    is within 5 % of the duration it was collected at) over the rates of the committed micro-benchmark
+    is within 10 % of the duration it was collected at) over the rates of the committed micro-benchmark
     (tools/microbench/scattered_atomics.hip): uniformly random cells, and one 256-byte line per wave instruction.  The
     table is flushed in address order, so the kernel is not held to the random rate; since round 5 it is the walk's
     instruction issue that bounds it (profiles/r5/experiments.md, "Raycaster").  Counters cannot be read from inside
@@ -52,7 +52,7 @@ def atomic_roofline(cloud_key, raycast_ms, visits, distinct_cells, points):
         out["scattered_atomic_rate_G_per_s"] = rate
         out["one_line_per_wave_atomic_rate_G_per_s"] = (doc.get("microbench") or {}).get("one_line_G_atomics_per_s")
         out["rate_source"] = doc.get("rate_source")
-        if recorded_ms > 0 and abs(raycast_ms - recorded_ms) <= 0.05 * recorded_ms:
+        if recorded_ms > 0 and abs(raycast_ms - recorded_ms) <= 0.10 * recorded_ms:
             atomics = float(entry["l2_atomics_per_launch"])
             out.update({"l2_atomics_per_launch": int(atomics), "atomics_per_visit": round(atomics / max(visits, 1), 4),
                         "atomics_per_distinct_cell": round(atomics / max(distinct_cells, 1), 3),
