@@ -58,7 +58,10 @@ int vgt_hip_device_name(int device, char* buffer, size_t buffer_size);
 
 /* ---- context: the state behind hip_helpers::MakeHipVoxelizationHelper(options, log)
  *      (I/cuda_voxelization_helpers.h:19-24; ctor S/cuda_voxelization_helpers.cu:562-639).
- *      threads_per_block <= 0 selects the default (256).  Options HIP_DEVICE /
+ *      threads_per_block <= 0 selects the defaults: 256 for the filter and the small-cloud raycast
+ *      kernel, and the size the direction-sorted raycast kernel is tuned for (512: its LDS table, the
+ *      re-deal of rays by walk length and the flush scale with the workgroup); a positive value (a
+ *      multiple of 64, at most 1024) is used for all of them.  Options HIP_DEVICE /
  *      HIP_THREADS_PER_BLOCK of the C++ glue land here. */
 int vgt_hip_create(int device, int threads_per_block, vgt_hip_ctx** out_ctx);
 void vgt_hip_destroy(vgt_hip_ctx* ctx);

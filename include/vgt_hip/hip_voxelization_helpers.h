@@ -6,7 +6,8 @@
 //
 // Options understood by MakeHipVoxelizationHelper:
 //   HIP_DEVICE             device index, default 0
-//   HIP_THREADS_PER_BLOCK  threads per workgroup of the raycast / filter kernels, default 256
+//   HIP_THREADS_PER_BLOCK  threads per workgroup of the raycast / filter kernels; not given: 256, and 512 for the
+//                          raycast kernel of large (direction-sorted) clouds
 //   HIP_EXACT_FP64         1: filter ratio in double, as the reference's CPU voxelizer
 //                          (pointcloud_voxelization_interface.hpp:55-86); default 0 (float,
 //                          as the reference's device kernels)

@@ -817,10 +817,27 @@ void vgt_oracle_coarse_gradient(const float* sdf, int64_t nx, int64_t ny, int64_
 
 /* ------------------------------------------------------------------------- */
 
-static int32_t step_from_diff_i32(int32_t diff)
+/* float -> int32 as the DEVICE kernels' cast behaves (cuda_voxelization_helpers.cu:140-144, :229-240 run as CUDA
+ * cvt.rzi.s32.f32, and as v_cvt_i32_f32 on AMD): NaN -> 0, out of range -> saturated.  x86's cvttss2si would answer
+ * INT32_MIN to all of those; the difference shows on a ray of length zero seen from outside the grid (direction 0 / 0,
+ * entry point NaN): the device kernels start it in voxel (0, 0, 0). */
+static inline int32_t device_index_f32(float x)
 {
-  return (diff > 0) ? 1 : ((diff < 0) ? -1 : 0); /* S/cuda...cu:35-50 */
+  if (isnan(x)) return 0;
+  if (x >= 2147483648.0f) return INT32_MAX;
+  if (x <= -2147483648.0f) return INT32_MIN;
+  return (int32_t)x;
 }
+/* double -> int64 as the CPU voxelizer's cast behaves on x86-64 (cvttsd2si; cpu_pointcloud_voxelization.cpp:107, :181,
+ * :294-297 through LocationInGridFrameToGridIndex4d): NaN and out of range -> INT64_MIN, made explicit so that the
+ * oracle says the same on any host. */
+static inline int64_t host_index_f64(double x)
+{
+  if (!(x > -9223372036854775808.0 && x < 9223372036854775808.0)) return INT64_MIN;
+  return (int64_t)x;
+}
+
+/* (the step of an axis, S/cuda...cu:35-50: the sign of final - start index, taken inline below) */
 
 /* S/cuda_voxelization_helpers.cu:52-71 */
 static float axis_t_f32(float point_axis, float ray_axis, float vmin,
@@ -863,8 +880,8 @@ static void raycast_one_f32(const float* pt, float max_range, const float* T,
     fin[2] = o[2] + (ray[2] * (max_range / len));
   }
   /* :139-149 */
-  const int32_t oi[3] = {(int32_t)floorf(o[0] * ivs), (int32_t)floorf(o[1] * ivs),
-                         (int32_t)floorf(o[2] * ivs)};
+  const int32_t oi[3] = {device_index_f32(floorf(o[0] * ivs)), device_index_f32(floorf(o[1] * ivs)),
+                         device_index_f32(floorf(o[2] * ivs))};
   const int32_t dims[3] = {nx, ny, nz};
   const int origin_in_grid = oi[0] >= 0 && oi[0] < nx && oi[1] >= 0 &&
                              oi[1] < ny && oi[2] >= 0 && oi[2] < nz;
@@ -902,9 +919,11 @@ static void raycast_one_f32(const float* pt, float max_range, const float* T,
   int32_t si[3], fi[3], step[3];
   for (int a = 0; a < 3; a++)
   {
-    si[a] = (int32_t)floorf(start[a] * ivs);
-    fi[a] = (int32_t)floorf(fin[a] * ivs);
-    step[a] = step_from_diff_i32(fi[a] - si[a]);
+    si[a] = device_index_f32(floorf(start[a] * ivs));
+    fi[a] = device_index_f32(floorf(fin[a] * ivs));
+    /* (the difference in 64 bits: saturated indices must not overflow it) */
+    const int64_t diff = (int64_t)fi[a] - (int64_t)si[a];
+    step[a] = (diff > 0) ? 1 : ((diff < 0) ? -1 : 0);
   }
   /* :248-274 */
   const float half = vs * 0.5f;
@@ -1034,8 +1053,8 @@ static void raycast_one_f64(const double o[3], const int64_t oi[3],
   int64_t si[3], fi[3], step[3];
   for (int a = 0; a < 3; a++)
   {
-    si[a] = (int64_t)floor(start[a] * ivs);
-    fi[a] = (int64_t)floor(fin[a] * ivs);
+    si[a] = host_index_f64(floor(start[a] * ivs));
+    fi[a] = host_index_f64(floor(fin[a] * ivs));
     const int64_t diff = fi[a] - si[a];
     step[a] = (diff > 0) ? 1 : ((diff < 0) ? -1 : 0);
   }
@@ -1095,9 +1114,9 @@ void vgt_oracle_raycast_f64(const double* points, int64_t num_points,
   threads = resolve_threads(threads);
   const double gs[3] = {grid_x_size, grid_y_size, grid_z_size};
   const double o[3] = {T[12], T[13], T[14]}; /* :178 */
-  const int64_t oi[3] = {(int64_t)floor(o[0] * inverse_voxel_size),
-                         (int64_t)floor(o[1] * inverse_voxel_size),
-                         (int64_t)floor(o[2] * inverse_voxel_size)}; /* :180 */
+  const int64_t oi[3] = {host_index_f64(floor(o[0] * inverse_voxel_size)),
+                         host_index_f64(floor(o[1] * inverse_voxel_size)),
+                         host_index_f64(floor(o[2] * inverse_voxel_size))}; /* :180 */
 #pragma omp parallel for schedule(static) num_threads(threads)
   for (int64_t i = 0; i < num_points; i++)
   {

@@ -549,3 +549,28 @@ def test_random_scenes_counts_bit_exact(ctx, oracle):
         want = oracle.raycast_f32(pts, max_range, xf, vs, ivs, sizes, counts)
         assert np.array_equal(grids.retrieve(0, counts), want), (scene, counts, npts)
         grids.close()
+
+
+@pytest.mark.parametrize("npts", [3, 50_000])
+def test_zero_length_rays_outside_the_grid(ctx, oracle, npts):
+    """Points AT the sensor with the sensor outside the grid (direction 0 / 0, entry point NaN): the float kernel starts
+    them in voxel (0, 0, 0) like the reference's device kernels (the device cast of NaN is 0), the double kernel drops
+    them like the CPU voxelizer (x86's cast); see tests/test_oracle_voxelization.py.  Small cloud: the kernel without
+    the table; large: mixed into a sorted cloud."""
+    from test_oracle_voxelization import _zero_length_ray_scene
+    counts, vs, zero_pts, xf = _zero_length_ray_scene()
+    pts = synthetic.raycast_cloud(npts, seed=8, nan_every=0)
+    pts[::3] = 0.0
+    sizes = [np.float32(c) * vs for c in counts]
+    grids = ctx.tracking_grids(int(np.prod(counts)), 1)
+    grids.raycast_f32(0, pts, 3.0, xf.astype(np.float32), vs, np.float32(1.0) / vs, sizes, counts)
+    got = grids.retrieve(0, counts)
+    want = oracle.raycast_f32(pts, 3.0, xf.astype(np.float32), vs, np.float32(1.0) / vs, sizes, counts)
+    assert np.array_equal(got, want)
+    assert got[0, 0, 0, 0] >= len(pts[::3])
+    grids.clear()
+    sizes64 = [float(c) * float(vs) for c in counts]
+    call = (pts.astype(np.float64), 3.0, xf, float(vs), 1.0 / float(vs), sizes64, counts)
+    grids.raycast_f64(0, *call)
+    assert np.array_equal(grids.retrieve(0, counts), oracle.raycast_f64(*call))
+    grids.close()

@@ -34,12 +34,19 @@ namespace
 {
 template <typename Real>
 struct RaycastTraits;
+// ToIndex: what `static_cast<integer>(std::floor(x))` of the reference gives where IT runs.  The float walk restates
+// the device kernels (cuda_voxelization_helpers.cu:140-144, :229-240): on the device the cast saturates and turns NaN
+// into 0, which is what v_cvt_i32_f32 does as well.  The double walk restates the CPU voxelizer
+// (cpu_pointcloud_voxelization.cpp:107, :181, :294-297), whose cast on x86-64 answers "indefinite" (the most negative
+// integer) to NaN: never a voxel of the grid.  It matters for a ray of length zero seen from outside the grid (its
+// direction is 0 / 0 and its entry point NaN): the device kernels start it in voxel (0, 0, 0), the CPU voxelizer drops it.
 template <>
 struct RaycastTraits<float>
 {
   using Grid = RaycastGridF32;
   static constexpr float kFlat = 1e-10f;
   static constexpr float kNudge = 1e-10f;
+  static __device__ __forceinline__ int32_t ToIndex(float floored) { return static_cast<int32_t>(floored); }
 };
 template <>
 struct RaycastTraits<double>
@@ -47,6 +54,10 @@ struct RaycastTraits<double>
   using Grid = RaycastGridF64;
   static constexpr double kFlat = 1e-10;
   static constexpr double kNudge = 1e-10;
+  static __device__ __forceinline__ int32_t ToIndex(double floored)
+  {
+    return isnan(floored) ? INT32_MIN : static_cast<int32_t>(floored);
+  }
 };
 
 template <typename Real>
@@ -516,7 +527,7 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
       // entry point: the origin itself, or where the ray enters the grid's box
       int32_t origin_idx[3];
       for (int a = 0; a < 3; a++)
-        origin_idx[a] = static_cast<int32_t>(floor(origin[a] * g.inverse_voxel_size));
+        origin_idx[a] = RaycastTraits<Real>::ToIndex(floor(origin[a] * g.inverse_voxel_size));
       Real first[3] = {origin[0], origin[1], origin[2]};
       if (!InGrid(origin_idx, g.counts))
       {
@@ -558,8 +569,8 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
         const int64_t stride[3] = {static_cast<int64_t>(g.counts[1]) * g.counts[2], g.counts[2], 1};
         for (int a = 0; a < 3; a++)
         {
-          cur[a] = static_cast<int32_t>(floor(first[a] * g.inverse_voxel_size));
-          end[a] = static_cast<int32_t>(floor(last[a] * g.inverse_voxel_size));
+          cur[a] = RaycastTraits<Real>::ToIndex(floor(first[a] * g.inverse_voxel_size));
+          end[a] = RaycastTraits<Real>::ToIndex(floor(last[a] * g.inverse_voxel_size));
           const int64_t diff = static_cast<int64_t>(end[a]) - cur[a];
           const int32_t step = (diff > 0) - (diff < 0);
           const Real centre = (static_cast<Real>(cur[a]) + Real(0.5)) * g.voxel_size;
