@@ -81,7 +81,7 @@ def main():
             sides[int(rng.integers(0, 3))] //= 2
         counts = tuple(max(1, s) for s in sides)
         vs = np.float32(rng.uniform(0.01, 0.2))
-        npts = int(rng.choice([100, 20_000, 40_000, 150_000]))
+        npts = int(rng.choice([100, 12_000, 20_000, 40_000, 150_000]))
         pts = synthetic.raycast_cloud(npts, seed=int(rng.integers(1, 1 << 30)), nan_every=int(rng.choice([0, 7, 100])))
         pts = (pts * np.float32(rng.choice([0.02, 0.5, 1.0, 3.0, 20.0]))).astype(np.float32)
         if rng.random() < 0.2:

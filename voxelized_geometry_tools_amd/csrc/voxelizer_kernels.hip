@@ -306,7 +306,7 @@ constexpr int kFaceBits = 5;
 constexpr int kSortBins = 6 << (2 * kFaceBits);               // 6144
 constexpr int kSortChunk = 4096;                              // rays per workgroup of the two kernels
 constexpr int kSortThreads = 256;
-constexpr int64_t kSortMinPoints = 32768;                     // smaller clouds: the extra launches cost more than they save
+constexpr int64_t kSortMinPoints = 16384;                     // smaller clouds: the extra launches cost more than they save
 static_assert(kSortBins % kSortThreads == 0 && kSortBins < 65536 && kSortChunk < 65536, "16-bit bins and counts");
 __device__ __forceinline__ uint32_t SpreadBits(uint32_t x)    // 0b..cba -> 0b..0c0b0a
 {
