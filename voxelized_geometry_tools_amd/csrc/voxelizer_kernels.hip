@@ -177,62 +177,44 @@ struct VisitTable
     }
   }
   // A seen-free visit of `cell` (cell < 2^32 - 1) is recorded in two halves with a step of the walk between them, so
-  // that the wave never waits for the LDS: Lookup() asks for the key of the cell's slot and sends off the claim a lane
-  // still owes from its PREVIOUS visit; Record(), a DDA step later, counts the visit if the slot holds the cell, or -- a
-  // first visit -- remembers the empty slot as the lane's owed claim, or -- the slot is another cell's -- sends the
-  // visit to global memory.  A claim is a compare-and-swap (empty -> cell) whose answer settles it: the slot now
-  // holds the cell (count it there) or another lane's cell won the slot (global).
+  // that the wave never waits for the LDS: Lookup() asks for the key of the cell's slot; Record(), a DDA step later,
+  // counts the visit if the slot holds the cell, or -- a first visit: the slot is empty -- sends off a claim at once,
+  // whose answer is what the lane OWES looking at in its next Record(), or -- the slot is another cell's -- sends the
+  // visit to global memory.  A claim is a compare-and-swap (empty -> cell) whose answer settles it: the slot now holds
+  // the cell (count the visit there) or another lane's cell won the slot (global).  The sooner a claim lands, the fewer of
+  // the rays that enter the voxel in the next steps still see the slot empty and claim it again.
   struct Owed
   {
     uint32_t cell;
-    uint32_t slot;  // kNoSlot: nothing owed
+    uint32_t slot;     // kNoSlot: nothing owed
+    uint32_t claimed;  // the claim's answer (in flight until it is looked at)
   };
   static constexpr uint32_t kNoSlot = 0xffffffffu;
-  struct Pending
-  {
-    uint32_t key;      // the slot's key as read
-    uint32_t claimed;  // answer of the owed claim
-  };
-  __device__ __forceinline__ Pending Lookup(uint32_t slot, const Owed& owed) const
-  {
-    Pending p;
-    p.key = keys[slot];
-    p.claimed = 0u;
-    if (owed.slot != kNoSlot) p.claimed = LdsClaim(keys + owed.slot, kEmptyKey, owed.cell);
-    return p;
-  }
-  __device__ __forceinline__ void Settle(Owed& owed, uint32_t claimed, int32_t* __restrict__ tracking)
+  __device__ __forceinline__ uint32_t Lookup(uint32_t slot) const { return keys[slot]; }
+  __device__ __forceinline__ void Settle(Owed& owed, int32_t* __restrict__ tracking)
   {
     if (owed.slot != kNoSlot)
     {
-      const bool mine = claimed == kEmptyKey || claimed == owed.cell;
+      const bool mine = owed.claimed == kEmptyKey || owed.claimed == owed.cell;
       if (mine) LdsCount(counts + owed.slot, 1u);
       if (!mine) atomicAdd(&tracking[static_cast<int64_t>(owed.cell) * 2], 1);
       owed.slot = kNoSlot;
     }
   }
-  __device__ __forceinline__ void Record(uint32_t cell, uint32_t slot, const Pending& p, Owed& owed,
+  __device__ __forceinline__ void Record(uint32_t cell, uint32_t slot, uint32_t key, Owed& owed,
                                          int32_t* __restrict__ tracking)
   {
-    Settle(owed, p.claimed, tracking);
-    if (p.key == cell)
+    Settle(owed, tracking);
+    if (key == cell)
       LdsCount(counts + slot, 1u);
-    else if (p.key == kEmptyKey)
+    else if (key == kEmptyKey)
     {
       owed.cell = cell;
       owed.slot = slot;
+      owed.claimed = LdsClaim(keys + slot, kEmptyKey, cell);
     }
     else
       atomicAdd(&tracking[static_cast<int64_t>(cell) * 2], 1);
-  }
-  // before a flush: the claim still owed is made and settled on the spot
-  __device__ __forceinline__ void SettleNow(Owed& owed, int32_t* __restrict__ tracking)
-  {
-    if (owed.slot != kNoSlot)
-    {
-      const uint32_t claimed = LdsClaim(keys + owed.slot, kEmptyKey, owed.cell);
-      Settle(owed, claimed, tracking);
-    }
   }
   __device__ __forceinline__ void Flush(int32_t* __restrict__ tracking)
   {
@@ -664,7 +646,7 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
 
   // The walk, in segments of kWalkSegment steps; with the table, the workgroup flushes it between segments.
   int walked = 0;
-  VisitTable::Owed owed{0u, VisitTable::kNoSlot};
+  VisitTable::Owed owed{0u, VisitTable::kNoSlot, 0u};
   for (;;)
   {
     if constexpr (kTable)
@@ -679,10 +661,10 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
       {
         const Index here = cell;
         const uint32_t here_slot = slot;
-        VisitTable::Pending lookup{};
+        uint32_t lookup = 0u;
         if constexpr (kTable)
         {
-          lookup = table.Lookup(here_slot, owed);
+          lookup = table.Lookup(here_slot);
           __builtin_amdgcn_sched_barrier(0);  // the step below is what the wave does while the LDS answers
         }
         else if (walked < kAggregatedSteps)  // `walked` is the same for every lane still in the loop
@@ -724,7 +706,7 @@ __global__ void RaycastKernel(const Real* __restrict__ points, int64_t num_point
         }
       }
     }
-    if constexpr (kTable) table.SettleNow(owed, tracking);
+    if constexpr (kTable) table.Settle(owed, tracking);  // (the last step's claim)
     if constexpr (kTable)
     {
       __syncthreads();
