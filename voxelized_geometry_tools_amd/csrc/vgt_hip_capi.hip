@@ -25,7 +25,6 @@ struct UploadLane
   std::mutex mutex;
   hipStream_t stream = nullptr;
   hipEvent_t after_ctx = nullptr;  // orders the lane behind what the context's stream holds (grid zeroing)
-  hipEvent_t copied = nullptr;     // the lane's last upload has arrived (the next lane's upload starts behind it)
   void* stage = nullptr;
   size_t stage_bytes = 0;
   // Page-locked host buffer the caller's cloud is copied to first: a 12-MB cloud from pageable memory goes through the
@@ -35,7 +34,7 @@ struct UploadLane
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
 };
-constexpr int kUploadLanes = 4;  // (eight: the runtime folds the streams onto four hardware queues, 8 clouds 5.9 -> 13 ms)
+constexpr int kUploadLanes = 4;
 
 struct vgt_hip_ctx
 {
@@ -47,10 +46,6 @@ struct vgt_hip_ctx
   std::mutex mutex;              // serialises enqueues + the staging buffer
   UploadLane lanes[kUploadLanes];
   std::atomic<unsigned> next_lane{0};
-  // Uploads of different lanes share one link: started together, four 12-MB clouds all arrive after 0.8 ms and no
-  // kernel runs until then; one behind the other, the first is there after 0.2 ms and its kernel runs under the
-  // others' copies.  The most recent upload's event (its lane's `copied`), guarded by `mutex`.
-  hipEvent_t last_upload = nullptr;
   void* ray_scratch = nullptr;   // sort scratch of raycasts of device-resident clouds (context stream)
   size_t ray_scratch_bytes = 0;
   float* minmax_out = nullptr;   // 2 floats (device) for host-facing SDF calls
@@ -648,17 +643,10 @@ void FreeUploadLanes(vgt_hip_ctx* ctx, bool destroy_streams)
     if (destroy_streams)
     {
       if (lane.after_ctx) (void)hipEventDestroy(lane.after_ctx);
-      if (lane.copied) (void)hipEventDestroy(lane.copied);
-      lane.copied = nullptr;
       if (lane.stream) (void)hipStreamDestroy(lane.stream);
       lane.after_ctx = nullptr;
       lane.stream = nullptr;
     }
-  }
-  if (destroy_streams)
-  {
-    std::lock_guard<std::mutex> lock(ctx->mutex);
-    ctx->last_upload = nullptr;
   }
 }
 
@@ -693,7 +681,6 @@ int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratc
   {
     VGT_TRY_HIP(hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking), "create upload stream");
     VGT_TRY_HIP(hipEventCreateWithFlags(&lane.after_ctx, hipEventDisableTiming), "create upload event");
-    VGT_TRY_HIP(hipEventCreateWithFlags(&lane.copied, hipEventDisableTiming), "create upload event");
   }
   // staging copy of the cloud, followed by the kernel's scratch (256-byte aligned)
   const size_t scratch_at = AlignUp(bytes, 256);
@@ -738,16 +725,8 @@ int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratc
       }
     }
   }
-  {
-    // (one critical section: wait for the previous upload, enqueue this one, become the previous upload)
-    std::lock_guard<std::mutex> lock(ctx->mutex);
-    if (ctx->last_upload && ctx->last_upload != lane.copied)
-      VGT_TRY_HIP(hipStreamWaitEvent(lane.stream, ctx->last_upload, 0), "order upload behind the previous one");
-    VGT_TRY_HIP(hipMemcpyAsync(lane.stage, source, bytes, hipMemcpyHostToDevice, lane.stream),
-                "Failed to copy points to the device");
-    VGT_TRY_HIP(hipEventRecord(lane.copied, lane.stream), "record upload event");
-    ctx->last_upload = lane.copied;
-  }
+  VGT_TRY_HIP(hipMemcpyAsync(lane.stage, source, bytes, hipMemcpyHostToDevice, lane.stream),
+              "Failed to copy points to the device");
   VGT_TRY_HIP(launch(lane.stage, static_cast<char*>(lane.stage) + scratch_at, lane.stream),
               "Failed to dispatch raycast kernel");
   VGT_TRY_HIP(hipStreamSynchronize(lane.stream), "raycast");
