@@ -1055,8 +1055,9 @@ static void raycast_one_f64(const double o[3], const int64_t oi[3],
   {
     si[a] = host_index_f64(floor(start[a] * ivs));
     fi[a] = host_index_f64(floor(fin[a] * ivs));
-    const int64_t diff = fi[a] - si[a];
-    step[a] = (diff > 0) ? 1 : ((diff < 0) ? -1 : 0);
+    /* (the sign of final - start by comparison: with an "indefinite" index the subtraction overflows, and a ray that
+     * has one never walks) */
+    step[a] = (fi[a] > si[a]) ? 1 : ((fi[a] < si[a]) ? -1 : 0);
   }
   /* :324-364 */
   const double half = vs * 0.5;
