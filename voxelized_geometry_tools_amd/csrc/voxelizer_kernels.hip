@@ -121,8 +121,6 @@ constexpr uint32_t kEmptyKey = 0xffffffffu;
 // (LDS pointers carry their address space, so that the two places a visit can go -- the table or global memory -- stay two
 // instructions, ds_add and global_atomic_add, instead of one flat atomic on a selected address)
 using LdsWord = __attribute__((address_space(3))) uint32_t;
-typedef uint32_t WordPair __attribute__((ext_vector_type(2)));
-using LdsPair = __attribute__((address_space(3))) WordPair;
 
 __device__ __forceinline__ void LdsCount(LdsWord* word, uint32_t by)
 {
