@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL_PASS = 8.0  # 3 passes x (4 B read + 4 B write) = 24 B/voxel
-KERNEL_NAMES = ["PassZClassRecords", "PassY", "PassXFinalize"]  # (variants 1-3: pass 1 is the int16 Z scan)
+KERNEL_NAMES = ["PassZClassRecords", "PassY", "PassXFinalize"]  # (variant 1: pass 1 is the int16 Z scan)
 
 
 def parse_args():
@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=0, help="cube edge instead of the workload's shape (experiments)")
     ap.add_argument("--dist", default="spheres", choices=["spheres", "salt", "unknown_mix", "empty", "single"])
     ap.add_argument("--salt-p", type=float, default=0.01, help="fill probability of --dist salt")
-    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1, 2, 3 cross-check implementations; 3 = the int16 distance field + sweeps of round 3)")
+    ap.add_argument("--variant", type=int, default=0, help="EDT variant (0 default; 1 = the testing library's cross-check pipeline: int16 Z scan + pruned search)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab (multi-GPU) code path even with one rank: NCCL init, summary all-gather, "
                          "fix-up kernel, extrema all-reduce (smoke test of the N > 1 path on a single GPU)")

@@ -205,7 +205,7 @@ int vgt_hip_sdf_from_mask_u8(vgt_hip_ctx* ctx, const uint8_t* filled_mask_host, 
  * {min, max} as two floats on the device after the call (stream-ordered). */
 size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz);
 /* As above for a context set to EDT variant `variant` (0 = the default pipeline = vgt_hip_sdf_workspace_bytes; the
- * cross-check variants 1-3 exist in testing builds only, the product library returns 0 for them).  The default
+ * cross-check variant 1 exists in testing builds only, the product library returns 0 for it).  The default
  * workspace holds the class records of pass 1 (0.25 bytes per voxel), the int32 intermediate field (4 bytes per voxel)
  * and the line passes' scratch, which grows with the axis lengths, not with the volume (the spilled stack entries and
  * sign words of the at most 4096 waves in flight: 1.1 GB for a 1024^3 grid, 4.4 GB at 2048 x 2048 x 1024; the launches
@@ -247,10 +247,9 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
 /* ---- Testing builds only: libvgt_hip_testing.so (make -C voxelized_geometry_tools_amd/csrc testing), which the parity
  * tests load next to the product library.  The product library exports none of these and contains none of the
  * cross-check implementations. ----
- * Selects the EDT pipeline (all exact): 0 = default (pass 1 writes class records, lane-per-line sweeps: one lane runs
- * the Felzenszwalb-Huttenlocher stack of one line, stack tops in LDS, any extent); the others share an int16 distance
- * field along Z as pass 1: 1 = pruned outward search from HBM (any size), 2 = LDS-tiled lower envelope (band hulls +
- * merge; axes up to 2048, longer ones take the pruned search), 3 = the sweeps of 0 fed by the int16 field. */
+ * Selects the EDT pipeline (both exact): 0 = default (pass 1 writes class records, lane-per-line sweeps: one lane runs
+ * the Felzenszwalb-Huttenlocher stack of one line, stack tops in LDS, any extent); 1 = the independent cross-check: an
+ * int16 distance field along Z as pass 1, then a pruned outward search per voxel straight from HBM (any size). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant);
 /* The final conversion float(sqrt(double(d2)) * resolution) has a fast evaluation with an exact fallback
  * (csrc/edt_device.hpp); this runs both over d2 in [first_d2, first_d2 + count) on the device and reports how many
@@ -261,17 +260,10 @@ int vgt_hip_debug_finalize_check(vgt_hip_ctx* ctx, int64_t first_d2, int64_t cou
 /* Smallest grid (voxels) that the host-pointer SDF entry points pipeline (upload / kernels / download overlapped);
  * default 2^27, negative = never.  Lets the tests run that path on small grids. */
 int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels);
-/* Lines of at most `rows` rows (0 - 64; the product library: always 64) take the short-line kernels
- * (csrc/edt_short_kernels.hip) instead of the sweeps: lets the tests and benches run either formulation on any length. */
+/* Lines of at most `rows` rows (0 - 128) take the short-line kernels (csrc/edt_short_kernels.hip) instead of the sweeps,
+ * whatever the number of items: lets the tests and benches run either formulation on any length.  Negative: back to the
+ * product's rule (64 rows; the Y pass of launches of at most 1024 items: 128). */
 int vgt_hip_testing_set_short_line_rows(int rows);
-/* Non-zero: sweep launches of at most two rounds of items hand over the lower halves of their second sweeps to workgroups
- * that have run out of items (csrc/edt_sweep_kernels.hip, kSteal).  Exact, but measured slower than without
- * (profiles/r5/experiments.md): off by default and absent from the product library. */
-int vgt_hip_testing_set_sweep_hand_over(int on);
-/* Non-zero: the X pass (32-bit stack entries, lines of 768 - 1024 rows) sweeps every 32nd row first and uses that hull as
- * a filter in front of the sweep proper (csrc/edt_sweep_kernels.hip, kCoarse).  Exact; measured -4 % on the 1024^3 headline
- * and +6 % on dense scenes and one-round launches (profiles/r5/experiments.md): off by default, absent from the product. */
-int vgt_hip_testing_set_sweep_coarse_hull(int on);
 /* Pass 1 alone, for a test of the record format itself (csrc/vgt_internal.hpp, ClassRecord): the class records of a
  * device-resident occupancy grid, [x][64-voxel word][y] x 4 uint32 (mask_lo, mask_hi, below2, above2), into records_dev
  * (vgt_hip_testing_class_record_bytes bytes); summary_dev (optional): the 4-byte slab summaries per line, in which case the

@@ -1,7 +1,7 @@
 // CPU check of the lane-per-line sweep kernels (csrc/edt_sweep_kernels.hip, the default EDT line passes): the kernel source is compiled by
 // g++ against tests/cpp/hip_shim and run one lane at a time, on random lines, against a brute-force evaluation of
 //     out(q) = min( min_r (q-r)^2 + |F[r]|,  min over rows r of the other class (q-r)^2 ),
-// i.e. the per-line contract of the Y and X passes (edt_hull_kernels.hip header).  It exercises what the GPU parity tests
+// i.e. the per-line contract of the Y and X passes.  It exercises what the GPU parity tests
 // cannot reach cheaply: deep stacks (ring spills / refills in both sweeps), every ring / band size the kernel can be
 // built with (-DVGT_SWEEP_BAND / _RING / _CHUNK / _RING_WIDE / _CHUNK_WIDE), packed and 64-bit entries, partial waves, partial bands, the virtual
 // border and the final conversion.  The GPU tests (tests/test_gpu_sdf.py) pin the same kernels to the oracle.
@@ -22,9 +22,7 @@ inline void BlockMinMax(uint32_t lo, uint32_t hi, uint32_t* minmax_enc)
   minmax_enc[0] = std::min(minmax_enc[0], lo);
   minmax_enc[1] = std::max(minmax_enc[1], hi);
 }
-// (edt_kernels.hip defines these for the libraries; here the test flips the coarse hull of the X pass on and off)
-bool g_emulated_coarse_hull = true;
-bool SweepCoarseHull() { return g_emulated_coarse_hull; }
+int ShortLineOverride() { return -1; }  // (edt_kernels.hip defines it for the libraries; the launchers here never ask)
 }  // namespace vgt
 #include "../../voxelized_geometry_tools_amd/csrc/edt_sweep_kernels.hip"
 
@@ -52,69 +50,6 @@ int64_t BruteRow(const std::vector<int64_t>& f, const std::vector<uint8_t>& neg,
 }
 
 int failures = 0;
-
-// Y-pass shaped run: lines along y of an [nx][ny][nz] grid, int16 input (signed Z distance), int32 output.
-void CheckY(const Case& c, std::mt19937& rng)
-{
-  const int nx = c.nx, ny = c.ny, nz = c.nz;
-  const int64_t total = static_cast<int64_t>(nx) * ny * nz;
-  std::vector<int16_t> in(total);
-  for (int x = 0; x < nx; x++)
-    for (int z = 0; z < nz; z++)
-    {
-      int cls = rng() & 1;
-      for (int y = 0; y < ny; y++)
-      {
-        if (static_cast<int>(rng() % 100) < c.p_flip) cls ^= 1;
-        int d;
-        switch (c.mode)
-        {
-          case 0: d = 1 + rng() % 2; break;
-          case 1: d = 1 + rng() % std::max(1, nz - 1); break;
-          case 2: d = 1 + (std::abs(y - ny / 2) % std::max(1, nz - 1)); break;
-          default: d = 1; break;
-        }
-        d = std::min(d, std::max(1, nz - 1));
-        if (static_cast<int>(rng() % 100) >= c.p_site) d = vgt::kInf16;
-        in[(static_cast<int64_t>(x) * ny + y) * nz + z] = static_cast<int16_t>(cls ? -d : d);
-      }
-    }
-  std::vector<int32_t> out(total, 12345);
-  vgt::SdfParams p{};
-  p.nx = nx; p.ny = ny; p.nz = std::max(nz, 2);  // (max_input is derived from nz: keep it >= the largest distance used)
-  p.nz = nz;
-  p.resolution = 0.01;
-  std::vector<unsigned char> scratch(vgt::SweepPassScratchBytes(nx, ny, nz));
-  vgt::LaunchPassYSweep(in.data(), out.data(), vgt::SweepScratch{scratch.data(), scratch.size()}, p, nullptr);
-  std::vector<int64_t> f(ny);
-  std::vector<uint8_t> neg(ny);
-  for (int x = 0; x < nx; x++)
-    for (int z = 0; z < nz; z++)
-    {
-      for (int y = 0; y < ny; y++)
-      {
-        const int v = in[(static_cast<int64_t>(x) * ny + y) * nz + z];
-        neg[y] = v < 0;
-        const int a = std::abs(v);
-        f[y] = (a == vgt::kInf16) ? -1 : static_cast<int64_t>(a) * a;
-      }
-      for (int y = 0; y < ny; y++)
-      {
-        int64_t want = BruteRow(f, neg, ny, y);
-        want = (want == INT64_MAX) ? vgt::kInf32 : want;
-        const int64_t signed_want = neg[y] ? -want : want;
-        // the Y sweep hands its result to the X sweep as sign and magnitude (bit 31 = class), not two's complement
-        const int32_t raw = out[(static_cast<int64_t>(x) * ny + y) * nz + z];
-        const int32_t got = (raw < 0) ? -(raw & 0x7fffffff) : raw;
-        if (got != signed_want)
-        {
-          if (failures++ < 10)
-            std::printf("Y MISMATCH shape %dx%dx%d mode %d line (x=%d,z=%d) row %d: got %d want %lld\n", nx, ny, nz, c.mode, x,
-                        z, y, got, static_cast<long long>(signed_want));
-        }
-      }
-    }
-}
 
 // Class records (csrc/vgt_internal.hpp) of a class volume, by the definition: a plain restatement for the test, independent
 // of the device kernel that writes them (csrc/edt_record_kernels.hip, checked on the GPU through the SDF parity tests).
@@ -327,19 +262,6 @@ int main(int argc, char** argv)
   int cases = 0;
   for (int round = 0; round < rounds; round++)
   {
-    // {nx, ny, nz, mode, p_site, p_flip, border}
-    const Case y_cases[] = {
-        {2, 1, 3, 0, 100, 10, false},    {3, 2, 5, 0, 100, 50, false},   {2, 33, 7, 0, 100, 0, false},
-        {1, 300, 4, 0, 100, 0, false},   {2, 300, 3, 1, 100, 2, false},  {1, 1024, 2, 0, 100, 0, false},
-        {1, 1024, 70, 1, 30, 1, false},  {2, 700, 5, 2, 100, 0, false},  {1, 1500, 3, 0, 100, 1, false},
-        {1, 2050, 2, 3, 100, 0, false},  {3, 97, 66, 1, 60, 20, false},  {2, 64, 64, 0, 0, 5, false},
-        {1, 513, 3, 1, 5, 0, false},     {1, 999, 2, 0, 100, 100, false},
-    };
-    for (const Case& c : y_cases)
-    {
-      CheckY(c, rng);
-      cases++;
-    }
     // {nx, ny, nz, mode, p_site (mode 2: percent of lines with class changes), p_flip, border (no one-class marks)}
     const Case record_cases[] = {
         {2, 1, 3, 0, 0, 50, false},      {3, 2, 5, 1, 0, 30, false},     {2, 33, 7, 0, 0, 10, true},
@@ -365,15 +287,10 @@ int main(int argc, char** argv)
         {1024, 90, 2, 4, 100, 0, false},  {800, 60, 3, 4, 97, 1, true},   {770, 50, 2, 4, 100, 2, false},
         {1000, 2, 64, 1, 100, 1, false},
     };
-    // (every X case with the coarse hull in front of the sweep -- lines of 768 - 1024 rows take it -- and without)
-    for (const bool coarse_hull : {true, false})
+    for (const Case& c : x_cases)
     {
-      vgt::g_emulated_coarse_hull = coarse_hull;
-      for (const Case& c : x_cases)
-      {
-        CheckX(c, rng);
-        cases++;
-      }
+      CheckX(c, rng);
+      cases++;
     }
   }
   std::printf("%d cases, %d mismatches (band %d; 32-bit entries: ring %d, chunk %d; 64-bit entries: ring %d, chunk %d)\n", cases,

@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_testing_hooks_live_in_the_testing_library_only(lib):
-    """The cross-check EDT variants and the debug / tuning hooks are declared under VGT_HIP_TESTING, bound separately and
+    """The cross-check EDT variant and the debug / tuning hooks are declared under VGT_HIP_TESTING, bound separately and
     exported by libvgt_hip_testing.so -- which also exports the whole product ABI -- and by nothing else."""
     hooks = _declared_symbols(testing=True)
     assert sorted(capi.TESTING_SIGNATURES) == hooks and len(hooks) >= 3
@@ -77,19 +77,18 @@ def test_abi_version_and_workspace_size(lib):
     # class records (16 bytes per 64-voxel word of a Z line, plus 256 records of padding) + the int32 intermediate, a
     # small min/max block and the line passes' scratch (8 work counters + per workgroup in flight -- at most 4096 -- the
     # spill area of a full-depth stack per lane, chunks of 8 x 4-byte entries where the extents allow packed entries,
-    # and one 8-byte word record per 32 rows and lane), 256-byte aligned pieces; the cross-check variants keep an int16
+    # and one 8-byte word record per 32 rows and lane), 256-byte aligned pieces; the cross-check variant keeps an int16
     # distance field instead of the records
     n = 64 * 64 * 64
     slots, words = 64, 2
     narrow = ((64 + 4 + 7) // 8 + 1) * 64 * 8 * 4
-    # (the scratch's head: 8 work counters + the hand-over protocol's words, 4096 task records and 16 offer queues;
-    # per slot one more row of 64 x 8 bytes behind the sign words: the lanes' stack depths)
-    head = ((8 + 3 * 16) * 128 + 4096 * 16 + 16 * 4096 * 4 + 255) // 256 * 256
+    # (the scratch's head: 8 work counters, a cache line each; per slot one spare row of 64 x 8 bytes behind the sign words)
+    head = 8 * 128
     scratch = head + slots * (narrow + (words + 1) * 64 * 8) + 256
     records = (64 * 1 * 64 + 256) * 16
     assert capi.sdf_workspace_bytes((64, 64, 64)) == records + n * 4 + 256 + scratch
-    for variant in (1, 2, 3):
-        assert capi.sdf_workspace_bytes((64, 64, 64), variant) == n * 2 + n * 4 + 256 + scratch
+    assert capi.sdf_workspace_bytes((64, 64, 64), 1) == n * 2 + n * 4 + 256 + scratch
+    assert capi.sdf_workspace_bytes((64, 64, 64), 2) == 0  # (earlier rounds' other cross-check pipelines are gone)
     # the scratch grows with the axis lengths, not with the volume: at most 5120 workgroups are in flight
     big = capi.sdf_workspace_bytes((1024, 1024, 1024))
     assert big - 4 * 2 ** 30 - 2 ** 28 - 256 < 1.25 * 2 ** 30

@@ -24,7 +24,7 @@ def oracle():
 
 @pytest.fixture(scope="module")
 def vctx():
-    """A context of libvgt_hip_testing.so: the product's code plus the cross-check pipelines (EDT variants 1-3) and the
+    """A context of libvgt_hip_testing.so: the product's code plus the cross-check pipeline (EDT variant 1) and the
     testing hooks.  The product library (the `ctx` fixture, what every other test runs) contains none of them."""
     c = capi.Context(0, testing=True)
     yield c
@@ -32,10 +32,9 @@ def vctx():
     c.close()
 
 
-# 0 = the default pipeline (class records + lane-per-line sweeps; run on the PRODUCT library), and the cross-check
-# pipelines of the testing library, which share an int16 distance field along Z as pass 1: 1 = pruned search from HBM,
-# 2 = LDS-tiled envelope, 3 = the sweeps fed by the int16 field
-VARIANTS = [0, 1, 2, 3]
+# 0 = the default pipeline (class records + lane-per-line sweeps; run on the PRODUCT library), 1 = the independent
+# cross-check pipeline of the testing library: an int16 distance field along Z as pass 1, then a pruned search from HBM
+VARIANTS = [0, 1]
 
 
 def context_for(variant, ctx, vctx):
@@ -120,59 +119,26 @@ def test_short_line_kernels_and_sweeps_agree(vctx, oracle, shape):
                     assert bits_equal(got, want), (shape, kind, uif, vb, rows)
                     assert (lo, hi) == (wlo, whi), (shape, kind, rows)
     finally:
-        vctx.set_short_line_rows(64)
+        vctx.set_short_line_rows(-1)
 
 
-HAND_OVER_SHAPES = [(200, 150, 70), (129, 300, 64), (512, 130, 40), (128, 128, 128), (260, 1100, 20), (1100, 140, 65)]
+# launches of fewer items than workgroup slots on lines of 128 rows and more (1100-row lines take 64-bit stack entries), and
+# lines of 768 - 1024 rows with few items: smooth scenes and noisy ones
+SWEEP_SHAPES = [(200, 150, 70), (129, 300, 64), (512, 130, 40), (128, 128, 128), (260, 1100, 20), (1100, 140, 65),
+                (768, 9, 70), (769, 40, 64), (800, 33, 5), (1000, 20, 66), (1024, 12, 130), (1023, 300, 20)]
 
 
-@pytest.mark.parametrize("shape", HAND_OVER_SHAPES)
-def test_sweep_hand_over_on_and_off(vctx, oracle, shape):
-    """The testing library can make sweep launches of at most two rounds of items hand the lower half of an item's second
-    sweep to workgroups that have run out of items (csrc/edt_sweep_kernels.hip, kSteal): another wave finds its place in
-    the finished stack by bisection and evaluates rows [0, n / 2).  Measured slower than without and therefore not in the
-    product (profiles/r5/experiments.md) -- but built to be exact: every launch of these grids is such a launch (lines of
-    128 rows and more, fewer items than workgroup slots; 1100-row lines take 64-bit stack entries), and with the hand-over
-    on and off the result is the oracle's field."""
-    vctx.set_edt_variant(0)
-    try:
-        for kind, seed in (("spheres", 3), ("salt", 4), ("unknown_mix", 5), ("single", 0)):
-            occ = synthetic.make_occupancy(shape, kind, seed=seed)
-            for uif, vb in ((True, False), (False, True)):
-                want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0171, uif, vb)
-                for on in (True, False):
-                    vctx.set_sweep_hand_over(on)
-                    for _ in range(2 if on else 1):  # (who helps whom differs from run to run)
-                        got, lo, hi = vctx.sdf_from_occupancy(occ, 0.0171, uif, vb)
-                        assert bits_equal(got, want), (shape, kind, uif, vb, on)
-                        assert (lo, hi) == (wlo, whi), (shape, kind, on)
-    finally:
-        vctx.set_sweep_hand_over(False)
-
-
-COARSE_HULL_SHAPES = [(768, 9, 70), (769, 40, 64), (800, 33, 5), (1000, 20, 66), (1024, 12, 130), (1023, 300, 20)]
-
-
-@pytest.mark.parametrize("shape", COARSE_HULL_SHAPES)
-def test_coarse_hull_on_and_off(vctx, oracle, shape):
-    """The X pass of lines of 768 - 1024 rows sweeps every 32nd row first and uses that hull as a filter in front of the
-    sweep proper (csrc/edt_sweep_kernels.hip, kCoarse): rows strictly above the chord between two subsample vertices never
-    touch the stack.  Testing library only (measured: not worth it, profiles/r5/experiments.md) but exact by construction;
-    here against the oracle with the filter on and off, on smooth scenes -- where it removes most rows -- and noisy ones --
-    where it removes few."""
-    vctx.set_edt_variant(0)
-    try:
-        for kind, seed in (("spheres", 11), ("salt", 12), ("unknown_mix", 13), ("single", 0), ("full", 0)):
-            occ = synthetic.make_occupancy(shape, kind, seed=seed)
-            for uif, vb in ((True, False), (False, True)):
-                want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0331, uif, vb)
-                for on in (True, False):
-                    vctx.set_sweep_coarse_hull(on)
-                    got, lo, hi = vctx.sdf_from_occupancy(occ, 0.0331, uif, vb)
-                    assert bits_equal(got, want), (shape, kind, uif, vb, on)
-                    assert (lo, hi) == (wlo, whi), (shape, kind, on)
-    finally:
-        vctx.set_sweep_coarse_hull(False)
+@pytest.mark.parametrize("shape", SWEEP_SHAPES)
+def test_sweeps_on_few_item_and_long_line_shapes(ctx, oracle, shape):
+    """The lane-per-line sweeps (csrc/edt_sweep_kernels.hip) where their bookkeeping differs from the cube case: one-round
+    launches, partial last bands and sign words, both entry widths, ring spills on long lines."""
+    for kind, seed in (("spheres", 3), ("salt", 4), ("unknown_mix", 5), ("single", 0), ("full", 0)):
+        occ = synthetic.make_occupancy(shape, kind, seed=seed)
+        for uif, vb in ((True, False), (False, True)):
+            want, wlo, whi = oracle.sdf_from_occupancy(occ, 0.0171, uif, vb)
+            got, lo, hi = ctx.sdf_from_occupancy(occ, 0.0171, uif, vb)
+            assert bits_equal(got, want), (shape, kind, uif, vb)
+            assert (lo, hi) == (wlo, whi), (shape, kind)
 
 
 def test_degenerate_grids(ctx, oracle):

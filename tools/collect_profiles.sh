@@ -21,8 +21,6 @@ timeout 600 python3 tools/slab_rank_geometry.py --out $OUT/slab_rank_geometry.js
 timeout 300 python3 bench.py --workload c5 --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_c5_one_gpu.json 2> /dev/null
 python3 -c "import json,sys; p=sys.argv[1]; d=json.load(open(p)); d['commit']=sys.argv[2]; open(p,'w').write(json.dumps(d)+'\n')" $OUT/bench_c5_one_gpu.json $COMMIT
 timeout 300 python3 bench.py --force-slab --steps 3 --warmup 1 > $OUT/bench_config5_one_gpu_slab_path.json 2> /dev/null
-timeout 300 python3 bench.py --variant 3 --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_variant3_int16_field_round3_pipeline.json 2> /dev/null
-timeout 300 python3 bench.py --variant 2 --no-cpu-baseline --no-end-to-end --no-raycast > $OUT/bench1024_variant2_tiled_envelope.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-end-to-end --no-raycast --no-secondary > $OUT/bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-raycast --no-secondary > /dev/null 2>&1

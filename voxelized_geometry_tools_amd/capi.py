@@ -114,8 +114,6 @@ TESTING_SIGNATURES = {
     "vgt_hip_debug_finalize_check": (_int, [_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, _p, _p]),
     "vgt_hip_testing_set_host_pipeline_min_voxels": (_int, [ctypes.c_int64]),
     "vgt_hip_testing_set_short_line_rows": (_int, [_int]),
-    "vgt_hip_testing_set_sweep_hand_over": (_int, [_int]),
-    "vgt_hip_testing_set_sweep_coarse_hull": (_int, [_int]),
     "vgt_hip_testing_class_record_bytes": (_sz, [_i64, _i64, _i64]),
     "vgt_hip_testing_class_records_dev": (_int, [_p, _p, _i64, _i64, _i64, _int, _i64, _p, _p]),
 }
@@ -309,7 +307,7 @@ class Context:
         return out[:n.value].copy()
 
     def set_edt_variant(self, variant):
-        """Testing library only: 0 default, 1 / 2 / 3 the cross-check pipelines."""
+        """Testing library only: 0 default, 1 the cross-check pipeline (int16 Z scan + pruned search)."""
         if not self.testing:
             if int(variant) == 0:
                 return
@@ -324,16 +322,9 @@ class Context:
                                                           _ptr(summary_ptr)))
 
     def set_short_line_rows(self, rows):
-        """Testing library only: lines of at most `rows` rows take the short-line kernels (0 = sweeps everywhere)."""
+        """Testing library only: lines of at most `rows` rows take the short-line kernels whatever the item count
+        (0 = sweeps everywhere, negative = back to the product's rule)."""
         check(self._lib.vgt_hip_testing_set_short_line_rows(int(rows)))
-
-    def set_sweep_hand_over(self, on):
-        """Testing library only: whether short sweep launches hand over lower halves of their second sweeps."""
-        check(self._lib.vgt_hip_testing_set_sweep_hand_over(int(bool(on))))
-
-    def set_sweep_coarse_hull(self, on):
-        """Testing library only: whether the X pass builds a coarse hull in front of its sweep."""
-        check(self._lib.vgt_hip_testing_set_sweep_coarse_hull(int(bool(on))))
 
     def set_host_pipeline_min_voxels(self, min_voxels):
         """Testing library only (process-wide there): smallest grid the host-pointer SDF entry points pipeline."""

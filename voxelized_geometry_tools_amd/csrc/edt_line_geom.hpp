@@ -17,7 +17,6 @@ struct SweepGeom
   int groups;            // workgroup b draws from counter b % groups, which deals the outer indices = b (mod groups)
   int nwords;            // ceil(n / 32)
   int chunks;            // spill chunks per lane
-  int coarse_chunks;     // chunks per lane of the coarse hulls' area (sweeps with a coarse hull)
   int64_t row_stride;    // elements between consecutive rows
   int64_t outer_stride;  // elements between consecutive outer indices
   int nx, ny;

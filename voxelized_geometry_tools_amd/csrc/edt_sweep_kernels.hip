@@ -2,7 +2,7 @@
 //
 // One wave owns 64 neighbouring Z positions of one outer index; a lane owns one line of the pass axis and walks
 // it row by row, all lanes in lockstep, so every row access of the wave is one contiguous segment (256 B of
-// int32 / float, 128 B of int16) for both axes: no tile, no transpose, no partial cache lines on the store side.
+// int32 / float) for both axes: no tile, no transpose, no partial cache lines on the store side.
 // Each lane runs the Felzenszwalb-Huttenlocher stack algorithm (signed_distance_field_generation.cpp:124-226) on
 // its own line, in exact integer arithmetic:
 //
@@ -32,7 +32,7 @@
 //     along Z is the minimum over the transitions around it, one v_sad_u32 each.  Rows whose lines hold one class only
 //     are marked by pass 1 and cost a few scalar instructions per band of 16.
 //   * A site on or above the segment between its two neighbour rows' hull points is not on the lower hull and never
-//     touches the stack (X pass and the int16-fed Y pass of the cross-check pipelines).  A row that is no site is a hull
+//     touches the stack (X pass).  A row that is no site is a hull
 //     point far above every real one there (kNoSiteG): the same two comparisons handle it, no validity flags.
 //   * What the listing taught (profiles/r4/experiments.md): a row pays for exec-mask regions and scalar flag logic more
 //     than for vector instructions; a chunk of the ring is addressed ONCE (it never wraps), which turns its eight LDS
@@ -66,14 +66,6 @@ namespace
 #ifndef VGT_SWEEP_GROUP
 #define VGT_SWEEP_GROUP 2  // rows of the X pass's sweep 2 whose final conversions form one block of code (1, 2 or 4)
 #endif
-#ifndef VGT_SWEEP_EXP
-#define VGT_SWEEP_EXP 0
-#endif
-#ifndef VGT_STEAL_EXP
-// diagnostic builds of the hand-over: 1 = nobody helps (offers are made and withdrawn), 2 = helpers wait but never claim,
-// 4 = helpers claim and drop the task, 8 = helpers do the set-up only (4 and 8: wrong fields, timing only)
-#define VGT_STEAL_EXP 0
-#endif
 constexpr int kBand = VGT_SWEEP_BAND;    // rows held in registers at a time: 8, 16 or 32
 constexpr int kWord = 32;                // rows per sign word
 #ifndef VGT_SWEEP_RING_WIDE
@@ -89,25 +81,7 @@ constexpr int kWord = 32;                // rows per sign word
 #endif
 constexpr int kSweepGroups = VGT_SWEEP_GROUPS;  // work counters (= XCDs of an MI355X)
 constexpr int kCounterStride = 32;              // ints between two counters (128 bytes)
-// ---- Handing over the lower half of an item's second sweep (launches of at most two rounds of items; see SweepPassKernel)
-// The head of the scratch buffer: the work counters, then one `resolved` count, then per workgroup a task record.
-constexpr int kStealMinRows = 128;              // shorter lines are not worth a hand-over
-#ifndef VGT_COARSE_STRIDE
-#define VGT_COARSE_STRIDE 32
-#endif
-constexpr int kCoarseStride = VGT_COARSE_STRIDE;  // every how many rows the coarse hull takes one (a multiple of kBand)
-constexpr int kCoarseMinRows = 768;                // shorter lines: not worth the first sweep (512 rows: +-0, 256: +3 %)
 constexpr int kMaxSweepSlots = 4096;
-constexpr int kMaxXcc = 16;
-struct StealTask
-{
-  int state;   // kTaskNone -> kTaskOpen (the owner has published it) -> kTaskOwner / kTaskHelper (claimed)
-  int item;    // the item whose rows [0, split) are on offer
-  int flags;   // bit 0: class changes on some line of the wave, bit 1: some line without any site; bits 8..: the owner's XCC
-  int pad;
-};
-[[maybe_unused]] constexpr int kTaskNone = 0;
-constexpr int kTaskOpen = 1, kTaskOwner = 2, kTaskHelper = 3;
 template <bool kPacked>
 struct RingShape
 {
@@ -276,25 +250,6 @@ __device__ __forceinline__ int32_t Mad24Uniform(int32_t a, int32_t b_uniform, in
 #endif
 }
 
-// Calibration builds (-DVGT_SWEEP_BALLAST_S=n / -DVGT_SWEEP_BALLAST_V=n): n scalar / vector instructions of ballast per row of
-// either sweep -- what a pass pays per instruction of each kind (profiles/r4/experiments.md).
-#ifndef VGT_SWEEP_BALLAST_S
-#define VGT_SWEEP_BALLAST_S 0
-#endif
-#ifndef VGT_SWEEP_BALLAST_V
-#define VGT_SWEEP_BALLAST_V 0
-#endif
-[[maybe_unused]] __device__ __forceinline__ void RowBallast([[maybe_unused]] uint32_t& scalar_sink,
-                                                            [[maybe_unused]] uint32_t& vector_sink)
-{
-#ifndef VGT_HOST_EMULATION
-#pragma unroll
-  for (int i = 0; i < VGT_SWEEP_BALLAST_S; i++) asm volatile("s_cmp_eq_u32 0, 0" : : : "scc");  // (writes the condition bit only)
-#pragma unroll
-  for (int i = 0; i < VGT_SWEEP_BALLAST_V; i++) asm volatile("v_add_u32 %0, 1, %0" : "+v"(vector_sink));
-#endif
-}
-
 // A copy by an instruction of its own.  Sweep 2's rare pop moves its register pairs one place up (second <- third); written
 // as plain assignments the compiler renames the registers instead and pays for it with two copies per ROW on the path
 // that does not pop.
@@ -395,44 +350,6 @@ __device__ __forceinline__ uint32_t LowBits(int bits)  // bits in [0, 32]
 #define VGT_MAX3_F32(acc, a, b) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
 #endif
 
-#ifdef VGT_SWEEP_TIMING
-// diagnostic build (-DVGT_SWEEP_TIMING, tools/sweep_stats.py): item durations in 50-us bins (wall clock, 100 MHz),
-// [pass][class changes in the wave][bin], and when the waves ran out of work
-__device__ unsigned long long g_sweep_item_bins[2][2][32];
-__device__ unsigned long long g_sweep_exit[2][4];  // [pass]: first item start (min), last exit (max), sum of exits, waves
-#endif
-#ifdef VGT_SWEEP_PHASES
-// diagnostic build (-DVGT_SWEEP_PHASES, tools/sweep_phases.py): where a wave's time goes, in shader-clock ticks of s_memtime summed
-// over the waves (lane 0 adds): [0] sweep 1, waiting for the band's rows at the top of a band (all loads drained),
-// [1] sweep 1, the ring checks, [2] sweep 1, the rows, [3] sweep 2, the refill steps, [4] sweep 2, the rows,
-// [5] items (whole), [6] the first band's loads, [7] between the sweeps.  Read with vgt_hip_debug_sweep_stats.
-__device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X pass
-#define VGT_SWEEP_COUNT(i, v)
-#define VGT_PHASE_MARK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-// (summed in registers, added to the global counters once per item: an atomic per mark would be what gets measured)
-#define VGT_PHASE_ADD(i, from, to) phase_acc[i] += static_cast<unsigned long long>((to) - (from))
-#define VGT_PHASE_FLUSH()                                                                                \
-  do                                                                                                     \
-  {                                                                                                      \
-    if (lane == 0)                                                                                       \
-      for (int phase_i = 0; phase_i < 8; phase_i++) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + phase_i], phase_acc[phase_i]); \
-  } while (0)
-#define VGT_PHASE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#elif defined(VGT_SWEEP_STATS)
-// diagnostic build: [0] lane refills in sweep 1, [1] wave-level refill events in sweep 1, [2] / [3] the same in
-// sweep 2, [4] spilled chunks (lanes), [6] exact conversions (wave events), [7] / [8] wave-level pop iterations in
-// sweep 1 / 2, [9] waves with class changes, [10] waves, [11] / [12] lane pops in sweep 1 / 2, [13] lane pushes
-__device__ unsigned long long g_sweep_stats[32];  // [0..15] Y pass, [16..31] X pass
-#define VGT_SWEEP_COUNT(i, v) atomicAdd(&g_sweep_stats[(kFinal ? 16 : 0) + (i)], static_cast<unsigned long long>(v))
-#else
-#define VGT_SWEEP_COUNT(i, v)
-#endif
-#ifndef VGT_SWEEP_PHASES
-#define VGT_PHASE_MARK(var)
-#define VGT_PHASE_ADD(i, from, to)
-#define VGT_PHASE_DRAIN()
-#define VGT_PHASE_FLUSH()
-#endif
 
 // The wave's extrema (none when lo > hi) into minmax_enc[0 / 1], ordered encodings: one atomic pair per call.
 __device__ __forceinline__ void WaveMinMax(float lo_value, float hi_value, uint32_t* minmax_enc)
@@ -460,68 +377,11 @@ __device__ __forceinline__ void WaveMinMax(float lo_value, float hi_value, uint3
 #endif
 }
 
-// The hand-over protocol's words are shared by the workgroups of ONE XCC only, so they live in that XCC's L2: read-modify-
-// write atomics without the agent-scope bit execute there (global atomics never execute in a CU's L1).  They are READ the
-// same way, by an atomic add of zero that returns the word (written out: the compiler may turn an idempotent
-// read-modify-write into a load).  What was measured on the way (profiles/r5/experiments.md, 512^3, a 0.23 ms pass):
-// agent-scope loads go to memory and serialise there, 5.9 ms with every idle workgroup polling; loads below agent scope
-// are served by the CU's L1 for ever (a hang), and behind an L1 invalidate they were still stale often enough to send the
-// helpers' compare-and-swaps into a hot loop (10 ms); atomic reads by ALL idle workgroups serialise on the word (2.9 ms).
-// Hence: atomic reads, and only every eighth workgroup waits for offers (the others look once and leave).
-__device__ __forceinline__ int XccLoad([[maybe_unused]] const int* p)
-{
-#ifdef VGT_HOST_EMULATION
-  return *p;
-#else
-  int v;
-  const int zero = 0;
-  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
-  return v;
-#endif
-}
-__device__ __forceinline__ int XccAdd(int* p, int v)
-{
-#ifdef VGT_HOST_EMULATION
-  const int old = *p;
-  *p += v;
-  return old;
-#else
-  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-__device__ __forceinline__ bool XccCas(int* p, int expected, int desired)
-{
-#ifdef VGT_HOST_EMULATION
-  if (*p != expected) return false;
-  *p = desired;
-  return true;
-#else
-  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-
 // kPlain (X pass only): no virtual border and a resolution inside the fast conversion's range.
-// kSteal (testing library only; measured slower, see LaunchSweep): launches of at most two rounds of items (a pass then
-// lasts as long as its slowest items, and items differ 3x in duration: profiles/r5/item_durations.txt).  A workgroup that is on its LAST item flushes the stack to the scratch buffer
-// after sweep 1 and offers the lower half of sweep 2 -- rows [0, split) -- to workgroups that have run out of items: a
-// helper on the same XCC (same L2: the flushed stack needs no cross-L2 coherence) finds, per lane, the stack entry that
-// owns row split - 1 by bisection, takes the chunks around it into its own ring and evaluates downwards from there while
-// the owner evaluates rows [split, n); an offer nobody has taken when the owner reaches row `split` is withdrawn and the
-// owner carries on.  Same code, same arithmetic, same results whoever evaluates a row.
-// kCoarse (X pass, 32-bit entries; testing library only -- measured, see LaunchSweep): a COARSE HULL in front of the sweep.  On a sparse scene the X pass pushes 6.7 sites per
-// lane and 16 rows of which 2 stay -- the others are popped by sites far away, which no local test sees coming
-// (tools/sim/band_filter_sim.c).  So the line is swept twice: first every kCoarseStride-th row alone, through the same
-// stack code; the hull of that subsample (a dozen vertices per line on average) goes to the scratch, the stack starts
-// again, and in the sweep proper a row strictly above the chord between the two subsample vertices around it never
-// touches the stack -- it lies above a segment between two real sites, so it is no vertex of the line's hull, whatever
-// else the line holds.  In the simulation the rows on which ANY lane of a wave still needs the push / pop code fall from
-// 14.2 to 5.0 of 16 (D1, every 32nd row).
-template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain, bool kSteal, bool kCoarse>
+template <typename InT, typename OutT, bool kFinal, bool kPacked, bool kPlain>
 __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(const InT* __restrict__ in,
                                                                             OutT* __restrict__ out,
                                                                             unsigned char* __restrict__ spill,
-                                                                            unsigned char* __restrict__ coarse,
                                                                             uint2* __restrict__ word_info,
                                                                             uint32_t* __restrict__ minmax_enc,
                                                                             int* __restrict__ work_counter,
@@ -529,10 +389,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 {
   using C = Codec<kPacked>;
   using Entry = typename C::Entry;
-  // the Y pass reads class records (the default pipeline) or int16 distances along Z (the cross-check pipelines)
+  // the Y pass reads class records, the X pass the Y pass's int32 field
   constexpr bool kRecords = std::is_same<InT, ClassRecord>::value;
   static_assert(!(kRecords && kFinal), "records feed the Y pass");
-  static_assert(!kCoarse || (kFinal && kPacked && !kSteal), "the coarse hull is built for the X pass with 32-bit entries");
   constexpr int kRing = RingShape<kPacked>::kRing;
   constexpr int kChunk = RingShape<kPacked>::kChunk;
   constexpr int32_t kLimit = C::kSentinelG;  // values at or above: no site
@@ -552,33 +411,11 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // the lines it works on, so the scratch is sized by the number of workgroups in flight, not by the grid.
   unsigned char* const own_spill = spill + static_cast<int64_t>(blockIdx.x) * g.chunks * (kWaveSize * kChunkBytes);
   uint2* const own_info = word_info + static_cast<int64_t>(blockIdx.x) * (g.nwords + 1) * kWaveSize;
-  // (kCoarse: this slot's part of the coarse hulls' area, laid out like the spill area: chunks of kChunk entries per lane)
-  [[maybe_unused]] unsigned char* const own_coarse =
-      kCoarse ? coarse + static_cast<int64_t>(blockIdx.x) * g.coarse_chunks * (kWaveSize * kChunkBytes) : nullptr;
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
   float lo_value = INFINITY, hi_value = -INFINITY;
-  [[maybe_unused]] uint32_t ballast_s = 0, ballast_v = 0;
 #ifdef VGT_HOST_EMULATION
   int emulated_round = 0;
-#endif
-  // ---- kSteal: the hand-over of lower halves (see the comment above the kernel).  Behind the work counters: the count of
-  // workgroups whose offer is settled (made and claimed by someone, or never made), the open offers per XCC, the tasks ----
-  [[maybe_unused]] int* const steal_busy = work_counter + kSweepGroups * kCounterStride;  // [XCC]: workgroups at work
-  [[maybe_unused]] int* const steal_head = steal_busy + kMaxXcc * kCounterStride;  // [XCC], one cache line apart:
-  [[maybe_unused]] int* const steal_tail = steal_head + kMaxXcc * kCounterStride;  // offers taken from / put into the queue
-  [[maybe_unused]] StealTask* const steal_tasks = reinterpret_cast<StealTask*>(steal_tail + kMaxXcc * kCounterStride);
-  [[maybe_unused]] int* const steal_queue = reinterpret_cast<int*>(steal_tasks + kMaxSweepSlots);  // [XCC][kMaxSweepSlots]
-  [[maybe_unused]] const int steal_split = (n / 2) & ~(kWord - 1);  // rows [0, split) are handed over: whole sign words
-  [[maybe_unused]] int my_xcc = 0;
-  [[maybe_unused]] int next_item = -1;    // fetched ahead to learn whether the item at work is the last one
-  [[maybe_unused]] bool settled = false;  // this workgroup no longer counts as "at work" (or will not once its offer is claimed)
-#ifndef VGT_HOST_EMULATION
-  if constexpr (kSteal)
-  {
-    my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;  // hwreg(HW_REG_XCC_ID, 0, 4)
-    if (lane == 0) XccAdd(steal_busy + my_xcc * kCounterStride, 1);
-  }
 #endif
   [[maybe_unused]] auto fetch_item = [&]() -> int {
     int fetched = 0;
@@ -594,106 +431,18 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #endif
     return fetched;
   };
-  // An offer of this XCC, claimed for this workgroup (its index), or -1 when none can come any more: no workgroup of this
-  // XCC is at work.  (Workgroups that the dispatcher has not started yet are not counted: a helper that leaves early
-  // loses nothing but the chance to help -- an offer nobody takes is withdrawn by its owner.)  Offers queue up per XCC,
-  // and helpers draw TICKETS: ticket k waits for the k-th offer of the XCC, on a word of its own.  (A first version let
-  // every helper compare-and-swap the queue's head: with hundreds of helpers per XCC that is a quadratic number of atomics
-  // on one word, and a 0.23 ms pass took 3 ms.)
-  [[maybe_unused]] auto claim_offer = [&]() -> int {
-    int result = -1;
-#ifndef VGT_HOST_EMULATION
-    if (VGT_STEAL_EXP & 1) return -1;
-    if (lane == 0)
-    {
-      int* const busy = steal_busy + my_xcc * kCounterStride;
-      int* const queue = steal_queue + my_xcc * kMaxSweepSlots;
-      for (;;)
-      {
-        const int ticket = XccAdd(steal_head + my_xcc * kCounterStride, 1);
-        if (ticket >= kMaxSweepSlots) break;
-        int entry = 0;
-        int naps = 1;
-        for (int look = 0;; look++)
-        {
-          entry = XccLoad(queue + ticket);
-          if (entry != 0) break;
-          // (the count of workgroups at work is one word for everybody: looked at every fourth time)
-          if ((look & 3) == 0 && XccLoad(busy) <= 0) break;
-          for (int nap = 0; nap < naps; nap++) __builtin_amdgcn_s_sleep(127);  // 4 us at first, up to 32 us
-          if (naps < 8) naps *= 2;
-        }
-        if (entry == 0) break;  // nobody is at work: no offer will come
-        const int task = entry - 1;
-        if (!(VGT_STEAL_EXP & 2) && XccCas(&steal_tasks[task].state, kTaskOpen, kTaskHelper))
-        {
-          XccAdd(busy, -1);  // (the owner is settled: it will not offer again)
-          result = task;
-          break;
-        }
-        // (withdrawn: its owner got to the lower half first -- the next ticket)
-      }
-    }
-    result = __builtin_amdgcn_readfirstlane(result);
-#endif
-    return result;
-  };
   for (;;)
   {
   // ---- next unit of work: 64 neighbouring lines of one outer index ----
   int item = 0;
-  [[maybe_unused]] bool helping = false;   // kSteal: the lower half of another workgroup's item
-  [[maybe_unused]] int helped_flags = 0;
   unsigned char* wave_spill = own_spill;
   uint2* wave_info = own_info;
 #ifdef VGT_HOST_EMULATION
   item = static_cast<int>(blockIdx.x + gridDim.x * emulated_round++);  // (lanes run one after the other: fixed deal)
 #else
-  if constexpr (kSteal)
-  {
-    if (next_item >= 0)
-    {
-      item = next_item;
-      next_item = -1;
-    }
-    else
-      item = fetch_item();
-  }
-  else
-    item = fetch_item();
+  item = fetch_item();
 #endif
-  if (item >= g.items)
-  {
-    if constexpr (!kSteal)
-      break;
-    else
-    {
-      if (!settled)
-      {
-        // (no offer of this workgroup is or will be open: it never had an item, or its last one made none)
-        settled = true;
-        if (lane == 0) XccAdd(steal_busy + my_xcc * kCounterStride, -1);
-      }
-      const int task = claim_offer();
-      if (task < 0) break;
-      if (VGT_STEAL_EXP & 4) continue;  // (diagnostic: claimed and dropped -- wrong fields, timing only)
-      helping = true;
-      item = __builtin_amdgcn_readfirstlane(XccLoad(&steal_tasks[task].item));
-      helped_flags = __builtin_amdgcn_readfirstlane(XccLoad(&steal_tasks[task].flags));
-      // the owner's slot of the scratch buffer: its flushed stack and its sign words, read only from here on
-      wave_spill = spill + static_cast<int64_t>(task) * g.chunks * (kWaveSize * kChunkBytes);
-      wave_info = word_info + static_cast<int64_t>(task) * (g.nwords + 1) * kWaveSize;
-      asm volatile("" ::: "memory");
-    }
-  }
-#ifdef VGT_SWEEP_TIMING
-  const unsigned long long item_begin = wall_clock64();
-  if (lane == 0) atomicMin(&g_sweep_exit[kFinal ? 1 : 0][0], item_begin);
-#endif
-#ifdef VGT_SWEEP_PHASES
-  unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  VGT_PHASE_MARK(phase_item_begin);
+  if (item >= g.items) break;
   const int outer = item / g.zsegs;
   const int z0 = (item - outer * g.zsegs) * kWaveSize;
   // (a batch of grids: which grid, and the outer index inside it -- one grid: 0 and `outer`)
@@ -748,17 +497,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // chunks requested from the spill buffer at the last check (a refill_now of the same chunk drops them)
   Entry pf0[kChunk], pf1[kChunk];
   int pf_count = 0;
-  [[maybe_unused]] int stat_phase = 0;
   // the chunk that ends below entry lo comes back from the spill buffer (slow path: a run of pops reached it)
   auto refill_now = [&]() {
-#ifdef VGT_SWEEP_STATS
-    {
-      const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-      VGT_SWEEP_COUNT(stat_phase, 1);
-      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
-        VGT_SWEEP_COUNT(stat_phase + 1, 1);
-    }
-#endif
     L -= kChunkSlots;
     const Entry* src = spill_ptr(L);
     Entry* const slots = chunk_in_ring(L);
@@ -775,14 +515,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // of a site that is then pushed, and a push leaves the third entry in its register: a row's FIRST pop finds it there
   // (`third_in_register`), every further pop of the row reads the ring -- neither needs a test.
   auto pop = [&](auto third_in_register) {
-#ifdef VGT_SWEEP_STATS
-    {
-      const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-      VGT_SWEEP_COUNT(stat_phase == 0 ? 11 : 12, 1);
-      if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
-        VGT_SWEEP_COUNT(stat_phase == 0 ? 7 : 8, 1);
-    }
-#endif
     Gt += nB;
     rt -= A;
     if constexpr (decltype(third_in_register)::value)
@@ -815,7 +547,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Sweep 1: build the envelope.
   // =====================================================================================================
   uint32_t any_transition = 0;
-  if (!helping)  // (kSteal: a helper takes over a finished stack)
   {
     // every kChunk rows: the ring must have room for kChunk pushes
     auto check_ring = [&]() {
@@ -854,7 +585,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, L, j);
           StoreChunk(spill_ptr(L), buf);
           L += kChunkSlots;
-          VGT_SWEEP_COUNT(4, 1);
         }
       }
     };
@@ -892,7 +622,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
             } while (static_cast<int64_t>(dG) * A + static_cast<int64_t>(nB) * dr < 0);
           }
         }
-        VGT_SWEEP_COUNT(13, 1);
         ring_ref(D) = C::Pack(G, q);
         e3 = C::Pack(Gt + nB, rt - A);
         A = dr;
@@ -1066,6 +795,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     }
     else
     {
+      static_assert(kRecords || kFinal, "the X pass reads the Y pass's field");
       // Rows are loaded through a wave-uniform pointer that steps by the row stride, plus the lane's 32-bit offset: the
       // address of a row costs two scalar adds and no vector register (the readfirstlane keeps the compiler from folding
       // the lane offset into a per-lane 64-bit base, which costs a register pair and a 64-bit vector add per row).
@@ -1076,7 +806,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, lane_bytes) : &row_in[zl]));
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(LaneAddress(row_in, lane_bytes)));
             row_in = UniformPointer(row_in + rstride);
           }
         }
@@ -1086,38 +816,22 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(kFinal ? LaneAddress(row_in, lane_bytes) : &row_in[zl]));
+            dst[k] = static_cast<int32_t>(VGT_STREAM_LOAD(LaneAddress(row_in, lane_bytes)));
             if (first_row + k + 1 < n) row_in = UniformPointer(row_in + rstride);
           }
         }
       };
       int32_t nxt[kBand];
-      VGT_PHASE_MARK(phase_first_a);
       load_band(nxt, 0);
-      VGT_PHASE_DRAIN();
-      VGT_PHASE_MARK(phase_first_b);
-      VGT_PHASE_ADD(6, phase_first_a, phase_first_b);
       // Hull point of a row.  A row that is no site gets G = kNoSiteG + q^2: above every real hull point by more than any
       // site can make up before the last row (site()'s first test rejects it: kNoSiteG - G > 2 (n - 1)^2 for every real G of
       // either entry kind) and small enough that differences of two hull points never overflow.  So no row needs a "valid"
       // flag: the neighbour test below and site() see an ordinary, hopeless point.
       constexpr int32_t kNoSiteG = 0x60000000;
       auto decode = [&](int32_t v, int q, int32_t& G) {
-        // pass-1 distances are two's complement int16; the Y sweep hands its squared distances to the X sweep as
-        // sign and magnitude (bit 31 = class), which one `and` takes apart
-        int32_t f;
-        if constexpr (sizeof(InT) == 2)
-        {
-          const int32_t sign = v >> 31;
-          f = (v ^ sign) - sign;
-        }
-        else
-          f = v & 0x7fffffff;
-        // (pass-1 distances are below kInf16; the X pass's input holds squared distances below kLimit or kInf32)
-        if constexpr (sizeof(InT) == 2)
-          f = (f < static_cast<int32_t>(kInf16)) ? __mul24(f, f) : kNoSiteG;
-        else
-          f = static_cast<int32_t>(min(static_cast<uint32_t>(f), static_cast<uint32_t>(kNoSiteG)));
+        // the Y sweep hands its squared distances to the X sweep as sign and magnitude (bit 31 = class), which one `and`
+        // takes apart; they are below kLimit, or kInf32
+        const int32_t f = static_cast<int32_t>(min(static_cast<uint32_t>(v) & 0x7fffffffu, static_cast<uint32_t>(kNoSiteG)));
         G = f + q * q;
       };
       // A site whose hull point lies on or above the segment between its two NEIGHBOUR rows' points (2 G(q) >= G(q - 1) +
@@ -1126,224 +840,42 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       // successor -- that is every row but the ends.
       // (with "no site" as a huge hull point the test needs no flags: next to such a neighbour the site is kept, and a row
       // that is no site itself is dropped here or rejected by site())
-      // ---- kCoarse: the first sweep, over every kCoarseStride-th row, and what the sweep proper keeps of it ----
-      // cha / chb: the subsample hull's vertices around the band at work, as they lie in the scratch (chb: the next one
-      // ahead; "unknown" = none), chc: the one after chb, fetched a band or more before it is needed, ch_next its index.
-      [[maybe_unused]] Entry cha = C::Unknown(), chb = C::Unknown(), chc = C::Unknown();
-      [[maybe_unused]] int ch_next = 0;
-      [[maybe_unused]] bool coarse_synced = false;  // the coarse area's stores have been waited for (before the first load from it)
-      [[maybe_unused]] bool coarse_active = kCoarse;  // the filter is in use (not on lines it does nothing for)
-      [[maybe_unused]] auto coarse_entry = [&](int index) -> Entry {
-        const uint32_t chunk_first = static_cast<uint32_t>(index / kChunk) * kChunkSlots;
-        return reinterpret_cast<const Entry*>(own_coarse + (chunk_first + lane_chunk))[index % kChunk];
-      };
-      if constexpr (kCoarse)
-      {
-        static_assert(kCoarseStride % kBand == 0, "a band never holds two vertices of the subsample's hull");
-        VGT_PHASE_MARK(phase_coarse_a);
-        // (the first sweep spills into the coarse area, where its result is to lie anyway)
-        wave_spill = own_coarse;
-        constexpr int kBatch = 2 * kBand;  // subsample rows in flight at a time: one memory latency for a 1024-row line
-        for (int s0 = 0; s0 < n; s0 += kBatch * kCoarseStride)
-        {
-          int32_t sub[kBatch];
-          {
-            // (rows past the line's end repeat the last subsample row and are not used)
-            const int last_sub = (n - 1) / kCoarseStride * kCoarseStride;
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-            {
-              const int q = min(s0 + k * kCoarseStride, last_sub);
-              const VGT_GLOBAL InT* row_in = UniformPointer(GlobalPointer(wave_in + static_cast<int64_t>(q) * rstride));
-              sub[k] = static_cast<int32_t>(*LaneAddress(row_in, lane_bytes));
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < kBatch; k++)
-          {
-            const int q = s0 + k * kCoarseStride;
-            if (q < n)
-            {
-              if (k % kChunk == 0) check_ring();
-              int32_t G_sub;
-              decode(sub[k], q, G_sub);
-              site(q, G_sub, true);
-            }
-          }
-        }
-        // The subsample hull's first two vertices (entries 4 and 5: behind the sentinels) straight from the ring, where they
-        // still are unless the first sweep spilled (33 rows and the sentinels: rare) -- no round trip through memory at
-        // the start of the sweep proper.
-        const int coarse_depth = static_cast<int>(D >> kShift);
-        const bool in_ring = L == 0u;
-        // Where (nearly) every row of the subsample is a vertex of its hull the line is convex at that scale -- noise on top
-        // of row^2, or the smooth far field of a single obstacle -- and the rows in between are vertices too: the filter
-        // would remove nothing and is not consulted (a dense scene: X pass +9 % with it, profiles/r5/experiments.md).
-        {
-          const int subsample_rows = (n + kCoarseStride - 1) / kCoarseStride;
-          const uint64_t useful = __builtin_amdgcn_ballot_w64(4 * (coarse_depth - 4) <= 3 * subsample_rows);
-          coarse_active = __builtin_popcountll(useful) >= kWaveSize / 2;
-        }
-        if (coarse_depth > 4 && in_ring) chb = ring_ref(4u << kShift);
-        if (coarse_depth > 5 && in_ring) chc = ring_ref(5u << kShift);
-        ch_next = 5;
-        // the whole stack into the coarse area (the ring's entries join the chunks spilled on the way), "unknown" behind it
-        for (uint32_t first = L; __builtin_amdgcn_ballot_w64(first < D) != 0ull;)
-        {
-          if (first < D)
-          {
-            Entry buf[kChunk];
-            Entry* const slots = chunk_in_ring(first);
-#pragma unroll
-            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, first, j);
-            StoreChunk(spill_ptr(first), buf);
-            first += kChunkSlots;
-          }
-        }
-        {
-          const uint32_t chunk_first = static_cast<uint32_t>(coarse_depth / kChunk) * kChunkSlots;
-          reinterpret_cast<Entry*>(own_coarse + (chunk_first + lane_chunk))[coarse_depth % kChunk] = C::Unknown();
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_ring) != 0ull, 0))
-        {
-          VGT_COLD_PATH();
-#ifndef VGT_HOST_EMULATION
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (read back by the same lanes)
-#endif
-          if (!in_ring)
-          {
-            chb = coarse_entry(4);
-            if (!C::IsUnknown(chb)) chc = coarse_entry(5);
-          }
-          coarse_synced = true;
-        }
-        // the stack starts again
-        wave_spill = own_spill;
-        D = 4u << kShift;
-        L = 0;
-        Gt = C::kSentinelG;
-        nB = 1;
-        rt = 0;
-        A = 0;
-        e3 = C::Pack(C::kSentinelG + 2, 0);
-        pf_count = 0;
-        ring_ref(0u << kShift) = C::Pack(0, 0);
-        ring_ref(1u << kShift) = C::Pack(C::kSentinelG + 2, 0);
-        ring_ref(2u << kShift) = C::Pack(C::kSentinelG + 1, 0);
-        ring_ref(3u << kShift) = C::Pack(C::kSentinelG, 0);
-        VGT_PHASE_MARK(phase_coarse_b);
-        VGT_PHASE_ADD(7, phase_coarse_a, phase_coarse_b);
-      }
       int32_t G_prev = kNoSiteG, G_cur = 0;
       decode(nxt[0], 0, G_cur);
       for (int r0 = 0; r0 < n; r0 += kBand)
       {
         __builtin_assume(r0 >= 0 && r0 < 16384);
-        // (kCoarse) the chord over this band: from the vertex at or below its first row to the next one, which lies beyond
-        // its last row; no chord (width 0: the test below then never fires) before the first and behind the last vertex
-        [[maybe_unused]] int32_t chord_G = 0, chord_dG = 0;
-        [[maybe_unused]] int chord_row = 0, chord_width = 0;
-        if constexpr (kCoarse)
-        {
-          const bool arrived = static_cast<int>(!C::IsUnknown(chb)) & static_cast<int>(r0 >= C::Row(chb));
-          if (__builtin_amdgcn_ballot_w64(arrived) != 0ull)
-          {
-#ifndef VGT_HOST_EMULATION
-            if (!coarse_synced)
-            {
-              // (the first load from the coarse area: its stores -- issued a first sweep ago -- are waited for here, once)
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              coarse_synced = true;
-            }
-#endif
-            if (arrived)
-            {
-              cha = chb;
-              chb = chc;
-              if (!C::IsUnknown(chc))
-              {
-                ch_next++;
-                chc = coarse_entry(ch_next);
-              }
-            }
-          }
-          if (static_cast<int>(!C::IsUnknown(cha)) & static_cast<int>(!C::IsUnknown(chb)))
-          {
-            chord_G = C::G(cha);
-            chord_row = C::Row(cha);
-            chord_dG = C::G(chb) - chord_G;
-            chord_width = C::Row(chb) - chord_row;
-          }
-        }
         int32_t cur[kBand];
-        VGT_PHASE_MARK(phase_top_a);
-        VGT_PHASE_DRAIN();
-        VGT_PHASE_MARK(phase_top_b);
-        VGT_PHASE_ADD(0, phase_top_a, phase_top_b);
 #pragma unroll
         for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
         if (r0 + kBand < n) load_band(nxt, r0 + kBand);
         uint32_t bits = 0;  // sign bits of this band
-        auto rows = [&](auto guarded, auto filtered) {
+        auto rows = [&](auto guarded) {
           constexpr bool kGuard = decltype(guarded)::value;
-          constexpr bool kFiltered = decltype(filtered)::value;  // (kCoarse) the chord of the subsample's hull is consulted
 #pragma unroll
           for (int k = 0; k < kBand; k++)
           {
-            if (k % kChunk == 0)
-            {
-              VGT_PHASE_MARK(phase_ring_a);
-              check_ring();
-              VGT_PHASE_MARK(phase_ring_b);
-              VGT_PHASE_ADD(1, phase_ring_a, phase_ring_b);
-            }
+            if (k % kChunk == 0) check_ring();
             if (kGuard && r0 + k >= n) bits <<= 1;  // (keeps the rows of a partial band at their bit positions)
             if (!kGuard || r0 + k < n)
             {
               const int q = r0 + k;
-              if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0) RowBallast(ballast_s, ballast_v);
               // the class (bit 31 of either input format) is shifted in from the bottom by ONE instruction, (bits : v) >> 31;
               // the band's bits come out in reverse order and are turned round once per band below
               bits = __builtin_amdgcn_alignbit(bits, static_cast<uint32_t>(cur[k]), 31);
               int32_t G_next = kNoSiteG + (q + 1) * (q + 1);  // (past the last row: no site)
               // (every row of a full band but its last has a successor: no test)
               if ((!kGuard && k + 1 < kBand) || q + 1 < n) decode(k + 1 < kBand ? cur[k + 1] : nxt[0], q + 1, G_next);
-              if constexpr (kFiltered)
-              {
-                // strictly above the chord of the subsample's hull over this row: no vertex of the line's hull
-                const bool above = static_cast<int64_t>(G_cur - chord_G) * chord_width -
-                                       static_cast<int64_t>(chord_dG) * (q - chord_row) > 0;
-                site(q, G_cur, static_cast<int>(G_cur - G_prev < G_next - G_cur) & static_cast<int>(!above));
-              }
-              else
-                site(q, G_cur, G_cur - G_prev < G_next - G_cur);
+              site(q, G_cur, G_cur - G_prev < G_next - G_cur);
               G_prev = G_cur;
               G_cur = G_next;
             }
           }
         };
-        VGT_PHASE_MARK(phase_rows_a);
-        if constexpr (kCoarse)
-        {
-          // (A test of whole bands -- the band's smallest hull point against the chord's largest value over it -- in front of
-          // the per-row tests was measured too: it skips most bands of a sparse scene and is slower all the same, 2.41
-          // against 2.37 ms; profiles/r5/experiments.md.)
-          if (r0 + kBand > n)
-            rows(std::true_type{}, std::true_type{});
-          else if (coarse_active)
-            rows(std::false_type{}, std::true_type{});
-          else
-            rows(std::false_type{}, std::false_type{});
-        }
+        if (r0 + kBand <= n)
+          rows(std::false_type{});
         else
-        {
-          if (r0 + kBand <= n)
-            rows(std::false_type{}, std::false_type{});
-          else
-            rows(std::true_type{}, std::false_type{});
-        }
-        VGT_PHASE_MARK(phase_rows_b);
-        VGT_PHASE_ADD(2, phase_rows_a, phase_rows_b);
+          rows(std::true_type{});
         band_done(r0, __builtin_bitreverse32(bits));  // (row k of the band: bit kBand - 1 - k -> bit 32 - kBand + k)
       }
     }
@@ -1352,77 +884,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // =====================================================================================================
   // Sweep 2: evaluate, last row first.
   // =====================================================================================================
-  bool classes = (VGT_SWEEP_EXP & 2) ? false : (__builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull);
-  bool any_empty = __builtin_amdgcn_ballot_w64(D == (4u << kShift)) != 0ull;  // a line without any site
-  if constexpr (kSteal)
-  {
-    if (helping)
-    {
-      classes = (helped_flags & 1) != 0;
-      any_empty = (helped_flags & 2) != 0;
-    }
-  }
-#ifdef VGT_SWEEP_STATS
-  stat_phase = 2;
-  if (lane == 0)
-  {
-    VGT_SWEEP_COUNT(10, 1);
-    VGT_SWEEP_COUNT(9, classes ? 1 : 0);
-  }
-#endif
+  const bool classes = __builtin_amdgcn_ballot_w64(any_transition != 0u) != 0ull;
+  const bool any_empty = __builtin_amdgcn_ballot_w64(D == (4u << kShift)) != 0ull;  // a line without any site
   // No site on any of the wave's 64 lines and no class change along them (more than half of the Y pass's items on a sparse
   // scene: the slice holds no voxel whose Z line changes class): every row's result is "no voxel of the other class",
   // +-infinity by the line's class, and the evaluation is a fill from the sign words.  (The virtual border turns "none" into a finite distance: then the
   // general evaluation runs.)
   bool all_empty = !classes && __builtin_amdgcn_ballot_w64(D != (4u << kShift)) == 0ull;
   if constexpr (kFinal && !kPlain) all_empty = all_empty && !g.add_virtual_border;
-  [[maybe_unused]] bool offered = false;  // kSteal: rows [0, steal_split) of this item are on offer
-  if constexpr (kSteal)
-  {
-    if (helping) all_empty = false;  // (items that take the fill path make no offer)
-#ifndef VGT_HOST_EMULATION
-    if (!helping && !all_empty && n >= kStealMinRows)
-    {
-      next_item = fetch_item();
-      if (next_item >= g.items)
-      {
-        // The item at work is this workgroup's last one: the whole stack goes to the scratch buffer -- the ring's
-        // entries [lo, depth) join the chunks spilled earlier; the ring itself stays as it is -- with each lane's depth
-        // behind the sign words, and the lower half of the evaluation is offered to workgroups that have run out of items.
-        for (uint32_t first = L; __builtin_amdgcn_ballot_w64(first < D) != 0ull;)
-        {
-          if (first < D)
-          {
-            Entry buf[kChunk];
-            Entry* const slots = chunk_in_ring(first);
-#pragma unroll
-            for (int j = 0; j < kChunk; j++) buf[j] = chunk_slot(slots, first, j);
-            StoreChunk(spill_ptr(first), buf);
-            first += kChunkSlots;
-          }
-        }
-        StorePair(wave_info + static_cast<int64_t>(g.nwords) * kWaveSize + lane, D, 0u);
-        // (every store of this item -- spilled chunks, sign words, the flush -- has reached the L2 before the offer opens)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-        {
-          // (plain stores reach the L2 -- the L1 is write-through -- and are waited for before the offer opens)
-          StealTask* const mine = steal_tasks + blockIdx.x;
-          mine->item = item;
-          mine->flags = (classes ? 1 : 0) | (any_empty ? 2 : 0) | (my_xcc << 8);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          mine->state = kTaskOpen;
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          const int place = XccAdd(steal_tail + my_xcc * kCounterStride, 1);
-          steal_queue[my_xcc * kMaxSweepSlots + place] = static_cast<int>(blockIdx.x) + 1;
-        }
-        offered = true;
-        settled = true;  // (whoever claims the offer counts it)
-      }
-    }
-#endif
-  }
-  if (all_empty && !(VGT_SWEEP_EXP & 32))
+  if (all_empty)
   {
     const int nwords = g.nwords;
     VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));
@@ -1454,7 +924,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       }
     }
   }
-  else if (!(VGT_SWEEP_EXP & 8) || any_transition == 0x12345u)
+  else
   {
     // Every kStep rows the chunks requested at the last step go into the ring and up to two more are requested
     // when the ring has room (between two steps the ring only shrinks).
@@ -1485,52 +955,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     };
     constexpr int kStep = (kChunk < 8) ? 8 : kChunk;  // rows between two refill steps
 
-    if constexpr (kSteal)
-    {
-      if (helping)
-      {
-        // The stack as the owner left it, entries [0, depth) in its slot of the scratch buffer.  The entry that owns row
-        // split - 1: along a hull the members' values at a row fall, then rise -- bisection on "is the next one better".
-        const int q = steal_split - 1;
-        auto entry_at = [&](int index) -> Entry {
-          const uint32_t chunk_first = static_cast<uint32_t>(index / kChunk) * kChunkSlots;
-          return reinterpret_cast<const Entry*>(wave_spill + (chunk_first + lane_chunk))[index % kChunk];
-        };
-        const uint32_t depth_scaled = LoadPair(wave_info + static_cast<int64_t>(g.nwords) * kWaveSize + lane).x;
-        int lo_index = 3, hi_index = static_cast<int>(depth_scaled >> kShift) - 1;
-        while (__builtin_amdgcn_ballot_w64(lo_index < hi_index) != 0ull)
-        {
-          if (lo_index < hi_index)
-          {
-            const int mid = (lo_index + hi_index) >> 1;
-            const Entry a = entry_at(mid), b = entry_at(mid + 1);
-            const int32_t va = C::G(a) - 2 * q * C::Row(a), vb = C::G(b) - 2 * q * C::Row(b);
-            if (vb < va)
-              lo_index = mid + 1;
-            else
-              hi_index = mid;
-          }
-        }
-        // entries [lo, depth) with depth = owner's index + 1 and lo = the start of the owner's chunk: that chunk goes into
-        // the ring, everything below comes through the usual refills
-        D = static_cast<uint32_t>(lo_index + 1) << kShift;
-        L = static_cast<uint32_t>(lo_index / kChunk) * kChunkSlots;
-        {
-          const Entry* src = spill_ptr(L);
-          Entry* const slots = chunk_in_ring(L);
-#pragma unroll
-          for (int j = 0; j < kChunk; j++) chunk_slot(slots, L, j) = src[j];
-        }
-        const Entry top = ring_ref(D - kSlot);
-        Gt = C::G(top);
-        rt = C::Row(top);
-        if (D - 2 * kSlot < L) refill_now();
-        const Entry second = ring_ref(D - 2 * kSlot);
-        A = rt - C::Row(second);
-        nB = C::G(second) - Gt;
-        e3 = C::Unknown();
-      }
-    }
     if (C::IsUnknown(e3))  // (sweep 1 loads the third entry lazily)
     {
       if (D - 3 * kSlot < L) refill_now();
@@ -1546,14 +970,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     if (__builtin_expect(D - 4 * kSlot < L, 0)) refill_now();
     Entry e4 = ring_ref(D - 4 * kSlot);
     auto pop_down = [&]() {
-#ifdef VGT_SWEEP_STATS
-      {
-        const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-        VGT_SWEEP_COUNT(12, 1);
-        if (static_cast<unsigned>(lane) == static_cast<unsigned>(__ffsll(static_cast<long long>(active)) - 1))
-          VGT_SWEEP_COUNT(8, 1);
-      }
-#endif
       Gt += nB;
       rt -= A;
       A = FreshCopy(A2);
@@ -1576,58 +992,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     uint32_t xdn_word = 0, xup_word = 0;
     VGT_GLOBAL OutT* row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(n - 1) * rstride));  // row being evaluated
     const int last_band = (n - 1) / kBand * kBand;
-    int first_band = last_band;
-    if constexpr (kSteal)
-    {
-      if (helping)
-      {
-        // A helper begins at the top of the sign word below row `split`, as if it had just left the word above: that word,
-        // the word at work and the one below it in the three registers, and the distance from row `split` to the nearest
-        // row of the other class above it -- which the owner's walk would have carried down -- from the words above.
-        const int word_above = steal_split / kWord;
-        first_band = steal_split - kBand;
-        row_out = UniformPointer(GlobalPointer(wave_out + static_cast<int64_t>(steal_split - 1) * rstride));
-        info = LoadPair(wave_info + static_cast<int64_t>(word_above) * kWaveSize + lane);
-        info_below = LoadPair(wave_info + static_cast<int64_t>(word_above - 1) * kWaveSize + lane);
-        if (word_above >= 2) info_next = LoadPair(wave_info + static_cast<int64_t>(word_above - 2) * kWaveSize + lane);
-        if (classes)
-        {
-          const uint32_t mine = 0u - (info.x & 1u);  // class of row `split`, spread over a word
-          bool found = false;
-          for (int w = word_above; w < nwords; w++)
-          {
-            if (__builtin_amdgcn_ballot_w64(!found) == 0ull) break;
-            const uint32_t sw = LoadPair(wave_info + static_cast<int64_t>(w) * kWaveSize + lane).x;
-            const uint32_t other = (sw ^ mine) & LowBits(min(kWord, n - w * kWord));
-            if (!found && other != 0u)
-            {
-              dn = w * kWord + (__ffs(static_cast<int>(other)) - 1) - steal_split;
-              found = true;
-            }
-          }
-        }
-      }
-    }
-    for (int r0 = first_band; r0 >= 0; r0 -= kBand)
+    for (int r0 = last_band; r0 >= 0; r0 -= kBand)
     {
       __builtin_assume(r0 >= 0 && r0 < 16384);
-      if constexpr (kSteal)
-      {
-        if ((VGT_STEAL_EXP & 8) && helping) break;  // (diagnostic: set-up only)
-#ifndef VGT_HOST_EMULATION
-        if (offered && r0 == steal_split - kBand)
-        {
-          // rows [split, n) are done.  An offer nobody has taken is withdrawn: the owner carries on.
-          int mine = 0;
-          if (lane == 0)
-          {
-            mine = XccCas(&steal_tasks[blockIdx.x].state, kTaskOpen, kTaskOwner) ? 1 : 0;
-            if (mine) XccAdd(steal_busy + my_xcc * kCounterStride, -1);
-          }
-          if (!__builtin_amdgcn_readfirstlane(mine)) break;
-        }
-#endif
-      }
       const int sub = r0 & (kWord - 1);
       if (sub + kBand == kWord || r0 == last_band)
       {
@@ -1668,13 +1035,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = kBand - 1; k >= 0; k--)
         {
-          if (k % kStep == kStep - 1 && !(VGT_SWEEP_EXP & 4))
-          {
-            VGT_PHASE_MARK(phase_refill_a);
-            refill_step();
-            VGT_PHASE_MARK(phase_refill_b);
-            VGT_PHASE_ADD(3, phase_refill_a, phase_refill_b);
-          }
+          if (k % kStep == kStep - 1) refill_step();
           if (kClasses && k % 8 == 7)
           {
             const int first = sub + k - 7;  // position of the group's first row in the word
@@ -1692,13 +1053,12 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           {
             const int q = r0 + k;
             const int q2 = 2 * q;
-            if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0) RowBallast(ballast_s, ballast_v);
             // t1 = value of the second entry at row q minus the top's, t2 = the third's minus the second's
             // (rows and row differences are below 2^14: plain unsigned 24-bit multiplies)
             __builtin_assume(A >= 0 && A < 16384 && A2 >= 0 && A2 < 16384 && rt >= 0 && rt < 16384);
             int32_t t1 = Mad24Uniform(A, q2, nB);
             int32_t t2 = Mad24Uniform(A2, q2, nB2);
-            if (!(VGT_SWEEP_EXP & 16) && __builtin_expect(__builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull, 0))
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(t2 <= 0) != 0ull, 0))
             {
               do
               {
@@ -1754,13 +1114,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                     exact = !(g.resolution > 1.0e-30 && g.resolution < 1.0e30);
                   }
                   bool unsure;
-                  if (VGT_SWEEP_EXP & 1)
-                  {
-                    unsure = false;
-                    dist[j] = __uint_as_float(d2);
-                  }
-                  else
-                    dist[j] = FastSqrtTimesResolution(d2, g.resolution, unsure);
+                  dist[j] = FastSqrtTimesResolution(d2, g.resolution, unsure);
                   // no voxel of the other class anywhere: only on lines whose stack holds nothing but the sentinels, and
                   // waves with such a line run the copy of the band code that also has the class candidates
                   none[j] = kClasses && d2 >= static_cast<uint32_t>(kLimit);
@@ -1771,9 +1125,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_rare) != 0ull, 0))
                 {
                   VGT_COLD_PATH();  // keeps the block out of the straight-line code
-#ifdef VGT_SWEEP_STATS
-                  if (lane == 0) VGT_SWEEP_COUNT(6, 1);
-#endif
 #pragma unroll
                   for (int j = 0; j < kGroup; j++)
                   {
@@ -1814,40 +1165,20 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
               const int32_t d2 =
                   (kClasses && best >= static_cast<uint32_t>(kLimit)) ? kInf32 : static_cast<int32_t>(best);
               // (sign and magnitude, not two's complement: see sweep 1 of the X pass)
-#if VGT_SWEEP_EXP & 64
-              if (d2 == 0x12345679)  // (experiment: the evaluation without its stores)
-#endif
               VGT_STREAM_STORE(static_cast<OutT>(d2 | (sign & static_cast<int32_t>(0x80000000u))), LaneAddress(row_out, lane_bytes));
               row_out = UniformPointer(row_out - rstride);
             }
           }
         }
       };
-      VGT_PHASE_MARK(phase_eval_a);
       if (r0 + kBand > n)
         rows(std::true_type{}, std::true_type{});  // (the partial band: one copy, the candidates are "far" without classes)
       else if (classes || any_empty)
         rows(std::false_type{}, std::true_type{});
       else
         rows(std::false_type{}, std::false_type{});
-      VGT_PHASE_MARK(phase_eval_b);
-      VGT_PHASE_ADD(4, phase_eval_a, phase_eval_b);
       if (classes) dn = min(dn, kFar);
     }
-  }
-#ifdef VGT_SWEEP_TIMING
-  if (lane == 0)
-  {
-    const unsigned long long ticks = wall_clock64() - item_begin;  // 10 ns each
-    unsigned long long bin = ticks / 5000ull;
-    if (bin > 31ull) bin = 31ull;
-    atomicAdd(&g_sweep_item_bins[kFinal ? 1 : 0][classes ? 1 : 0][bin], 1ull);
-  }
-#endif
-  {
-    VGT_PHASE_MARK(phase_item_end);
-    VGT_PHASE_ADD(5, phase_item_begin, phase_item_end);
-    VGT_PHASE_FLUSH();
   }
   if constexpr (kFinal)
   {
@@ -1860,19 +1191,6 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     }
   }
   }  // next unit of work
-#ifdef VGT_SWEEP_TIMING
-  if (lane == 0)
-  {
-    const unsigned long long now = wall_clock64();
-    atomicMax(&g_sweep_exit[kFinal ? 1 : 0][1], now);
-    atomicAdd(&g_sweep_exit[kFinal ? 1 : 0][2], now);
-    atomicAdd(&g_sweep_exit[kFinal ? 1 : 0][3], 1ull);
-  }
-#endif
-  if constexpr (VGT_SWEEP_BALLAST_S + VGT_SWEEP_BALLAST_V > 0)
-  {
-    if (ballast_s + ballast_v == 0x12345u) lo_value = 0.0f;  // (keeps the sinks alive)
-  }
   if constexpr (kFinal)
   {
     uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
@@ -1890,19 +1208,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #ifdef VGT_HOST_EMULATION
 constexpr int64_t kSweepSlots = 3;  // (the CPU test wants slots that are used again and again)
 #else
-#ifndef VGT_SWEEP_SLOTS
-#define VGT_SWEEP_SLOTS 4096
+constexpr int64_t kSweepSlots = kMaxSweepSlots;
 #endif
-constexpr int64_t kSweepSlots = VGT_SWEEP_SLOTS;
-static_assert(kSweepSlots <= kMaxSweepSlots, "one task record per workgroup");
-#endif
-// Head of the scratch buffer: the work counters, each on its own cache line, then the hand-over protocol's words (one
-// workgroups at work and the offer queues' heads and tails per XCC, one task record per workgroup, the queues), cleared
-// before every launch.
-constexpr size_t kCounterBytes = ((kSweepGroups + 3 * kMaxXcc) * kCounterStride * sizeof(int) +
-                                  kMaxSweepSlots * sizeof(StealTask) + kMaxXcc * kMaxSweepSlots * sizeof(int) + 255) /
-                                 256 * 256;
-static_assert(sizeof(StealTask) == 16, "layout");
+// Head of the scratch buffer: the work counters, each on its own cache line, cleared before every launch.
+constexpr size_t kCounterBytes = (kSweepGroups * kCounterStride * sizeof(int) + 255) / 256 * 256;
 
 int64_t SpillChunks(int64_t n, int chunk) { return (n + 4 + chunk - 1) / chunk + 1; }
 
@@ -1912,15 +1221,6 @@ bool PackedEntries(int64_t n, int64_t max_input)
   return n <= 1024 && max_input + (n - 1) * (n - 1) < Codec<true>::kSentinelG;
 }
 
-// Chunks per lane and bytes per slot of the coarse hulls' area (32-bit entries, lines of kCoarseMinRows rows and more):
-// the subsample's hull at full depth, the sentinels, the "unknown" behind it.
-int64_t CoarseChunks(int64_t n) { return (n / kCoarseStride + 1 + 5 + RingShape<true>::kChunk - 1) / RingShape<true>::kChunk + 1; }
-size_t CoarseAreaBytes(int64_t n, bool packed)
-{
-  if (!packed || n < kCoarseMinRows) return 0;
-  return static_cast<size_t>(CoarseChunks(n)) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t);
-}
-
 // Scratch of one slot: the spill chunks of its 64 lines (every entry of a full-depth stack) and one (sign word, carry) pair
 // per 32 rows and lane.
 size_t SlotScratchBytes(int64_t n, bool packed)
@@ -1928,8 +1228,7 @@ size_t SlotScratchBytes(int64_t n, bool packed)
   const int64_t nwords = (n + kWord - 1) / kWord;
   const size_t spill = packed ? SpillChunks(n, RingShape<true>::kChunk) * kWaveSize * RingShape<true>::kChunk * sizeof(uint32_t)
                               : SpillChunks(n, RingShape<false>::kChunk) * kWaveSize * RingShape<false>::kChunk * sizeof(uint2);
-  // (+ one row: each lane's stack depth, for a hand-over)
-  return spill + static_cast<size_t>(nwords + 1) * kWaveSize * sizeof(uint2) + CoarseAreaBytes(n, packed);
+  return spill + static_cast<size_t>(nwords + 1) * kWaveSize * sizeof(uint2);
 }
 
 // Scratch of one pass: the work counters and the slots of the workgroups in flight, for the entry kind the extents call
@@ -1979,91 +1278,31 @@ hipError_t LaunchSweep(const InT* in, OutT* out, void* scratch, size_t scratch_b
   const size_t spill_bytes =
       static_cast<size_t>(slots) * g.chunks * kWaveSize * chunk * (packed ? sizeof(uint32_t) : sizeof(uint2));
   uint2* info = reinterpret_cast<uint2*>(bytes + kCounterBytes + spill_bytes);
-  // (behind the sign words: the coarse hulls' area of the slots, when the extents give it any)
-  unsigned char* coarse_area = reinterpret_cast<unsigned char*>(info) +
-                               static_cast<size_t>(slots) * (g.nwords + 1) * kWaveSize * sizeof(uint2);
-  g.coarse_chunks = static_cast<int>(CoarseChunks(g.n));
 #ifdef VGT_HOST_EMULATION
   *counter = 0;
 #endif
   const dim3 grid(static_cast<unsigned>(slots)), block(kWaveSize);
   // the plain X pass: no virtual border, resolution inside the range of the fast final conversion
   const bool general = kFinal && (g.add_virtual_border || !(g.resolution > 1.0e-30 && g.resolution < 1.0e30));
-  // Launches of at most two rounds of items hand over lower halves (kSteal): the pass lasts as long as its slowest items.
-  // MEASURED SLOWER (profiles/r5/experiments.md: 512^3 Y +27 %, X +17 %; the 8-rank slab shape +-0): the slots that fast
-  // items leave idle are not spare capacity -- the waves still at work speed up on the emptier chip, and helpers take that
-  // away from the slowest items.  Built, parity-tested (tests/test_gpu_sdf.py::test_sweep_hand_over_on_and_off) and kept
-  // in the testing library only, off unless vgt_hip_testing_set_sweep_hand_over turns it on.
-#if defined(VGT_HIP_TESTING) && !defined(VGT_HOST_EMULATION)
-  const bool steal = items <= 2 * slots && g.n >= kStealMinRows && SweepHandOver();
-#else
-  [[maybe_unused]] const bool steal = false;
-#endif
 #ifndef VGT_HOST_EMULATION
   {
-    // the work counters (and, for a hand-over launch, the protocol's words behind them) start at zero
-    const hipError_t err =
-        hipMemsetAsync(counter, 0, steal ? kCounterBytes : kSweepGroups * kCounterStride * sizeof(int), stream);
+    // the work counters start at zero
+    const hipError_t err = hipMemsetAsync(counter, 0, kSweepGroups * kCounterStride * sizeof(int), stream);
     if (err != hipSuccess) return err;
   }
 #endif
-  // The X pass with 32-bit entries on lines of kCoarseMinRows rows and more: a coarse hull in front of the sweep.
-  // MEASURED (profiles/r5/experiments.md): it removes 71 % of sweep 1's pops, 47 % of its pushes and 97 % of its
-  // synchronous refills on the 1024^3 headline -- and 4 % of the pass's time, while dense scenes and one-round launches
-  // lose 6 %: the pass is not bound by what the filter removes.  Built, parity-tested
-  // (tests/test_gpu_sdf.py::test_coarse_hull_on_and_off, the CPU emulation) and kept in the testing library only, off unless
-  // vgt_hip_testing_set_sweep_coarse_hull turns it on (diagnostic builds: -DVGT_SWEEP_COARSE_DEFAULT=1).
-#if (defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION) || VGT_SWEEP_COARSE_DEFAULT)
-  const bool coarse_hull = kFinal && packed && !steal && g.n >= kCoarseMinRows && SweepCoarseHull() &&
-                           CoarseAreaBytes(g.n, packed) > 0;
-#else
-  const bool coarse_hull = false;
-#endif
-#define VGT_LAUNCH_SWEEP_COARSE(PACKED, PLAIN, STEAL, COARSE)                                                         \
-  hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, PACKED, PLAIN, STEAL, COARSE>), grid, block, 0, stream, in, \
-                     out, spill, coarse_area, info, minmax_enc, counter, g)
-#define VGT_LAUNCH_SWEEP(PACKED, PLAIN, STEAL) VGT_LAUNCH_SWEEP_COARSE(PACKED, PLAIN, STEAL, false)
-#if (defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION) || VGT_SWEEP_COARSE_DEFAULT)
-  if constexpr (kFinal)
-  {
-    if (coarse_hull)
-    {
-      if (general)
-        VGT_LAUNCH_SWEEP_COARSE(true, false, false, true);
-      else
-        VGT_LAUNCH_SWEEP_COARSE(true, true, false, true);
-      return hipGetLastError();
-    }
-  }
-#else
-  (void)coarse_hull;
-#endif
-#if defined(VGT_HIP_TESTING) && !defined(VGT_HOST_EMULATION)
-  if (steal)
-  {
-    if (packed && general)
-      VGT_LAUNCH_SWEEP(true, !kFinal, true);
-    else if (packed)
-      VGT_LAUNCH_SWEEP(true, true, true);
-    else if (general)
-      VGT_LAUNCH_SWEEP(false, !kFinal, true);
-    else
-      VGT_LAUNCH_SWEEP(false, true, true);
-  }
+#define VGT_LAUNCH_SWEEP(PACKED, PLAIN)                                                                             \
+  hipLaunchKernelGGL((SweepPassKernel<InT, OutT, kFinal, PACKED, PLAIN>), grid, block, 0, stream, in, out, spill, info, \
+                     minmax_enc, counter, g)
+  if (packed && general)
+    VGT_LAUNCH_SWEEP(true, !kFinal);
+  else if (packed)
+    VGT_LAUNCH_SWEEP(true, true);
+  else if (general)
+    VGT_LAUNCH_SWEEP(false, !kFinal);
   else
-#endif
-  {
-    if (packed && general)
-      VGT_LAUNCH_SWEEP(true, !kFinal, false);
-    else if (packed)
-      VGT_LAUNCH_SWEEP(true, true, false);
-    else if (general)
-      VGT_LAUNCH_SWEEP(false, !kFinal, false);
-    else
-      VGT_LAUNCH_SWEEP(false, true, false);
-  }
+    VGT_LAUNCH_SWEEP(false, true);
 #undef VGT_LAUNCH_SWEEP
-#undef VGT_LAUNCH_SWEEP_COARSE
   return hipGetLastError();
 }
 
@@ -2086,18 +1325,6 @@ size_t SweepPassScratchBytes(int64_t nx, int64_t ny, int64_t nz, int64_t batch)
   const size_t y = PassScratchBytes(ny, batch * nx * zsegs, max_y), x = PassScratchBytes(nx, batch * ny * zsegs, max_x);
   return (y > x ? y : x) + 256;
 }
-
-#if defined(VGT_HIP_TESTING) || defined(VGT_HOST_EMULATION)
-// Y pass fed by the int16 distance field of the cross-check pipelines (EdtVariant::kDistanceField).
-hipError_t LaunchPassYSweep(const int16_t* in16, int32_t* out32, SweepScratch scratch, const SdfParams& p,
-                            hipStream_t stream)
-{
-  int64_t outer_count = 0;
-  const SweepGeom g = SweepGeometry(p, 1, &outer_count);
-  return LaunchSweep<int16_t, int32_t, false>(in16, out32, scratch.ptr, scratch.bytes, nullptr, g, outer_count,
-                                              MaxInputY(p), stream);
-}
-#endif
 
 // Y pass of the default pipeline: class records (pass 1, edt_record_kernels.hip) of p.nx slices -> int32.
 // `records` must be followed by kRecordPadding readable records (vgt_internal.hpp: the block loads run up to 191 rows
@@ -2150,33 +1377,4 @@ hipError_t LaunchPassXSweepFinalize(const int32_t* in32, float* sdf, uint32_t* m
 
 }  // namespace vgt
 
-#ifdef VGT_SWEEP_TIMING
-extern "C" __attribute__((visibility("default"))) int vgt_hip_debug_sweep_items(unsigned long long* bins128, unsigned long long* exit8, int reset)
-{
-  hipError_t err = hipDeviceSynchronize();
-  if (err == hipSuccess) err = hipMemcpyFromSymbol(bins128, HIP_SYMBOL(vgt::g_sweep_item_bins), 128 * sizeof(unsigned long long));
-  if (err == hipSuccess) err = hipMemcpyFromSymbol(exit8, HIP_SYMBOL(vgt::g_sweep_exit), 8 * sizeof(unsigned long long));
-  if (err == hipSuccess && reset)
-  {
-    unsigned long long zeros[128] = {0};
-    err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_item_bins), zeros, sizeof(zeros));
-    unsigned long long init[8] = {~0ull, 0, 0, 0, ~0ull, 0, 0, 0};
-    if (err == hipSuccess) err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_exit), init, sizeof(init));
-  }
-  return err == hipSuccess ? 0 : 2;
-}
-#endif
 
-#if defined(VGT_SWEEP_STATS) || defined(VGT_SWEEP_PHASES)
-extern "C" __attribute__((visibility("default"))) int vgt_hip_debug_sweep_stats(unsigned long long* out32, int reset)
-{
-  hipError_t err = hipDeviceSynchronize();
-  if (err == hipSuccess) err = hipMemcpyFromSymbol(out32, HIP_SYMBOL(vgt::g_sweep_stats), 32 * sizeof(unsigned long long));
-  if (err == hipSuccess && reset)
-  {
-    unsigned long long zeros[32] = {0};
-    err = hipMemcpyToSymbol(HIP_SYMBOL(vgt::g_sweep_stats), zeros, sizeof(zeros));
-  }
-  return err == hipSuccess ? 0 : 2;
-}
-#endif

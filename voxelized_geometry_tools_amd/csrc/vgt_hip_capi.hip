@@ -937,7 +937,7 @@ int vgt_hip_device_of(const vgt_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
 /* Testing builds only (libvgt_hip_testing.so; declared in vgt_hip.h under VGT_HIP_TESTING). */
 int vgt_hip_set_edt_variant(vgt_hip_ctx* ctx, int variant)
 {
-  if (!ctx || variant < 0 || variant > 3) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
+  if (!ctx || variant < 0 || variant > 1) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "invalid EDT variant");
   ctx->variant = static_cast<vgt::EdtVariant>(variant);
   return VGT_HIP_OK;
 }
@@ -974,18 +974,6 @@ int vgt_hip_testing_set_host_pipeline_min_voxels(int64_t min_voxels)
 int vgt_hip_testing_set_short_line_rows(int rows)
 {
   vgt::SetShortLineRows(rows);
-  return VGT_HIP_OK;
-}
-
-int vgt_hip_testing_set_sweep_hand_over(int on)
-{
-  vgt::SetSweepHandOver(on != 0);
-  return VGT_HIP_OK;
-}
-
-int vgt_hip_testing_set_sweep_coarse_hull(int on)
-{
-  vgt::SetSweepCoarseHull(on != 0);
   return VGT_HIP_OK;
 }
 
@@ -1464,7 +1452,7 @@ size_t vgt_hip_sdf_workspace_bytes(int64_t nx, int64_t ny, int64_t nz)
 
 size_t vgt_hip_sdf_workspace_bytes_for_variant(int64_t nx, int64_t ny, int64_t nz, int variant)
 {
-  if (nx <= 0 || ny <= 0 || nz <= 0 || variant < 0 || variant > 3) return 0;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || variant < 0 || variant > 1) return 0;
 #ifndef VGT_HIP_TESTING
   if (variant != 0) return 0;  // the cross-check variants are not part of this build
 #endif

@@ -27,8 +27,8 @@ hipStream_t ContextStream(const vgt_hip_ctx* ctx);
 //                      voxels along Z to the nearest voxel of the OTHER class,
 //                      |value| == kInf16 when the line holds no such voxel.
 //  pass 2 (Y pass)  -> int32: +-(squared distance in the YZ plane), kInf32 when none (two's complement between the
-//                      tiled-envelope / brute-force passes, sign and magnitude between the sweep passes: the Y and X
-//                      passes of one extraction are always of the same variant).
+//                      brute-force passes, sign and magnitude between the sweep passes: the Y and X passes of one
+//                      extraction are always of the same variant).
 //  pass 3 (X pass)  -> float SDF.
 constexpr int16_t kInf16 = 32767;
 constexpr int32_t kInf32 = 0x7fffffff;
@@ -112,12 +112,11 @@ struct SlabLineCarry
 };
 
 // kDefault: class records (pass 1, edt_record_kernels.hip) + lane-per-line sweep passes, Felzenszwalb-Huttenlocher
-// stacks with their tops in LDS (edt_sweep_kernels.hip; any extent).  The others exist for cross-checking and share the
-// Z scan to an int16 distance field (edt_kernels.hip): kBruteForce: pruned outward search straight from HBM; kHull:
-// LDS-tiled lower-envelope passes (band hulls + merge, edt_hull_kernels.hip; axes up to 2048, longer ones fall back to
-// the pruned search); kDistanceField: the sweep passes fed by the int16 field (the default of earlier versions).  All exact.
-enum class EdtVariant : int { kDefault = 0, kBruteForce = 1, kHull = 2, kDistanceField = 3 };
-inline bool IsSweepVariant(EdtVariant v) { return v == EdtVariant::kDefault || v == EdtVariant::kDistanceField; }
+// stacks with their tops in LDS (edt_sweep_kernels.hip; any extent).  kBruteForce (testing library only): the one
+// independent cross-check -- an int16 Z scan and a pruned outward search per voxel straight from HBM (edt_kernels.hip).
+// Both exact.  (Earlier rounds' other pipelines -- LDS-tiled envelopes, the int16-fed sweeps -- are in the git history
+// and profiles/r2 ... r5/experiments.md.)
+enum class EdtVariant : int { kDefault = 0, kBruteForce = 1 };
 
 // --- launchers (edt_kernels.hip).  All asynchronous on `stream`. ---
 // Z scan: occupancy (float) or mask (u8) -> int16 signed 1-D distance.
@@ -162,35 +161,29 @@ hipError_t LaunchPassXFinalize(const int32_t* in32, float* sdf, uint32_t* minmax
                                SweepScratch scratch, const SdfParams& p, EdtVariant variant,
                                hipStream_t stream);
 // Lines of at most kShortLineRows rows take the short-line kernels (edt_short_kernels.hip: the whole line in registers,
-// exhaustive search) instead of the sweeps; same encodings, same results.  ShortLineRows() is the limit in force:
-// kShortLineRows, or what a testing build was told (vgt_hip_testing_set_short_line_rows; 0 = sweeps for every length).
+// exhaustive search) instead of the sweeps; same encodings, same results.  ShortLineRows() is the limit in force for
+// the X pass: kShortLineRows, or what a testing build was told (vgt_hip_testing_set_short_line_rows; 0 = sweeps for
+// every length); ShortLineLimit(items) the Y pass's.
 constexpr int kShortLineRows = 64;
 // ... and lines of up to kShortLineRowsFewItems rows when the launch has so few items (at most kFewLineItems bundles of
 // 64 lines) that the sweeps would leave most of the chip idle: the search costs O(rows^2) but splits over the waves.
 constexpr int kShortLineRowsFewItems = 128;
 constexpr int64_t kFewLineItems = 1024;
-int ShortLineRows();
-// Whether sweep launches of at most two rounds of items hand over lower halves of their second sweeps: never in the
-// product (measured slower, edt_sweep_kernels.hip), in a testing build when vgt_hip_testing_set_sweep_hand_over says so.
-bool SweepHandOver();
-// Whether the X pass builds a coarse hull in front of its sweep (edt_sweep_kernels.hip, kCoarse): never in the product
-// (measured: -4 % on the 1024^3 headline, +6 % on dense scenes and on one-round launches; profiles/r5/experiments.md), in a
-// testing build when vgt_hip_testing_set_sweep_coarse_hull says so.
-bool SweepCoarseHull();
-#ifndef VGT_SWEEP_COARSE_DEFAULT
-#define VGT_SWEEP_COARSE_DEFAULT 0
-#endif
-constexpr bool kSweepCoarseHullDefault = VGT_SWEEP_COARSE_DEFAULT != 0;
+// What a testing build was told (vgt_hip_testing_set_short_line_rows), -1 = nothing (the product library: always).
+int ShortLineOverride();
+inline int ShortLineRows()
+{
+  const int told = ShortLineOverride();
+  return told >= 0 ? told : kShortLineRows;
+}
 inline int ShortLineLimit(int64_t items)
 {
-  const int rows = ShortLineRows();
-  if (rows != kShortLineRows) return rows;  // (a testing build was told: that limit, whatever the item count)
+  const int told = ShortLineOverride();
+  if (told >= 0) return told;  // (a testing build was told: that limit, whatever the item count)
   return items <= kFewLineItems ? kShortLineRowsFewItems : kShortLineRows;
 }
 #ifdef VGT_HIP_TESTING
-void SetShortLineRows(int rows);
-void SetSweepHandOver(bool on);
-void SetSweepCoarseHull(bool on);
+void SetShortLineRows(int rows);  // 0 ... kShortLineRowsFewItems; negative: back to the defaults
 #endif
 hipError_t LaunchPassYShortRecords(const ClassRecord* records, int32_t* out32, const SdfParams& p, hipStream_t stream);
 hipError_t LaunchPassXShortFinalizeRange(const int32_t* in32, float* sdf, uint32_t* minmax_enc, const SdfParams& p,
