@@ -154,6 +154,8 @@ int vgt_hip_filter_grid_create_deferred(vgt_hip_ctx* ctx, int64_t num_cells,
                                         const float* occupancy_host, vgt_hip_filter** out_filter);
 void vgt_hip_filter_grid_destroy(vgt_hip_filter* filter);
 int64_t vgt_hip_filter_grid_num_cells(const vgt_hip_filter* filter);
+/* The grid's device buffer.  Waits for a deferred upload first (the pointer is then usable on any stream); NULL, with the
+ * reason in vgt_hip_last_error(), when that wait fails. */
 void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter);
 
 /* DeviceVoxelizationHelperInterface::FilterTrackingGrids

@@ -71,6 +71,12 @@ public:
 
 private:
   void EnforceAvailable() const;
+  // both overloads; before_download (optional) runs after the filter kernel is enqueued and before the download starts
+  VoxelizerRuntime DoVoxelizePointClouds(const OccupancyMap& static_environment,
+                                         const PointCloudVoxelizationFilterOptions& filter_options,
+                                         const std::vector<PointCloudWrapperSharedPtr>& pointclouds,
+                                         OccupancyMap& output_environment,
+                                         const std::function<void()>& before_download) const;
   std::unique_ptr<DeviceVoxelizationHelperInterface> helper_interface_;
   std::string device_name_ = "HipPointCloudVoxelizer";
   int dispatch_threads_ = 1;

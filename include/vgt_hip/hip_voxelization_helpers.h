@@ -8,9 +8,12 @@
 //   HIP_DEVICE             device index, default 0
 //   HIP_THREADS_PER_BLOCK  threads per workgroup of the raycast / filter kernels; not given: 256, and 512 for the
 //                          raycast kernel of large (direction-sorted) clouds
-//   HIP_EXACT_FP64         1: filter ratio in double, as the reference's CPU voxelizer
-//                          (pointcloud_voxelization_interface.hpp:55-86); default 0 (float,
-//                          as the reference's device kernels)
+//   HIP_EXACT_FP64         1: the arithmetic of the reference's CPU voxelizer -- the rays are walked in float64 from double
+//                          points and transforms (cpu_pointcloud_voxelization.cpp:167-206,208-436; the helper's
+//                          ExactRaycastInterface, which HipPointCloudVoxelizer feeds through
+//                          CopyPointLocationIntoDoublePtr) and the filter's ratio is a double
+//                          (pointcloud_voxelization_interface.hpp:55-86); default 0 (float32 walk and ratio, as the
+//                          reference's device kernels)
 #pragma once
 
 #include <cstdint>
@@ -51,6 +54,21 @@ class DeferredFilterGridInterface
 public:
   virtual ~DeferredFilterGridInterface() {}
   virtual std::unique_ptr<FilterGridHandle> PrepareFilterGridDeferred(int64_t num_cells, const void* host_data_ptr) = 0;
+};
+
+// Extension of the plugin interface implemented by the HIP helper: the float64 walk of the reference's CPU voxelizer on the
+// device (vgt_hip_raycast_points_f64).  ExactFp64(): whether the helper was made with HIP_EXACT_FP64 -- a caller that
+// wants CPU-voxelizer-identical grids then hands its points over as doubles.  Discovered with dynamic_cast on the helper.
+class ExactRaycastInterface
+{
+public:
+  virtual ~ExactRaycastInterface() {}
+  virtual bool ExactFp64() const = 0;
+  virtual void RaycastPointsExact(
+      const std::vector<double>& raw_points, double max_range, const double* grid_pointcloud_transform,
+      double voxel_size, double inverse_voxel_size, double grid_x_size, double grid_y_size, double grid_z_size,
+      int32_t num_x_voxels, int32_t num_y_voxels, int32_t num_z_voxels, TrackingGridsHandle& tracking_grids,
+      size_t tracking_grid_index) = 0;
 };
 
 std::vector<AvailableDevice> GetAvailableDevices();

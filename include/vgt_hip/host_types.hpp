@@ -16,6 +16,8 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace vgt_hip
@@ -87,6 +89,31 @@ struct Isometry3
   }
 };
 
+// std::allocator whose value-less construct() leaves the memory as it is: a vector sized through it has its elements'
+// storage but has not touched a page of it (DenseGrid::UninitializedLike: a map whose every cell a download overwrites).
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T>
+{
+  template <typename U>
+  struct rebind
+  {
+    using other = DefaultInitAllocator<U>;
+  };
+  DefaultInitAllocator() = default;
+  template <typename U>
+  DefaultInitAllocator(const DefaultInitAllocator<U>&) noexcept {}
+  template <typename U>
+  void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value)
+  {
+    ::new (static_cast<void*>(p)) U;  // default-, not value-initialised: a no-op for float
+  }
+  template <typename U, typename... Args>
+  void construct(U* p, Args&&... args)
+  {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+
 // Dense X-major / Z-fastest grid of floats with a uniform voxel size: the part of
 // OccupancyMap (occupancy_map.hpp:65-217) and SignedDistanceField<float>
 // (signed_distance_field.hpp:193-789) that the hot path touches.
@@ -102,6 +129,22 @@ public:
     if (!(resolution > 0.0) || num_x <= 0 || num_y <= 0 || num_z <= 0)
       throw std::invalid_argument("Grid must have positive resolution and voxel counts");
     data_.assign(static_cast<size_t>(num_x * num_y * num_z), default_value);
+  }
+  // A grid with the frame, transform and extents of `other` whose cells are NOT initialised -- not even touched: for a
+  // caller that overwrites every cell (the by-value VoxelizePointClouds, whose result the download fills) and does not
+  // want to pay for a copy and its page faults first.
+  static DenseGrid UninitializedLike(const DenseGrid& other)
+  {
+    DenseGrid grid;
+    grid.origin_ = other.origin_;
+    grid.inverse_origin_ = other.inverse_origin_;
+    grid.frame_ = other.frame_;
+    grid.resolution_ = other.resolution_;
+    grid.nx_ = other.nx_;
+    grid.ny_ = other.ny_;
+    grid.nz_ = other.nz_;
+    grid.data_.resize(other.data_.size());
+    return grid;
   }
   // VoxelGridSizes::FromGridSizes: counts = size / resolution
   static DenseGrid FromGridSizes(const Isometry3& origin_transform, const std::string& frame,
@@ -146,15 +189,16 @@ public:
     if (!IndexInBounds(x, y, z)) throw std::runtime_error("index out of grid bounds");
     data_[static_cast<size_t>((x * ny_ + y) * nz_ + z)] = value;
   }
-  const std::vector<float>& GetImmutableRawData() const { return data_; }
-  std::vector<float>& GetMutableRawData() { return data_; }
+  using Storage = std::vector<float, DefaultInitAllocator<float>>;
+  const Storage& GetImmutableRawData() const { return data_; }
+  Storage& GetMutableRawData() { return data_; }
 
 private:
   Isometry3 origin_, inverse_origin_;
   std::string frame_;
   double resolution_ = 0.0;
   int64_t nx_ = 0, ny_ = 0, nz_ = 0;
-  std::vector<float> data_;
+  Storage data_;
 };
 
 using OccupancyMap = DenseGrid;
@@ -300,6 +344,12 @@ public:
     if (point_index < 0 || point_index >= Size()) throw std::out_of_range("point_index out of range");
     CopyPointLocationIntoFloatPtrImpl(point_index, destination);
   }
+  // (pointcloud_voxelization_interface.hpp:117-133: what the reference's CPU voxelizer reads its points through)
+  void CopyPointLocationIntoDoublePtr(int64_t point_index, double* destination) const
+  {
+    if (point_index < 0 || point_index >= Size()) throw std::out_of_range("point_index out of range");
+    CopyPointLocationIntoDoublePtrImpl(point_index, destination);
+  }
 
   // Extension: a wrapper whose points sit in one buffer of fixed-size records
   // with x, y, z as consecutive FLOAT32 reports the layout, and the HIP voxelizer raycasts the
@@ -314,6 +364,14 @@ public:
 
 protected:
   virtual void CopyPointLocationIntoFloatPtrImpl(int64_t point_index, float* destination) const = 0;
+  // Default: the float location widened -- exact for clouds whose storage is FLOAT32 (PointCloud2); a wrapper that
+  // stores doubles overrides it (the reference declares it pure, pointcloud_voxelization_interface.hpp:193-199).
+  virtual void CopyPointLocationIntoDoublePtrImpl(int64_t point_index, double* destination) const
+  {
+    float xyz[3];
+    CopyPointLocationIntoFloatPtrImpl(point_index, xyz);
+    for (int a = 0; a < 3; a++) destination[a] = static_cast<double>(xyz[a]);
+  }
 };
 using PointCloudWrapperSharedPtr = std::shared_ptr<PointCloudWrapper>;
 

@@ -10,6 +10,7 @@
 #include <limits>
 
 #include "../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
+#include "../../oracle/vgt_oracle.h"  // the checker of the CPU-exact mode (test infrastructure: oracle/ never ships)
 
 using namespace vgt_hip;
 namespace hip_helpers = voxelized_geometry_tools::pointcloud_voxelization::hip_helpers;
@@ -320,9 +321,42 @@ private:
   {
     for (int a = 0; a < 3; a++) dst[a] = static_cast<float>(points_[static_cast<size_t>(i)][a]);
   }
+  void CopyPointLocationIntoDoublePtrImpl(int64_t i, double* dst) const override
+  {
+    for (int a = 0; a < 3; a++) dst[a] = points_[static_cast<size_t>(i)][a];
+  }
   std::vector<std::array<double, 3>> points_;
   Isometry3 origin_;
 };
+
+// The reference's CPU voxelizer, as the oracle restates it (oracle/vgt_oracle.c: the float64 walk of
+// cpu_pointcloud_voxelization.cpp:167-206,208-436 and the double-ratio filter of :438-497), on the clouds of a scene.
+static OccupancyMap OracleCpuVoxelization(const OccupancyMap& static_environment,
+                                          const PointCloudVoxelizationFilterOptions& filter_options,
+                                          const std::vector<PointCloudWrapperSharedPtr>& clouds)
+{
+  const int64_t cells = static_environment.NumTotalVoxels();
+  const size_t num_grids = std::max<size_t>(clouds.size(), 1);
+  std::vector<int32_t> tracking(static_cast<size_t>(2 * cells) * num_grids, 0);
+  for (size_t c = 0; c < clouds.size(); c++)
+  {
+    const PointCloudWrapper& cloud = *clouds[c];
+    if (cloud.Size() <= 0) continue;
+    const Isometry3 X_GC = static_environment.InverseOriginTransform() * cloud.PointCloudOriginTransform();
+    std::vector<double> points(static_cast<size_t>(cloud.Size()) * 3);
+    for (int64_t i = 0; i < cloud.Size(); i++) cloud.CopyPointLocationIntoDoublePtr(i, points.data() + 3 * i);
+    vgt_oracle_raycast_f64(points.data(), cloud.Size(), cloud.MaxRange(), X_GC.m.data(), static_environment.VoxelXSize(),
+                           1.0 / static_environment.VoxelXSize(), static_environment.GridXSize(),
+                           static_environment.GridYSize(), static_environment.GridZSize(), static_environment.NumXVoxels(),
+                           static_environment.NumYVoxels(), static_environment.NumZVoxels(),
+                           tracking.data() + c * static_cast<size_t>(2 * cells), 1);
+  }
+  OccupancyMap filtered = static_environment;
+  vgt_oracle_filter(tracking.data(), cells, static_cast<int32_t>(num_grids), filter_options.PercentSeenFree(),
+                    filter_options.OutlierPointsThreshold(), filter_options.NumCamerasSeenFree(), 1,
+                    filtered.GetMutableRawData().data(), 1);
+  return filtered;
+}
 
 static void check_empty_voxelization(const OccupancyMap& occupancy)
 {
@@ -451,6 +485,30 @@ static void PointCloudVoxelizationTests(int dispatch_threads)
           split_voxelizer.VoxelizePointClouds(static_environment, filter_options, {cam1, cam2, cam3});
       check_voxelization(from_shares);
       EXPECT_TRUE(from_shares.GetImmutableRawData() == voxelized.GetImmutableRawData());
+    }
+    {
+      // SURVEY 8c, the CPU-exact mode: HIP_EXACT_FP64 walks the rays in float64 from the wrappers' DOUBLE points and
+      // transforms and filters with a double ratio -- the grid of the reference's CPU voxelizer, which the oracle
+      // restates.  Equal cell for cell, on the reference scene and on one where float and double walks differ.
+      std::map<std::string, int32_t> exact = merged;
+      exact["HIP_EXACT_FP64"] = 1;
+      const HipPointCloudVoxelizer exact_voxelizer(exact, logging_fn);
+      const OccupancyMap got = exact_voxelizer.VoxelizePointClouds(static_environment, filter_options, {cam1, cam2, cam3});
+      check_voxelization(got);
+      const OccupancyMap want = OracleCpuVoxelization(static_environment, filter_options, {cam1, cam2, cam3});
+      EXPECT_TRUE(got.GetImmutableRawData() == want.GetImmutableRawData());
+      // (points that are no floats, a max range that clips, a filter ratio below one)
+      auto cam4 = std::make_shared<VectorPointCloudWrapper>();
+      cam4->SetPointCloudOriginTransform(QuatZ_then_X(0.3, -1.1, -0.7, 0.2, 0.4));
+      for (int i = 0; i < 20000; i++)
+      {
+        const double a = 0.001 * i, b = 0.37 * i;
+        cam4->PushBack(1.7 * std::cos(a) * std::sin(b) + 1e-9 * i, 1.9 * std::sin(a) * std::sin(b), 2.3 * std::cos(b) + 0.1);
+      }
+      const PointCloudVoxelizationFilterOptions loose(0.6, 2, 1);
+      const OccupancyMap got4 = exact_voxelizer.VoxelizePointClouds(static_environment, loose, {cam4, cam1});
+      const OccupancyMap want4 = OracleCpuVoxelization(static_environment, loose, {cam4, cam1});
+      EXPECT_TRUE(got4.GetImmutableRawData() == want4.GetImmutableRawData());
     }
     // argument validation of the public entry point (pointcloud_voxelization_interface.hpp:267-289)
     bool threw = false;

@@ -69,7 +69,8 @@ private:
 
 class HipVoxelizationHelper : public DeviceVoxelizationHelperInterface,
                               public StridedRaycastInterface,
-                              public DeferredFilterGridInterface
+                              public DeferredFilterGridInterface,
+                              public ExactRaycastInterface
 {
 public:
   HipVoxelizationHelper(const std::map<std::string, int32_t>& options,
@@ -159,6 +160,21 @@ public:
         ctx_, real.Get(), tracking_grid_index, data, num_points, point_step, xyz_offset, max_range,
         grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size,
         num_x_voxels, num_y_voxels, num_z_voxels));
+  }
+
+  bool ExactFp64() const override { return exact_fp64_; }
+
+  void RaycastPointsExact(
+      const std::vector<double>& raw_points, const double max_range, const double* const grid_pointcloud_transform,
+      const double voxel_size, const double inverse_voxel_size, const double grid_x_size, const double grid_y_size,
+      const double grid_z_size, const int32_t num_x_voxels, const int32_t num_y_voxels, const int32_t num_z_voxels,
+      TrackingGridsHandle& tracking_grids, const size_t tracking_grid_index) override
+  {
+    HipTrackingGridsHandle& real = dynamic_cast<HipTrackingGridsHandle&>(tracking_grids);
+    Check(vgt_hip_raycast_points_f64(
+        ctx_, real.Get(), tracking_grid_index, raw_points.data(), static_cast<int64_t>(raw_points.size() / 3), max_range,
+        grid_pointcloud_transform, voxel_size, inverse_voxel_size, grid_x_size, grid_y_size, grid_z_size, num_x_voxels,
+        num_y_voxels, num_z_voxels));
   }
 
   std::unique_ptr<FilterGridHandle> PrepareFilterGrid(

@@ -459,6 +459,19 @@ int CheckBatch(int64_t batch, int64_t nx, int64_t ny, int64_t nz)
   return VGT_HIP_OK;
 }
 
+// The largest group of a batch that one launch can take: CheckBatch's limits (2^20 grids, 2^28 lines, 32-bit item counts)
+// and `device_bytes` of buffers at `bytes_per_grid` each.  At least 1.
+int64_t BatchGroup(int64_t batch, int64_t nx, int64_t ny, int64_t nz, size_t device_bytes, size_t bytes_per_grid)
+{
+  const int64_t zsegs = (nz + 63) / 64;
+  int64_t group = batch;
+  const int64_t limits[] = {int64_t{1} << 20, ((int64_t{1} << 28) - 1) / (nx * ny), 0x7fffffffLL / (nx * zsegs),
+                            0x7fffffffLL / (ny * zsegs), static_cast<int64_t>(device_bytes / (bytes_per_grid + 1))};
+  for (const int64_t limit : limits)
+    if (group > limit) group = limit;
+  return group < 1 ? 1 : group;
+}
+
 // Large grids through the host-pointer entry points: the three phases of a call -- upload, kernels, download --
 // overlap.  The grid is uploaded in X chunks (contiguous) on a copy stream and every chunk is scanned along Z and
 // swept along Y as soon as it has arrived; the X pass then runs over ranges of Y, and every finished range
@@ -1365,10 +1378,27 @@ void* vgt_hip_filter_grid_dev_ptr(const vgt_hip_filter* filter)
   if (!filter) return nullptr;
   // A deferred upload is ordered behind nothing the caller's own streams know of: wait for it here, so that the
   // pointer can be used on any stream (the pin on the caller's array is released by retrieve / destroy as before).
-  if (filter->upload_pending)
+  // (the flag is written under the context's mutex by filter / retrieve: read it the same way; a failed wait means the
+  // grid's content is not known to be there -- no pointer then, the reason in vgt_hip_last_error(); the calling thread's
+  // current device is left as it was)
+  bool pending = false;
   {
-    (void)hipSetDevice(filter->device);
-    (void)hipEventSynchronize(filter->uploaded);
+    std::lock_guard<std::mutex> lock(filter->ctx->mutex);
+    pending = filter->upload_pending;
+  }
+  if (pending)
+  {
+    int previous = -1;
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+    hipError_t err = hipSetDevice(filter->device);
+    if (err == hipSuccess) err = hipEventSynchronize(filter->uploaded);
+    if (previous >= 0 && previous != filter->device) (void)hipSetDevice(previous);
+    if (err != hipSuccess)
+    {
+      (void)hipGetLastError();
+      Fail(VGT_HIP_ERR_RUNTIME, std::string("waiting for the filter grid's upload: ") + hipGetErrorString(err));
+      return nullptr;
+    }
   }
   return filter->dev;
 }
@@ -1535,12 +1565,7 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t n = static_cast<size_t>(nx * ny * nz);
   // Grids per launch: as many as the limits of a batch and a memory budget allow (the context keeps the buffers).
-  int64_t group = batch;
-  const int64_t by_lines = ((int64_t{1} << 28) - 1) / (nx * ny);
-  const int64_t by_bytes = static_cast<int64_t>((size_t{2} << 30) / (n * 9 + 1));
-  if (group > by_lines) group = by_lines;
-  if (group > by_bytes) group = by_bytes;
-  if (group < 1) group = 1;
+  const int64_t group = BatchGroup(batch, nx, ny, nz, size_t{2} << 30, n * 9);
   std::lock_guard<std::mutex> lock(ctx->mutex);
   const size_t ws_bytes = CarveWorkspace(nullptr, nx, ny, nz, ctx->variant, ctx->variant == vgt::EdtVariant::kDefault ? group : 1).bytes;
   VGT_TRY_HIP(Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, static_cast<size_t>(group) * n * sizeof(float)), "allocate SDF input");
@@ -1555,6 +1580,13 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
   for (int64_t first = 0; first < batch; first += group)
   {
     const int64_t count = batch - first < group ? batch - first : group;
+    // (page-locked for the group's copies, like the arrays of vgt_hip_cells_object_sdfs; small arrays are left alone)
+    std::vector<std::unique_ptr<ScopedHostPin>> pins;
+    for (int64_t b = 0; b < count; b++)
+    {
+      pins.emplace_back(new ScopedHostPin(occupancy_host[first + b], n * sizeof(float)));
+      pins.emplace_back(new ScopedHostPin(sdf_host[first + b], n * sizeof(float)));
+    }
     for (int64_t b = 0; b < count; b++)
       VGT_TRY_HIP(hipMemcpyAsync(in_dev + static_cast<size_t>(b) * n, occupancy_host[first + b], n * sizeof(float),
                                  hipMemcpyHostToDevice, s),
@@ -1895,12 +1927,7 @@ int vgt_hip_cells_object_sdfs(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint
   const size_t n = static_cast<size_t>(nx * ny * nz);
   // Objects per launch: what the limits of a batch and a memory budget allow (9.25 bytes per voxel and object: mask,
   // intermediate field, field, records).
-  int64_t group = num_objects;
-  const int64_t by_lines = ((int64_t{1} << 28) - 1) / (nx * ny);
-  const int64_t by_bytes = static_cast<int64_t>((size_t{4} << 30) / (n * 10 + 1));
-  if (group > by_lines) group = by_lines;
-  if (group > by_bytes) group = by_bytes;
-  if (group < 1) group = 1;
+  const int64_t group = BatchGroup(num_objects, nx, ny, nz, size_t{4} << 30, n * 10);
   std::lock_guard<std::mutex> lock(ctx->mutex);
   if (ctx->variant != vgt::EdtVariant::kDefault)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batches run on the default EDT pipeline only");

@@ -26,7 +26,9 @@
 #include "vgt_internal.hpp"
 
 #include <cmath>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace vgt
 {
@@ -46,7 +48,16 @@ struct RaycastTraits<float>
   using Grid = RaycastGridF32;
   static constexpr float kFlat = 1e-10f;
   static constexpr float kNudge = 1e-10f;
-  static __device__ __forceinline__ int32_t ToIndex(float floored) { return static_cast<int32_t>(floored); }
+  // (spelled out: a bare float -> int cast of NaN or of an out-of-range value is undefined in C++, whatever v_cvt_i32_f32
+  // does with it; the compiler folds this back into the one conversion instruction -- the same contract as the oracle's
+  // device_index_f32)
+  static __device__ __forceinline__ int32_t ToIndex(float floored)
+  {
+    if (isnan(floored)) return 0;
+    if (floored >= 2147483648.0f) return INT32_MAX;
+    if (floored <= -2147483648.0f) return INT32_MIN;
+    return static_cast<int32_t>(floored);
+  }
 };
 template <>
 struct RaycastTraits<double>
@@ -56,7 +67,13 @@ struct RaycastTraits<double>
   static constexpr double kNudge = 1e-10;
   static __device__ __forceinline__ int32_t ToIndex(double floored)
   {
-    return isnan(floored) ? INT32_MIN : static_cast<int32_t>(floored);
+    // The CPU voxelizer's index is 64 bits wide (the oracle's host_index_f64): NaN and everything outside int64 is x86's
+    // "indefinite", the most negative integer; a value inside int64 but outside int32 keeps its sign -- all that matters
+    // about an index that far outside the grid is which way the walk steps away from it.
+    if (!(floored > -9223372036854775808.0 && floored < 9223372036854775808.0)) return INT32_MIN;
+    if (floored >= 2147483648.0) return INT32_MAX;
+    if (floored <= -2147483648.0) return INT32_MIN;
+    return static_cast<int32_t>(floored);
   }
 };
 
@@ -762,6 +779,43 @@ size_t RaycastScratchBytes(int64_t num_points)
 
 namespace
 {
+// Whether the table kernel can run with `threads` threads and `table_lds` bytes of dynamic LDS on the current device:
+// the attribute must be granted AND a workgroup must fit a CU with the kernel's static LDS on top (a target with less LDS
+// than gfx950 grants the attribute and rejects the launch).  Decided once per device, workgroup size and table size --
+// before anything of the sorted path has been launched -- and remembered; a refusal sends the call down the plain kernel.
+template <typename Real>
+bool TableKernelFits(int threads, size_t table_lds)
+{
+  struct Known
+  {
+    int device, threads;
+    size_t lds;
+    bool fits;
+  };
+  static std::mutex guard;
+  static std::vector<Known> known;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return false;
+  }
+  std::lock_guard<std::mutex> lock(guard);
+  for (const Known& k : known)
+    if (k.device == device && k.threads == threads && k.lds == table_lds) return k.fits;
+  const void* const kernel = reinterpret_cast<const void*>(RaycastKernel<Real, true>);
+  bool fits = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds)) == hipSuccess;
+  if (fits)
+  {
+    int resident = 0;
+    fits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, RaycastKernel<Real, true>, threads, table_lds) == hipSuccess &&
+           resident > 0;
+  }
+  if (!fits) (void)hipGetLastError();
+  known.push_back(Known{device, threads, table_lds, fits});
+  return fits;
+}
+
 template <typename Real>
 hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t point_stride,
                          const typename RaycastTraits<Real>::Grid& g, int32_t* tracking_dev,
@@ -782,16 +836,7 @@ hipError_t LaunchRaycast(const Real* points_dev, int64_t num_points, int64_t poi
   const size_t table_lds = static_cast<size_t>(2 * table_slots) * sizeof(uint32_t);
   bool sorted_path = need > 0 && scratch_dev && scratch_bytes >= need && num_points < 0x7fffffffLL &&
                      num_cells < 0xffffffffLL;
-  if (sorted_path)
-  {
-    const hipError_t granted = hipFuncSetAttribute(reinterpret_cast<const void*>(RaycastKernel<Real, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(table_lds));
-    if (granted != hipSuccess)
-    {
-      (void)hipGetLastError();
-      sorted_path = false;
-    }
-  }
+  if (sorted_path) sorted_path = TableKernelFits<Real>(table_threads, table_lds);
   if (sorted_path)
   {
     const int num_chunks = static_cast<int>((num_points + kSortChunk - 1) / kSortChunk);
