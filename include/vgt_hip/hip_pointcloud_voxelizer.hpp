@@ -37,6 +37,10 @@ struct VoxelizePhases
   double filter_and_download_s = 0;          // rest of the upload, filter kernel, download of the filtered grid (blocking)
   double release_s = 0;                      // device buffers back to the pool
   double total_s = 0;
+  // by-value overload only: making the returned map (no cell touched) and waiting, before the download, for the threads
+  // that fault its pages in
+  double output_allocate_s = 0;
+  double output_pages_wait_s = 0;
 };
 
 class HipPointCloudVoxelizer

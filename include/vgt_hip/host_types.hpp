@@ -13,7 +13,10 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <cstdlib>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -89,11 +92,83 @@ struct Isometry3
   }
 };
 
-// std::allocator whose value-less construct() leaves the memory as it is: a vector sized through it has its elements'
-// storage but has not touched a page of it (DenseGrid::UninitializedLike: a map whose every cell a download overwrites).
-template <typename T>
-struct DefaultInitAllocator : std::allocator<T>
+// Large blocks (a grid's cells) that a destroyed grid hands back and the next grid of the same size takes over, pages and
+// all: a map of 256^3 cells is 64 MiB, which malloc maps afresh every time -- 16 384 page faults for the first thread that
+// writes to it, more than a voxelization takes on the device.  A caller that voxelizes frame after frame (the by-value
+// VoxelizePointClouds returns a new map per call) gets the block of the map it dropped a frame ago.  Bounded: at most
+// kMaxBytes are kept, larger or surplus blocks go back to the system.  Process-wide, thread-safe.
+class GridBlockCache
 {
+public:
+  static constexpr size_t kMinBytes = size_t{1} << 20, kMaxBytes = size_t{512} << 20;
+  static void* Take(size_t bytes)
+  {
+    if (bytes >= kMinBytes)
+    {
+      std::lock_guard<std::mutex> lock(Guard());
+      auto& blocks = Blocks();
+      for (size_t i = 0; i < blocks.size(); i++)
+        if (blocks[i].second == bytes)
+        {
+          void* const p = blocks[i].first;
+          Held() -= bytes;
+          blocks.erase(blocks.begin() + static_cast<std::ptrdiff_t>(i));
+          return p;
+        }
+    }
+    void* p = nullptr;
+    if (posix_memalign(&p, 4096, bytes < 4096 ? 4096 : bytes) != 0) throw std::bad_alloc();
+    return p;
+  }
+  static void Give(void* p, size_t bytes) noexcept
+  {
+    if (bytes >= kMinBytes)
+    {
+      std::lock_guard<std::mutex> lock(Guard());
+      if (Held() + bytes <= kMaxBytes)
+      {
+        Blocks().emplace_back(p, bytes);
+        Held() += bytes;
+        return;
+      }
+    }
+    std::free(p);
+  }
+  // gives every cached block back to the system
+  static void Release() noexcept
+  {
+    std::lock_guard<std::mutex> lock(Guard());
+    for (const auto& b : Blocks()) std::free(b.first);
+    Blocks().clear();
+    Held() = 0;
+  }
+
+private:
+  // (never destroyed: grids with static storage duration may give their blocks back after any static of this class)
+  static std::mutex& Guard()
+  {
+    static std::mutex* const guard = new std::mutex();
+    return *guard;
+  }
+  static std::vector<std::pair<void*, size_t>>& Blocks()
+  {
+    static std::vector<std::pair<void*, size_t>>* const blocks = new std::vector<std::pair<void*, size_t>>();
+    return *blocks;
+  }
+  static size_t& Held()
+  {
+    static size_t held = 0;
+    return held;
+  }
+};
+
+// Allocator of a grid's cells: blocks come from / go back to GridBlockCache, and its value-less construct() leaves the
+// memory as it is -- a vector sized through it has its elements' storage but has not touched a page of it
+// (DenseGrid::UninitializedLike: a map whose every cell a download overwrites).
+template <typename T>
+struct DefaultInitAllocator
+{
+  using value_type = T;
   template <typename U>
   struct rebind
   {
@@ -102,6 +177,12 @@ struct DefaultInitAllocator : std::allocator<T>
   DefaultInitAllocator() = default;
   template <typename U>
   DefaultInitAllocator(const DefaultInitAllocator<U>&) noexcept {}
+  T* allocate(size_t count) { return static_cast<T*>(GridBlockCache::Take(count * sizeof(T))); }
+  void deallocate(T* p, size_t count) noexcept { GridBlockCache::Give(p, count * sizeof(T)); }
+  template <typename U>
+  bool operator==(const DefaultInitAllocator<U>&) const noexcept { return true; }
+  template <typename U>
+  bool operator!=(const DefaultInitAllocator<U>&) const noexcept { return false; }
   template <typename U>
   void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value)
   {

@@ -122,6 +122,7 @@ int main()
     for (const int n : {1, 2, 8})
     {
       double best[2] = {1e30, 1e30}, ray[2] = {0, 0}, fil[2] = {0, 0};
+      VoxelizePhases phases_value;
       // by reference into a map the caller keeps (strided clouds)
       double best_ref = 1e30, ray_ref = 0, fil_ref = 0;
       VoxelizePhases phases_ref;
@@ -153,15 +154,20 @@ int main()
             best[kind] = t;
             ray[kind] = r;
             fil[kind] = f;
+            if (kind == 0) phases_value = voxelizer.LastPhases();
           }
         }
       }
       std::printf("%s\"%d\": {\"voxelize_end_to_end_ms\": %.3f, \"raycast_phase_ms\": %.3f, \"filter_phase_ms\": %.3f, "
-                  "\"per_point_copy_interface_ms\": %.3f, \"by_reference\": {\"voxelize_end_to_end_ms\": %.3f, "
+                  "\"per_point_copy_interface_ms\": %.3f, \"by_value_phases_ms\": {\"allocate_output\": %.3f, "
+                  "\"cloud_uploads_and_raycasts\": %.3f, \"wait_for_output_pages\": %.3f, "
+                  "\"upload_rest_filter_kernel_download\": %.3f}, \"by_reference\": {\"voxelize_end_to_end_ms\": %.3f, "
                   "\"raycast_phase_ms\": %.3f, \"filter_phase_ms\": %.3f, \"phases_ms\": {\"prepare_tracking_grids\": %.3f, "
                   "\"static_grid_upload_enqueue\": %.3f, \"cloud_uploads_and_raycasts\": %.3f, \"filter_enqueue\": %.3f, "
                   "\"upload_rest_filter_kernel_download\": %.3f, \"release_buffers\": %.3f}}}",
-                  first ? "" : ", ", n, best[0] * 1e3, ray[0] * 1e3, fil[0] * 1e3, best[1] * 1e3, best_ref * 1e3,
+                  first ? "" : ", ", n, best[0] * 1e3, ray[0] * 1e3, fil[0] * 1e3, best[1] * 1e3,
+                  phases_value.output_allocate_s * 1e3, phases_value.raycast_s * 1e3, phases_value.output_pages_wait_s * 1e3,
+                  phases_value.filter_and_download_s * 1e3, best_ref * 1e3,
                   ray_ref * 1e3, fil_ref * 1e3, phases_ref.prepare_tracking_grids_s * 1e3,
                   phases_ref.filter_grid_enqueue_s * 1e3, phases_ref.raycast_s * 1e3, phases_ref.filter_enqueue_s * 1e3,
                   phases_ref.filter_and_download_s * 1e3, phases_ref.release_s * 1e3);
@@ -170,7 +176,9 @@ int main()
     std::printf("}, \"note\": \"best of 3; voxelize_end_to_end_ms = VoxelizePointClouds with clouds handed over as one strided "
                 "FLOAT32 buffer (H2D of points and static grid, raycast, filter, D2H of the 64 MiB grid); "
                 "per_point_copy_interface_ms = the same through CopyPointLocationIntoFloatPtr point by point; voxelize_end_to_end_ms is "
-                "the by-value overload (a fresh 64 MiB copy of the static map per call, whose pages fault in under the download); "
+                "the by-value overload: the returned map starts with untouched cells (no copy of the static map), its block comes "
+                "from the grids' block cache when the caller has dropped a map of that size before (every call but the first here), "
+                "and helper threads fault a fresh block's pages in beside the raycasts; "
                 "by_reference = the overload that writes into a map the caller keeps, with host-clock phases of the best call\"}\n");
     return 0;
   }

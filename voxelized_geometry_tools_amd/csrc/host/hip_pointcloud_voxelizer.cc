@@ -56,7 +56,9 @@ OccupancyMap HipPointCloudVoxelizer::VoxelizePointClouds(
   // UNTOUCHED cells -- no 4 bytes per cell copied, no page faulted by this thread -- and helper threads fault its pages in
   // while the device raycasts, so that the download (which page-locks its destination) finds them resident.  (At 256^3 the
   // copy and its page faults were 10 of the call's 12.7 ms.)
+  const auto allocate_time = std::chrono::steady_clock::now();
   OccupancyMap output_environment = OccupancyMap::UninitializedLike(static_environment);
+  const double allocate_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - allocate_time).count();
   float* const cells = output_environment.GetMutableRawData().data();
   const size_t num_cells = output_environment.GetMutableRawData().size();
   constexpr size_t kPageFloats = 4096 / sizeof(float);
@@ -71,9 +73,12 @@ OccupancyMap HipPointCloudVoxelizer::VoxelizePointClouds(
         for (size_t page = num_pages * t / touchers; page < num_pages * (t + 1) / touchers; page++)
           reinterpret_cast<volatile float*>(cells)[page * kPageFloats] = 0.0f;
       });
-  const auto join_touchers = [&pool]() {
+  double pages_wait_s = 0.0;
+  const auto join_touchers = [&pool, &pages_wait_s]() {
+    const auto t0 = std::chrono::steady_clock::now();
     for (auto& th : pool) th.join();
     pool.clear();
+    pages_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   VoxelizerRuntime runtime(0.0, 0.0);
   try
@@ -86,6 +91,11 @@ OccupancyMap HipPointCloudVoxelizer::VoxelizePointClouds(
     throw;
   }
   join_touchers();
+  {
+    std::lock_guard<std::mutex> lock(phases_mutex_);
+    last_phases_.output_allocate_s = allocate_s;
+    last_phases_.output_pages_wait_s = pages_wait_s;
+  }
   if (runtime_log_fn) runtime_log_fn(runtime);
   return output_environment;
 }
@@ -314,6 +324,7 @@ void ReleaseCachedDeviceMemory()
   }
   for (vgt_hip_ctx* ctx : existing) (void)vgt_hip_trim(ctx);
   vgt_hipx_release();  // the multi-device entry point's slab set
+  GridBlockCache::Release();  // host blocks of dropped grids (host_types.hpp)
 }
 
 SignedDistanceField ExtractSignedDistanceField(

@@ -14,6 +14,7 @@
 #include <vector>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 // Host point clouds are uploaded and raycast on one of a few "upload lanes" (own stream + own staging
@@ -64,6 +65,10 @@ struct vgt_hip_ctx
   size_t sdf_out_bytes = 0;
   void* sdf_ws = nullptr;
   size_t sdf_ws_bytes = 0;
+  // Page-locked staging ring of the batched downloads (DownloadToHostArrays): kStagingSlots slots of kStagingSlotBytes,
+  // allocated by the first such call, kept until vgt_hip_trim / vgt_hip_destroy; one event per slot.
+  void* host_staging = nullptr;
+  std::vector<hipEvent_t> staging_events;
   // Handles created from this context (grids, filter grids, cell grids) point back at it.  A
   // context destroyed while handles are alive releases its device resources at once but keeps this
   // struct until the last handle is gone, so handle destructors never touch freed memory.
@@ -250,6 +255,11 @@ void FreeCachedSdfBuffers(vgt_hip_ctx* ctx)
     *p = nullptr;
   }
   ctx->sdf_in_bytes = ctx->sdf_out_bytes = ctx->sdf_ws_bytes = ctx->ray_scratch_bytes = 0;
+  if (ctx->host_staging) (void)hipHostFree(ctx->host_staging);
+  ctx->host_staging = nullptr;
+  for (hipEvent_t e : ctx->staging_events)
+    if (e) (void)hipEventDestroy(e);
+  ctx->staging_events.clear();
 }
 
 // Page-locks a caller-owned host range for the duration of a call, unless it already is pinned
@@ -457,6 +467,105 @@ int CheckBatch(int64_t batch, int64_t nx, int64_t ny, int64_t nz)
       batch * ny * zsegs > 0x7fffffffLL)
     return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "batch too large: batch * nx * ny must stay below 2^28 lines");
   return VGT_HIP_OK;
+}
+
+// Many device fields into many host arrays the caller has just allocated (the per-object fields of a tagged map, the
+// fields of a batch of maps).  Page-locking such arrays costs more than the copy: their pages have never been touched,
+// so the registration faults every one of them in, on one thread, and at the end they are unlocked again (32 fields of
+// 128^3: 21 ms for 268 MB, a third of the link).  Instead the fields cross the link into a ring of page-locked slots
+// that the context keeps, and a few host threads copy every slot's content on into the caller's arrays -- touching the
+// arrays' pages in parallel -- while the next slot fills.  `fields`: device pointer and host pointer per array, `bytes`
+// each.  The caller holds ctx->mutex; `s` has everything the fields depend on enqueued.
+constexpr size_t kStagingSlotBytes = size_t{8} << 20;
+constexpr int kStagingSlots = 4;
+struct HostArrayCopy
+{
+  const void* device;
+  void* host;
+};
+hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& fields, size_t bytes, hipStream_t s)
+{
+  if (fields.empty() || bytes == 0) return hipSuccess;
+  if (!ctx->host_staging)
+  {
+    const hipError_t err = hipHostMalloc(&ctx->host_staging, kStagingSlots * kStagingSlotBytes, hipHostMallocDefault);
+    if (err != hipSuccess)
+    {
+      ctx->host_staging = nullptr;
+      return err;
+    }
+  }
+  while (static_cast<int>(ctx->staging_events.size()) < kStagingSlots)
+  {
+    hipEvent_t e = nullptr;
+    const hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (err != hipSuccess) return err;
+    ctx->staging_events.push_back(e);
+  }
+  // the pieces, in order: (field, offset, bytes), each at most one slot
+  struct Piece
+  {
+    size_t field, offset, bytes;
+  };
+  std::vector<Piece> pieces;
+  for (size_t f = 0; f < fields.size(); f++)
+    for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
+      pieces.push_back(Piece{f, off, std::min(kStagingSlotBytes, bytes - off)});
+  const int workers = static_cast<int>(std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+  // arrived[i]: the copy of piece i into its slot has been ENQUEUED (its event recorded); copied[i]: workers done with it
+  std::vector<std::atomic<int>> arrived(pieces.size()), copied(pieces.size());
+  for (auto& a : arrived) a.store(0);
+  for (auto& c : copied) c.store(0);
+  std::atomic<int> failed{0};
+  char* const staging = static_cast<char*>(ctx->host_staging);
+  const int device = ctx->device;
+  std::vector<std::thread> pool;
+  for (int w = 0; w < workers; w++)
+    pool.emplace_back([&, w]() {
+      (void)hipSetDevice(device);
+      for (size_t i = 0; i < pieces.size(); i++)
+      {
+        while (arrived[i].load(std::memory_order_acquire) == 0)
+        {
+          if (failed.load()) return;
+          std::this_thread::yield();
+        }
+        const int slot = static_cast<int>(i % kStagingSlots);
+        if (hipEventSynchronize(ctx->staging_events[static_cast<size_t>(slot)]) != hipSuccess)
+        {
+          failed.store(1);
+          return;
+        }
+        const Piece& p = pieces[i];
+        // (slices on page boundaries of the destination's offset: two workers never fault the same page)
+        const size_t pages = (p.bytes + 4095) / 4096;
+        const size_t begin = std::min(p.bytes, pages * static_cast<size_t>(w) / workers * 4096);
+        const size_t end = std::min(p.bytes, pages * static_cast<size_t>(w + 1) / workers * 4096);
+        if (end > begin)
+          std::memcpy(static_cast<char*>(fields[p.field].host) + p.offset + begin,
+                      staging + static_cast<size_t>(slot) * kStagingSlotBytes + begin, end - begin);
+        copied[i].fetch_add(1, std::memory_order_release);
+      }
+    });
+  hipError_t err = hipSuccess;
+  for (size_t i = 0; i < pieces.size() && err == hipSuccess; i++)
+  {
+    const int slot = static_cast<int>(i % kStagingSlots);
+    if (i >= static_cast<size_t>(kStagingSlots))
+      while (copied[i - kStagingSlots].load(std::memory_order_acquire) < workers && !failed.load()) std::this_thread::yield();
+    if (failed.load()) break;
+    const Piece& p = pieces[i];
+    err = hipMemcpyAsync(staging + static_cast<size_t>(slot) * kStagingSlotBytes,
+                         static_cast<const char*>(fields[p.field].device) + p.offset, p.bytes, hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipEventRecord(ctx->staging_events[static_cast<size_t>(slot)], s);
+    if (err == hipSuccess) arrived[i].store(1, std::memory_order_release);
+  }
+  if (err != hipSuccess) failed.store(1);
+  for (auto& th : pool) th.join();
+  const hipError_t sync = hipStreamSynchronize(s);
+  if (err == hipSuccess) err = sync;
+  if (err == hipSuccess && failed.load()) err = hipErrorUnknown;
+  return err;
 }
 
 // The largest group of a batch that one launch can take: CheckBatch's limits (2^20 grids, 2^28 lines, 32-bit item counts)
@@ -1580,13 +1689,9 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
   for (int64_t first = 0; first < batch; first += group)
   {
     const int64_t count = batch - first < group ? batch - first : group;
-    // (page-locked for the group's copies, like the arrays of vgt_hip_cells_object_sdfs; small arrays are left alone)
+    // (the inputs are page-locked for the group's uploads -- they hold data, their pages exist; small arrays are left alone)
     std::vector<std::unique_ptr<ScopedHostPin>> pins;
-    for (int64_t b = 0; b < count; b++)
-    {
-      pins.emplace_back(new ScopedHostPin(occupancy_host[first + b], n * sizeof(float)));
-      pins.emplace_back(new ScopedHostPin(sdf_host[first + b], n * sizeof(float)));
-    }
+    for (int64_t b = 0; b < count; b++) pins.emplace_back(new ScopedHostPin(occupancy_host[first + b], n * sizeof(float)));
     for (int64_t b = 0; b < count; b++)
       VGT_TRY_HIP(hipMemcpyAsync(in_dev + static_cast<size_t>(b) * n, occupancy_host[first + b], n * sizeof(float),
                                  hipMemcpyHostToDevice, s),
@@ -1608,13 +1713,15 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
         if (rc != VGT_HIP_OK) return rc;
       }
     }
-    for (int64_t b = 0; b < count; b++)
-      VGT_TRY_HIP(hipMemcpyAsync(sdf_host[first + b], out_dev + static_cast<size_t>(b) * n, n * sizeof(float),
-                                 hipMemcpyDeviceToHost, s),
-                  "copy SDF to host");
     VGT_TRY_HIP(hipMemcpyAsync(mm.data(), mm_dev, static_cast<size_t>(count) * 2 * sizeof(float), hipMemcpyDeviceToHost, s),
                 "copy extrema to host");
-    VGT_TRY_HIP(hipStreamSynchronize(s), "synchronize");
+    {
+      std::vector<HostArrayCopy> copies;
+      for (int64_t b = 0; b < count; b++) copies.push_back(HostArrayCopy{out_dev + static_cast<size_t>(b) * n, sdf_host[first + b]});
+      const hipError_t moved = DownloadToHostArrays(ctx, copies, n * sizeof(float), s);  // (synchronises the stream)
+      if (moved != hipSuccess) (void)hipStreamSynchronize(s);
+      VGT_TRY_HIP(moved, "copy SDF to host");
+    }
     for (int64_t b = 0; b < count; b++)
     {
       if (out_min) out_min[first + b] = mm[static_cast<size_t>(2 * b)];
@@ -1973,18 +2080,13 @@ int vgt_hip_cells_object_sdfs(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint
       return rc;
     }
     {
-      // the callers' arrays are page-locked for the copies (pageable memory moves at a fraction of the link rate)
-      std::vector<std::unique_ptr<ScopedHostPin>> pins;
-      for (int64_t b = 0; b < count; b++)
-        pins.emplace_back(new (std::nothrow) ScopedHostPin(sdf_host[first + b], n * sizeof(float)));
-      hipError_t err = hipSuccess;
-      for (int64_t b = 0; b < count && err == hipSuccess; b++)
-        err = hipMemcpyAsync(sdf_host[first + b], sdf_dev + static_cast<size_t>(b) * n, n * sizeof(float),
-                             hipMemcpyDeviceToHost, s);
-      if (err == hipSuccess)
-        err = hipMemcpyAsync(mm.data(), mm_dev, static_cast<size_t>(count) * 2 * sizeof(float), hipMemcpyDeviceToHost, s);
-      const hipError_t sync = hipStreamSynchronize(s);
-      if (err == hipSuccess) err = sync;
+      // the fields go through the context's page-locked ring and on into the callers' arrays on several threads
+      std::vector<HostArrayCopy> copies;
+      for (int64_t b = 0; b < count; b++) copies.push_back(HostArrayCopy{sdf_dev + static_cast<size_t>(b) * n, sdf_host[first + b]});
+      hipError_t err = hipMemcpyAsync(mm.data(), mm_dev, static_cast<size_t>(count) * 2 * sizeof(float), hipMemcpyDeviceToHost, s);
+      const hipError_t moved = DownloadToHostArrays(ctx, copies, n * sizeof(float), s);  // (synchronises the stream)
+      if (err == hipSuccess) err = moved;
+      if (err != hipSuccess) (void)hipStreamSynchronize(s);
       VGT_TRY_HIP(err, "copy the objects' fields to the host");
     }
     for (int64_t b = 0; b < count; b++)
