@@ -414,6 +414,26 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   const uint32_t lane_entry = static_cast<uint32_t>(lane) * kEntryBytes;  // byte offset of this lane inside a ring slot
   const uint32_t lane_chunk = static_cast<uint32_t>(lane) * kChunkBytes;  // ... inside a row of spill chunks
   float lo_value = INFINITY, hi_value = -INFINITY;
+  // The plain X pass with 32-bit entries: the final conversion float(sqrt(double(d2)) * resolution) of SMALL squared
+  // distances comes from a table of kSmallD2 exact values in LDS, filled once per workgroup.  A dozen dependent
+  // instructions per row (reciprocal square root, fp64 steps) become one LDS read -- on the bands where sweep 1 has seen
+  // that every lane's inputs, hence every result, are below kSmallD2: the rows of a dense scene (every voxel a few cells
+  // from the other class), the neighbourhood of obstacles on a sparse one.  (`small_bands`: one bit per band of the line.)
+  constexpr bool kUseTable = kFinal && kPlain && kPacked && (1024 / kBand <= 64);
+  constexpr uint32_t kSmallD2 = 512;
+  [[maybe_unused]] float* small_table = nullptr;
+  if constexpr (kUseTable)
+  {
+    __shared__ float small_table_storage[kSmallD2];
+    small_table = small_table_storage;
+#ifdef VGT_HOST_EMULATION
+    for (uint32_t d2 = 0; d2 < kSmallD2; d2++)  // (lanes run one after the other here: each fills all of it)
+#else
+    for (uint32_t d2 = static_cast<uint32_t>(lane); d2 < kSmallD2; d2 += kWaveSize)
+#endif
+      small_table[d2] = SqrtTimesResolutionExact(static_cast<int32_t>(d2), g.resolution);
+    __syncthreads();
+  }
 #ifdef VGT_HOST_EMULATION
   int emulated_round = 0;
 #endif
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
   // Sweep 1: build the envelope.
   // =====================================================================================================
   uint32_t any_transition = 0;
+  [[maybe_unused]] uint64_t small_bands = 0;  // (kUseTable) bit b: every input of band b, in every lane, is below kSmallD2
   {
     // every kChunk rows: the ring must have room for kChunk pushes
     auto check_ring = [&]() {
@@ -849,6 +870,15 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
 #pragma unroll
         for (int k = 0; k < kBand; k++) cur[k] = nxt[k];
         if (r0 + kBand < n) load_band(nxt, r0 + kBand);
+        if constexpr (kUseTable)
+        {
+          // (a row's result is at most its own input: the row itself is a candidate)
+          uint32_t any = 0u;
+#pragma unroll
+          for (int k = 0; k < kBand; k++) any |= static_cast<uint32_t>(cur[k]);
+          if (r0 + kBand <= n && __builtin_amdgcn_ballot_w64((any & 0x7fffffffu) >= kSmallD2) == 0ull)
+            small_bands |= 1ull << (r0 / kBand);
+        }
         uint32_t bits = 0;  // sign bits of this band
         auto rows = [&](auto guarded) {
           constexpr bool kGuard = decltype(guarded)::value;
@@ -1024,9 +1054,10 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
       uint32_t xup = 0;
       if (classes) xup = xup_word >> sub;
       // (two copies of a full band's code, with and without the class-change candidates: no test per row)
-      auto rows = [&](auto guarded, auto with_classes) {
+      auto rows = [&](auto guarded, auto with_classes, auto from_table) {
         constexpr bool kGuard = decltype(guarded)::value;
         constexpr bool kClasses = decltype(with_classes)::value;
+        constexpr bool kTable = decltype(from_table)::value;  // every result of this band is below kSmallD2
         constexpr int kGroup = kGuard ? 1 : VGT_SWEEP_GROUP;  // rows finished together (X pass)
         [[maybe_unused]] float& lo_acc = lo_value;  // (named here: the uses below sit in code that depends on kGroup)
         [[maybe_unused]] float& hi_acc = hi_value;
@@ -1094,6 +1125,21 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                 uint32_t d2s[kGroup];
                 bool redo[kGroup], none[kGroup];
                 bool any_rare = false;
+                if constexpr (kTable)
+                {
+#pragma unroll
+                  for (int j = kGroup - 1; j >= 0; j--)
+                  {
+#ifdef VGT_HOST_EMULATION
+                    assert(grp_best[j] < kSmallD2);
+#endif
+                    dist[j] = small_table[grp_best[j]];
+                    redo[j] = none[j] = false;
+                    d2s[j] = 0;
+                  }
+                }
+                else
+                {
 #pragma unroll
                 for (int j = kGroup - 1; j >= 0; j--)  // row k + j
                 {
@@ -1122,7 +1168,8 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
                   d2s[j] = d2;
                   any_rare = any_rare || redo[j] || none[j];
                 }
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(any_rare) != 0ull, 0))
+                }
+                if (!kTable && __builtin_expect(__builtin_amdgcn_ballot_w64(any_rare) != 0ull, 0))
                 {
                   VGT_COLD_PATH();  // keeps the block out of the straight-line code
 #pragma unroll
@@ -1171,12 +1218,25 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
           }
         }
       };
+      bool small_band = false;
+      if constexpr (kUseTable) small_band = ((small_bands >> (r0 / kBand)) & 1ull) != 0ull;
       if (r0 + kBand > n)
-        rows(std::true_type{}, std::true_type{});  // (the partial band: one copy, the candidates are "far" without classes)
+        rows(std::true_type{}, std::true_type{}, std::false_type{});  // (the partial band: one copy, the candidates are "far" without classes)
+      else if (small_band)
+      {
+        // (a band of small results has sites in every lane: `any_empty` does not concern it)
+        if constexpr (kUseTable)
+        {
+          if (classes)
+            rows(std::false_type{}, std::true_type{}, std::true_type{});
+          else
+            rows(std::false_type{}, std::false_type{}, std::true_type{});
+        }
+      }
       else if (classes || any_empty)
-        rows(std::false_type{}, std::true_type{});
+        rows(std::false_type{}, std::true_type{}, std::false_type{});
       else
-        rows(std::false_type{}, std::false_type{});
+        rows(std::false_type{}, std::false_type{}, std::false_type{});
       if (classes) dn = min(dn, kFar);
     }
   }
@@ -1191,16 +1251,9 @@ __global__ __launch_bounds__(kWaveSize, VGT_SWEEP_WAVES) void SweepPassKernel(co
     }
   }
   }  // next unit of work
-  if constexpr (kFinal)
-  {
-    uint32_t lo_enc = 0xffffffffu, hi_enc = 0u;
-    if (lo_value <= hi_value)
-    {
-      lo_enc = EncodeOrdered(lo_value);
-      hi_enc = EncodeOrdered(hi_value);
-    }
-    BlockMinMax(lo_enc, hi_enc, minmax_enc);
-  }
+  // (the workgroup is one wave: no LDS for the reduction -- with the ring and the table of small distances a workgroup's
+  // LDS is exactly a sixteenth of the CU's 160 KiB)
+  if constexpr (kFinal) WaveMinMax(lo_value, hi_value, minmax_enc);
 }
 
 // Workgroups per launch = slots of the scratch buffer: what the 256 CUs x 16 waves of an MI355X hold at four waves per
