@@ -483,17 +483,24 @@ struct HostArrayCopy
   const void* device;
   void* host;
 };
+// The context's page-locked ring exists (allocated by the first call that wants it).
+hipError_t EnsureStaging(vgt_hip_ctx* ctx)
+{
+  if (ctx->host_staging) return hipSuccess;
+  const hipError_t err = hipHostMalloc(&ctx->host_staging, kStagingSlots * kStagingSlotBytes, hipHostMallocDefault);
+  if (err != hipSuccess)
+  {
+    ctx->host_staging = nullptr;
+    (void)hipGetLastError();
+  }
+  return err;
+}
 hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& fields, size_t bytes, hipStream_t s)
 {
   if (fields.empty() || bytes == 0) return hipSuccess;
-  if (!ctx->host_staging)
   {
-    const hipError_t err = hipHostMalloc(&ctx->host_staging, kStagingSlots * kStagingSlotBytes, hipHostMallocDefault);
-    if (err != hipSuccess)
-    {
-      ctx->host_staging = nullptr;
-      return err;
-    }
+    const hipError_t err = EnsureStaging(ctx);
+    if (err != hipSuccess) return err;
   }
   while (static_cast<int>(ctx->staging_events.size()) < kStagingSlots)
   {
@@ -673,7 +680,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   const ScopedHostPin pin_out(sdf_host, nvox * sizeof(float));
   std::lock_guard<std::mutex> lock(ctx->mutex);
   hipError_t err = Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, nvox * sizeof(InT));
-  if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float));
+  if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float) + 256);  // (+ extrema)
   if (err == hipSuccess) err = Reserve(&ctx->sdf_ws, &ctx->sdf_ws_bytes, ws_bytes);
   if (err != hipSuccess)
   {
@@ -705,6 +712,40 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
       if (out_min) *out_min = mm[0];
       if (out_max) *out_max = mm[1];
     }
+    return result;
+  }
+  // Small maps (the sizes of the reference's own examples and tests: below the page-locking threshold of ScopedHostPin):
+  // the map goes through the context's page-locked ring in both directions -- one plain memcpy into it, one DMA each way,
+  // the extrema riding behind the field in the SAME download -- instead of two pageable copies, which the runtime stages
+  // itself at several times the cost, and a third copy for two floats.
+  const size_t in_bytes = nvox * sizeof(InT), out_bytes = nvox * sizeof(float);
+  if (in_bytes <= (size_t{1} << 20) && out_bytes + 2 * sizeof(float) <= kStagingSlotBytes && EnsureStaging(ctx) == hipSuccess)
+  {
+    char* const up = static_cast<char*>(ctx->host_staging);
+    char* const down = up + kStagingSlotBytes;
+    std::memcpy(up, input_host, in_bytes);
+    err = hipMemcpyAsync(in_dev, up, in_bytes, hipMemcpyHostToDevice, s);
+    if (err != hipSuccess)
+      result = FailHip("copy occupancy to device", err);
+    else  // (extrema behind the field: ctx->sdf_out has room, see Reserve above)
+      result = RunSdfPipeline<InT>(ctx, in_dev, p, sdf_dev, ctx->sdf_ws, ctx->sdf_ws_bytes, sdf_dev + nvox, nullptr);
+    if (result == VGT_HIP_OK)
+    {
+      err = hipMemcpyAsync(down, sdf_dev, out_bytes + 2 * sizeof(float), hipMemcpyDeviceToHost, s);
+      if (err == hipSuccess) err = hipStreamSynchronize(s);
+      if (err != hipSuccess)
+        result = FailHip("copy SDF to host", err);
+      else
+      {
+        std::memcpy(sdf_host, down, out_bytes);
+        float mm[2];
+        std::memcpy(mm, down + out_bytes, sizeof(mm));
+        if (out_min) *out_min = mm[0];
+        if (out_max) *out_max = mm[1];
+      }
+    }
+    else
+      (void)hipStreamSynchronize(s);
     return result;
   }
   err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
