@@ -600,10 +600,47 @@ static void TaggedObjectSdfTests()
   }
 }
 
+// host_types.hpp: the grids' cells -- values of ordinary maps, the untouched map the by-value voxelizer returns, the block
+// cache that hands a dropped map's block to the next map of its size (and to no other).
+static void HostGridStorageTests()
+{
+  GridBlockCache::Release();
+  const float* first_block = nullptr;
+  {
+    OccupancyMap a = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 0.64, 0.25f);  // 1 MiB
+    EXPECT_EQ(a.NumTotalVoxels(), 64 * 64 * 64);
+    bool filled = true;
+    for (const float v : a.GetImmutableRawData()) filled = filled && v == 0.25f;
+    EXPECT_TRUE(filled);
+    first_block = a.GetImmutableRawData().data();
+    const OccupancyMap copy = a;  // (a copy is a copy: its own block, the same cells)
+    EXPECT_TRUE(copy.GetImmutableRawData().data() != first_block);
+    EXPECT_TRUE(copy.GetImmutableRawData() == a.GetImmutableRawData());
+    OccupancyMap shaped = OccupancyMap::UninitializedLike(a);
+    EXPECT_TRUE(shaped.IsInitialized() && shaped.SameSizes(a) && shaped.Frame() == a.Frame());
+    EXPECT_EQ(shaped.GetImmutableRawData().size(), a.GetImmutableRawData().size());
+    shaped.SetIndex(63, 63, 63, 2.0f);
+    EXPECT_EQ(shaped.GetIndexImmutable(63, 63, 63), 2.0f);
+  }
+  // `a` was dropped last: a map of the same size takes its block over, one of another size does not
+  {
+    OccupancyMap other_size = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 1.28, 0.0f);
+    EXPECT_TRUE(other_size.GetImmutableRawData().data() != first_block);
+    OccupancyMap again = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 0.64, 0.5f);
+    bool refilled = true;
+    for (const float v : again.GetImmutableRawData()) refilled = refilled && v == 0.5f;
+    EXPECT_TRUE(refilled);  // (recycled storage is still initialised storage)
+  }
+  GridBlockCache::Release();
+  // small grids never enter the cache
+  { OccupancyMap tiny = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.25, 1.0, 2.0, 3.0, 0.0f); (void)tiny; }
+}
+
 int main(int argc, char** argv)
 {
   const bool no_device = (argc > 1 && std::strcmp(argv[1], "--no-device") == 0);
   UnavailableBackendTests();
+  HostGridStorageTests();
   if (!no_device)
   {
     SdfGenerationTests();

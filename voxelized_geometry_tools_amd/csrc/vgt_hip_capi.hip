@@ -15,6 +15,9 @@
 #include <new>
 #include <string>
 #include <thread>
+#ifdef __linux__
+#include <sys/mman.h>
+#endif
 #include <vector>
 
 // Host point clouds are uploaded and raycast on one of a few "upload lanes" (own stream + own staging
@@ -518,7 +521,18 @@ hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCop
   for (size_t f = 0; f < fields.size(); f++)
     for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
       pieces.push_back(Piece{f, off, std::min(kStagingSlotBytes, bytes - off)});
-  const int workers = static_cast<int>(std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+  const int workers = static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
+#ifdef __linux__
+  // (fresh arrays of several MiB: ask for huge pages where the kernel gives them on request -- 2 MiB per fault instead of
+  // 4 KiB; a hint, any answer is fine)
+  if (bytes >= (size_t{4} << 20))
+    for (const HostArrayCopy& f : fields)
+    {
+      const uintptr_t begin = (reinterpret_cast<uintptr_t>(f.host) + 4095) & ~uintptr_t{4095};
+      const uintptr_t end = (reinterpret_cast<uintptr_t>(f.host) + bytes) & ~uintptr_t{4095};
+      if (end > begin) (void)madvise(reinterpret_cast<void*>(begin), end - begin, MADV_HUGEPAGE);
+    }
+#endif
   // arrived[i]: the copy of piece i into its slot has been ENQUEUED (its event recorded); copied[i]: workers done with it
   std::vector<std::atomic<int>> arrived(pieces.size()), copied(pieces.size());
   for (auto& a : arrived) a.store(0);
