@@ -18,8 +18,8 @@
 // to the nearest row of the OTHER class, from the line's class bits (one 64-bit word per lane), is a second candidate.
 // Same geometry as the sweeps (a wave = 64 neighbouring Z positions of one outer index, every row access one contiguous
 // 256-B segment), same input and output encodings, same final conversion: the two formulations are interchangeable
-// per pass, and the parity suite runs both (the cross-check variant 3 of the testing library keeps the sweeps on short
-// lines too).
+// per pass, and the parity suite runs both on every short shape (the testing library can move the limit between them:
+// vgt_hip_testing_set_short_line_rows).
 #include "edt_device.hpp"
 #include "edt_line_geom.hpp"
 

@@ -6,8 +6,9 @@
 // Each lane runs the Felzenszwalb-Huttenlocher stack algorithm (signed_distance_field_generation.cpp:124-226) on
 // its own line, in exact integer arithmetic:
 //
-//   * Classes are ignored while the envelope is built (see edt_hull_kernels.hip): out(q) = min(envelope over ALL
-//     rows with cost |F[r]| at q, squared distance to the nearest row of the other class below / above q).
+//   * Classes are ignored while the envelope is built: out(q) = min(envelope over ALL rows with cost |F[r]| at q, squared
+//     distance to the nearest row of the other class below / above q) -- a row of the other class is a zero-cost site, and
+//     a row of the own class can only offer its cost, which is a distance to the other class too.
 //   * A stack entry is (G = F + row^2, row) -- a point of the lower convex hull.  "The top never owns a point once
 //     the new site is there" is the cross-multiplied test of the three points (the pop test `s <= z[k]` of
 //     :193-197 without the division): (Gq - Gt)(rt - rs) - (Gt - Gs)(q - rt) < 0, two 64-bit multiply-adds.
@@ -26,7 +27,8 @@
 //     row (values along the envelope are unimodal), (Gs - Gt) + 2 q (rt - rs) <= 0 pops.  The distances to the
 //     bounding rows of the other class are running counters fed by the line's sign bits (one word per 32 rows, kept
 //     in the scratch buffer between the sweeps); waves whose 64 lines hold one class only skip that part.
-//   * X pass: fused sqrt / resolution / sign / virtual border / min-max as in the other variants.
+//   * X pass: fused sqrt / resolution / sign / virtual border / min-max; on bands whose inputs are all below 512 the
+//     conversion comes from an exact table in LDS (dense scenes).
 //   * The Y pass of the default pipeline does not read a distance field: its rows come as CLASS RECORDS (pass 1,
 //     edt_record_kernels.hip; vgt_internal.hpp) -- 64 rows per vector load, two blocks ahead -- and a lane's distance
 //     along Z is the minimum over the transitions around it, one v_sad_u32 each.  Rows whose lines hold one class only
@@ -37,6 +39,10 @@
 //   * What the listing taught (profiles/r4/experiments.md): a row pays for exec-mask regions and scalar flag logic more
 //     than for vector instructions; a chunk of the ring is addressed ONCE (it never wraps), which turns its eight LDS
 //     accesses into four paired instructions; conditions of rare paths are combined bitwise, not with || and &&.
+//
+//   * What rounds 5 and 6 measured and did not keep (profiles/r5, r6/experiments.md): a coarse hull in front of the X sweep,
+//     handing lower halves of second sweeps to idle workgroups, a packed-word form of sweep 1 (fewer instructions per row,
+//     hardly less time: a row costs its dependent chain, not its instruction count).
 //
 // The kernels are bound by instruction issue and by the latency of their dependent chains, not by HBM: rows are
 // processed kBand at a time (registers), the code below keeps rare paths (refills, exact final conversion) out of

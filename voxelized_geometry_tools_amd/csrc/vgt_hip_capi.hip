@@ -728,12 +728,12 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
     }
     return result;
   }
-  // Small maps (the sizes of the reference's own examples and tests: below the page-locking threshold of ScopedHostPin):
+  // Small maps (the sizes of the reference's own examples and tests; up to 512 KiB -- at 1 MiB page-locking the arrays wins):
   // the map goes through the context's page-locked ring in both directions -- one plain memcpy into it, one DMA each way,
   // the extrema riding behind the field in the SAME download -- instead of two pageable copies, which the runtime stages
   // itself at several times the cost, and a third copy for two floats.
   const size_t in_bytes = nvox * sizeof(InT), out_bytes = nvox * sizeof(float);
-  if (in_bytes <= (size_t{1} << 20) && out_bytes + 2 * sizeof(float) <= kStagingSlotBytes && EnsureStaging(ctx) == hipSuccess)
+  if (in_bytes <= (size_t{1} << 19) && out_bytes + 2 * sizeof(float) <= kStagingSlotBytes && EnsureStaging(ctx) == hipSuccess)
   {
     char* const up = static_cast<char*>(ctx->host_staging);
     char* const down = up + kStagingSlotBytes;
