@@ -22,6 +22,9 @@
 #include <type_traits>
 #include <utility>
 #include <vector>
+#ifdef __linux__
+#include <sys/mman.h>
+#endif
 
 namespace vgt_hip
 {
@@ -96,11 +99,19 @@ struct Isometry3
 // all: a map of 256^3 cells is 64 MiB, which malloc maps afresh every time -- 16 384 page faults for the first thread that
 // writes to it, more than a voxelization takes on the device.  A caller that voxelizes frame after frame (the by-value
 // VoxelizePointClouds returns a new map per call) gets the block of the map it dropped a frame ago.  Bounded: at most
-// kMaxBytes are kept, larger or surplus blocks go back to the system.  Process-wide, thread-safe.
+// Limit() bytes are kept, larger or surplus blocks go back to the system.  Process-wide, thread-safe.
 class GridBlockCache
 {
 public:
-  static constexpr size_t kMinBytes = size_t{1} << 20, kMaxBytes = size_t{512} << 20;
+  static constexpr size_t kMinBytes = size_t{1} << 20, kDefaultMaxBytes = size_t{512} << 20, kHugePage = size_t{2} << 20;
+  // How much the cache may hold (default 512 MiB).  A process that extracts fields of several GiB in a loop can raise it
+  // so that the block of the field it dropped is the block of the next one: no unmapping (4 GiB: 0.2 - 0.4 s on the
+  // caller's thread) and no page faults.
+  static void SetLimit(size_t bytes) noexcept
+  {
+    std::lock_guard<std::mutex> lock(Guard());
+    Limit() = bytes;
+  }
   static void* Take(size_t bytes)
   {
     if (bytes >= kMinBytes)
@@ -116,8 +127,15 @@ public:
           return p;
         }
     }
+    // Fresh blocks of 2 MiB and more start on a huge-page boundary and ask for huge pages (a hint; where the kernel gives
+    // them on request a 4 GiB grid is 2 048 page faults instead of a million, and page-locking it for a copy takes 8 ms
+    // instead of 70 - 140).
     void* p = nullptr;
-    if (posix_memalign(&p, 4096, bytes < 4096 ? 4096 : bytes) != 0) throw std::bad_alloc();
+    const size_t alignment = bytes >= kHugePage ? kHugePage : 4096;
+    if (posix_memalign(&p, alignment, bytes < 4096 ? 4096 : bytes) != 0) throw std::bad_alloc();
+#ifdef __linux__
+    if (bytes >= kHugePage) (void)madvise(p, bytes & ~(kHugePage - 1), MADV_HUGEPAGE);
+#endif
     return p;
   }
   static void Give(void* p, size_t bytes) noexcept
@@ -125,7 +143,7 @@ public:
     if (bytes >= kMinBytes)
     {
       std::lock_guard<std::mutex> lock(Guard());
-      if (Held() + bytes <= kMaxBytes)
+      if (Held() + bytes <= Limit())
       {
         Blocks().emplace_back(p, bytes);
         Held() += bytes;
@@ -159,6 +177,11 @@ private:
   {
     static size_t held = 0;
     return held;
+  }
+  static size_t& Limit()
+  {
+    static size_t limit = kDefaultMaxBytes;
+    return limit;
   }
 };
 
@@ -225,6 +248,33 @@ public:
     grid.ny_ = other.ny_;
     grid.nz_ = other.nz_;
     grid.data_.resize(other.data_.size());
+    return grid;
+  }
+  // A grid of the given frame and extents whose cells are allocated but NOT initialised (not even touched): for the
+  // fields an extraction hands back, every cell of which the download writes.  A fill first would cost more than the
+  // whole device path (1024^3: 4 GiB of stores and a million page faults before a 153 ms extraction).
+  static DenseGrid Uninitialized(const Isometry3& origin_transform, const std::string& frame, double resolution,
+                                 int64_t num_x, int64_t num_y, int64_t num_z)
+  {
+    DenseGrid grid = ShapeOnly(origin_transform, frame, resolution, num_x, num_y, num_z);
+    grid.data_.resize(static_cast<size_t>(num_x * num_y * num_z));
+    return grid;
+  }
+  // Frame, transform and extents without cells (IsInitialized() is false): the geometry a device-resident map keeps
+  // for the fields it hands back.
+  static DenseGrid ShapeOnly(const Isometry3& origin_transform, const std::string& frame, double resolution,
+                             int64_t num_x, int64_t num_y, int64_t num_z)
+  {
+    if (!(resolution > 0.0) || num_x <= 0 || num_y <= 0 || num_z <= 0)
+      throw std::invalid_argument("Grid must have positive resolution and voxel counts");
+    DenseGrid grid;
+    grid.origin_ = origin_transform;
+    grid.inverse_origin_ = origin_transform.Inverse();
+    grid.frame_ = frame;
+    grid.resolution_ = resolution;
+    grid.nx_ = num_x;
+    grid.ny_ = num_y;
+    grid.nz_ = num_z;
     return grid;
   }
   // VoxelGridSizes::FromGridSizes: counts = size / resolution

@@ -632,6 +632,29 @@ static void HostGridStorageTests()
     EXPECT_TRUE(refilled);  // (recycled storage is still initialised storage)
   }
   GridBlockCache::Release();
+  // the grids an extraction hands back: cells allocated but not filled; the geometry of a device-resident map: no cells
+  {
+    const DenseGrid field = DenseGrid::Uninitialized(Isometry3::Translation(1.0, 2.0, 3.0), "world", 0.5, 160, 128, 32);  // 2.5 MiB
+    EXPECT_TRUE(field.IsInitialized());
+    EXPECT_EQ(field.GetImmutableRawData().size(), static_cast<size_t>(160 * 128 * 32));
+    EXPECT_EQ(reinterpret_cast<uintptr_t>(field.GetImmutableRawData().data()) % (size_t{2} << 20), 0u);  // huge-page aligned
+    const DenseGrid shape = DenseGrid::ShapeOnly(Isometry3::Translation(1.0, 2.0, 3.0), "world", 0.5, 160, 128, 32);
+    EXPECT_TRUE(!shape.IsInitialized() && shape.GetImmutableRawData().empty());
+    EXPECT_TRUE(shape.SameSizes(field) && shape.Frame() == "world" && shape.Resolution() == 0.5);
+    bool threw = false;
+    try { (void)DenseGrid::Uninitialized(Isometry3::Identity(), "world", 0.0, 4, 4, 4); } catch (const std::invalid_argument&) { threw = true; }
+    EXPECT_TRUE(threw);
+  }
+  // the cache's limit: nothing is kept at 0, the default keeps the block
+  {
+    GridBlockCache::SetLimit(0);
+    const float* block = nullptr;
+    { OccupancyMap a = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 0.64, 0.0f); block = a.GetImmutableRawData().data(); }
+    GridBlockCache::SetLimit(GridBlockCache::kDefaultMaxBytes);
+    { OccupancyMap b = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 0.64, 0.0f); block = b.GetImmutableRawData().data(); }
+    { OccupancyMap c = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.01, 0.64, 0.64, 0.64, 0.0f); EXPECT_TRUE(c.GetImmutableRawData().data() == block); }
+    GridBlockCache::Release();
+  }
   // small grids never enter the cache
   { OccupancyMap tiny = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.25, 1.0, 2.0, 3.0, 0.0f); (void)tiny; }
 }

@@ -333,8 +333,8 @@ SignedDistanceField ExtractSignedDistanceField(
   if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
   SignedDistanceField sdf;
   sdf.oob_value = parameters.oob_value;
-  sdf.grid = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
-                       map.NumYVoxels(), map.NumZVoxels(), parameters.oob_value);
+  sdf.grid = DenseGrid::Uninitialized(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                                      map.NumYVoxels(), map.NumZVoxels());  // every cell is written below
   if (!parameters.hip_devices.empty())
   {
     // the large-grid branch: one Z slab per listed device, one process, one RCCL exchange
@@ -374,8 +374,8 @@ std::vector<SignedDistanceField> ExtractSignedDistanceFields(
     if (!map || !map->IsInitialized()) throw std::invalid_argument("Grid must be initialized");
     if (!map->SameSizes(*maps[0])) throw std::invalid_argument("the maps of a batch must have the same sizes");
     fields[i].oob_value = parameters.oob_value;
-    fields[i].grid = DenseGrid(map->OriginTransform(), map->Frame(), map->Resolution(), map->NumXVoxels(),
-                               map->NumYVoxels(), map->NumZVoxels(), parameters.oob_value);
+    fields[i].grid = DenseGrid::Uninitialized(map->OriginTransform(), map->Frame(), map->Resolution(),
+                                              map->NumXVoxels(), map->NumYVoxels(), map->NumZVoxels());
     inputs.push_back(map->GetImmutableRawData().data());
     outputs.push_back(fields[i].grid.GetMutableRawData().data());
   }
@@ -501,8 +501,8 @@ SignedDistanceField ExtractSignedDistanceField(
                                 &cells);
   SignedDistanceField sdf;
   sdf.oob_value = parameters.oob_value;
-  sdf.grid = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
-                       map.NumYVoxels(), map.NumZVoxels(), parameters.oob_value);
+  sdf.grid = DenseGrid::Uninitialized(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                                      map.NumYVoxels(), map.NumZVoxels());  // every cell is written below
   if (rc == VGT_HIP_OK)
     rc = vgt_hip_cells_sdf(ctx, cells, nullptr, 0, map.Resolution(), parameters.unknown_is_filled ? 1 : 0,
                            parameters.add_virtual_border ? 1 : 0, sdf.grid.GetMutableRawData().data(),
@@ -518,8 +518,8 @@ SignedDistanceField ExtractSignedDistanceField(
 DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyMap& map, int hip_device)
 {
   if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
-  shape_ = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(), map.NumYVoxels(),
-                     map.NumZVoxels(), 0.0f);
+  shape_ = DenseGrid::ShapeOnly(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                                map.NumYVoxels(), map.NumZVoxels());
   Upload(map.GetImmutableRawData().data(), static_cast<int>(sizeof(TaggedObjectOccupancyCell)),
          static_cast<int>(offsetof(TaggedObjectOccupancyCell, object_id)), hip_device);
 }
@@ -527,8 +527,8 @@ DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyMap& map
 DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyComponentMap& map, int hip_device)
 {
   if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
-  shape_ = DenseGrid(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(), map.NumYVoxels(),
-                     map.NumZVoxels(), 0.0f);
+  shape_ = DenseGrid::ShapeOnly(map.OriginTransform(), map.Frame(), map.Resolution(), map.NumXVoxels(),
+                                map.NumYVoxels(), map.NumZVoxels());
   Upload(map.GetImmutableRawData().data(), static_cast<int>(sizeof(TaggedObjectOccupancyComponentCell)),
          static_cast<int>(offsetof(TaggedObjectOccupancyComponentCell, object_id)), hip_device);
 }
@@ -559,8 +559,8 @@ SignedDistanceField DeviceTaggedObjectMap::EmptyField(
 {
   SignedDistanceField sdf;
   sdf.oob_value = parameters.oob_value;
-  sdf.grid = DenseGrid(shape_.OriginTransform(), shape_.Frame(), shape_.Resolution(), shape_.NumXVoxels(),
-                       shape_.NumYVoxels(), shape_.NumZVoxels(), parameters.oob_value);
+  sdf.grid = DenseGrid::Uninitialized(shape_.OriginTransform(), shape_.Frame(), shape_.Resolution(),
+                                      shape_.NumXVoxels(), shape_.NumYVoxels(), shape_.NumZVoxels());
   return sdf;
 }
 

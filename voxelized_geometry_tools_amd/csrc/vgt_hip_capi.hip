@@ -3,11 +3,13 @@
 #include "../../include/vgt_hip.h"
 
 #include "vgt_internal.hpp"
+#include "host_pages.hpp"
 
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -589,6 +591,89 @@ hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCop
   return err;
 }
 
+// Many host arrays that hold data into device buffers: the twin of DownloadToHostArrays.  Page-locking a 1 MiB array for
+// one copy costs ~0.15 ms (register + unregister) where the copy itself takes 0.02 -- 64 maps of 64^3 spent 10 ms
+// there.  The workers copy slices of each piece into a slot of the ring, the calling thread sends full slots on.
+// At return every copy is ENQUEUED on `s` (the ring is only reused by work enqueued on `s` later).
+hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& arrays, size_t bytes, hipStream_t s)
+{
+  if (arrays.empty() || bytes == 0) return hipSuccess;
+  {
+    const hipError_t err = EnsureStaging(ctx);
+    if (err != hipSuccess) return err;
+  }
+  while (static_cast<int>(ctx->staging_events.size()) < kStagingSlots)
+  {
+    hipEvent_t e = nullptr;
+    const hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (err != hipSuccess) return err;
+    ctx->staging_events.push_back(e);
+  }
+  struct Piece
+  {
+    size_t array, offset, bytes;
+  };
+  std::vector<Piece> pieces;
+  for (size_t a = 0; a < arrays.size(); a++)
+    for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
+      pieces.push_back(Piece{a, off, std::min(kStagingSlotBytes, bytes - off)});
+  const int workers = static_cast<int>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)));
+  // filled[i]: workers done writing piece i into its slot; sent[i]: its copy to the device is enqueued and its event recorded
+  std::vector<std::atomic<int>> filled(pieces.size()), sent(pieces.size());
+  for (auto& f : filled) f.store(0);
+  for (auto& d : sent) d.store(0);
+  std::atomic<int> failed{0};
+  char* const staging = static_cast<char*>(ctx->host_staging);
+  const int device = ctx->device;
+  std::vector<std::thread> pool;
+  for (int w = 0; w < workers; w++)
+    pool.emplace_back([&, w]() {
+      (void)hipSetDevice(device);
+      for (size_t i = 0; i < pieces.size(); i++)
+      {
+        const int slot = static_cast<int>(i % kStagingSlots);
+        if (i >= static_cast<size_t>(kStagingSlots))
+        {
+          // the slot's previous content must have left for the device
+          while (sent[i - kStagingSlots].load(std::memory_order_acquire) == 0)
+          {
+            if (failed.load()) return;
+            std::this_thread::yield();
+          }
+          if (hipEventSynchronize(ctx->staging_events[static_cast<size_t>(slot)]) != hipSuccess)
+          {
+            failed.store(1);
+            return;
+          }
+        }
+        const Piece& p = pieces[i];
+        const size_t pages = (p.bytes + 4095) / 4096;
+        const size_t begin = std::min(p.bytes, pages * static_cast<size_t>(w) / workers * 4096);
+        const size_t end = std::min(p.bytes, pages * static_cast<size_t>(w + 1) / workers * 4096);
+        if (end > begin)
+          std::memcpy(staging + static_cast<size_t>(slot) * kStagingSlotBytes + begin,
+                      static_cast<const char*>(arrays[p.array].host) + p.offset + begin, end - begin);
+        filled[i].fetch_add(1, std::memory_order_release);
+      }
+    });
+  hipError_t err = hipSuccess;
+  for (size_t i = 0; i < pieces.size() && err == hipSuccess; i++)
+  {
+    const int slot = static_cast<int>(i % kStagingSlots);
+    while (filled[i].load(std::memory_order_acquire) < workers && !failed.load()) std::this_thread::yield();
+    if (failed.load()) break;
+    const Piece& p = pieces[i];
+    err = hipMemcpyAsync(static_cast<char*>(const_cast<void*>(arrays[p.array].device)) + p.offset,
+                         staging + static_cast<size_t>(slot) * kStagingSlotBytes, p.bytes, hipMemcpyHostToDevice, s);
+    if (err == hipSuccess) err = hipEventRecord(ctx->staging_events[static_cast<size_t>(slot)], s);
+    if (err == hipSuccess) sent[i].store(1, std::memory_order_release);
+  }
+  if (err != hipSuccess) failed.store(1);
+  for (auto& th : pool) th.join();
+  if (err == hipSuccess && failed.load()) err = hipErrorUnknown;
+  return err;
+}
+
 // The largest group of a batch that one launch can take: CheckBatch's limits (2^20 grids, 2^28 lines, 32-bit item counts)
 // and `device_bytes` of buffers at `bytes_per_grid` each.  At least 1.
 int64_t BatchGroup(int64_t batch, int64_t nx, int64_t ny, int64_t nz, size_t device_bytes, size_t bytes_per_grid)
@@ -622,7 +707,7 @@ bool CanPipelineFromHost(const vgt_hip_ctx* ctx, const vgt::SdfParams& p)
 
 template <typename InT>
 int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, const vgt::SdfParams& p,
-                         float* sdf_dev, float* sdf_host)
+                         float* sdf_dev, float* sdf_host, const std::function<void()>& before_downloads)
 {
   const SdfWorkspace ws = CarveWorkspace(ctx->sdf_ws, p.nx, p.ny, p.nz, ctx->variant);
   if (ctx->sdf_ws_bytes < ws.bytes) return Fail(VGT_HIP_ERR_INVALID_ARGUMENT, "SDF workspace too small");
@@ -662,6 +747,8 @@ int SdfFromHostPipelined(vgt_hip_ctx* ctx, const InT* input_host, InT* in_dev, c
     VGT_TRY_HIP(LaunchPassOne<InT>(in_dev, ws, part, x_begin(c), nullptr, s), "pass 1");
     VGT_TRY_HIP(LaunchPassTwo(ws, part, x_begin(c), ctx->variant, s), "Y pass");
   }
+  // (everything up to here is enqueued and on its way: the moment to make the output array ready for the downloads)
+  before_downloads();
   const size_t pitch = static_cast<size_t>(plane) * sizeof(float);
   for (int c = 0; c < kPipelineChunks; c++)
   {
@@ -690,8 +777,15 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   VGT_TRY_HIP(hipSetDevice(ctx->device), "set device");
   const size_t nvox = static_cast<size_t>(p.nx * p.ny * p.nz);
   const size_t ws_bytes = CarveWorkspace(nullptr, p.nx, p.ny, p.nz, ctx->variant).bytes;
+  // The output is usually an array the caller has just allocated: its pages are faulted in by a few threads while the
+  // input is page-locked and uploaded, and it is page-locked only when the downloads are about to be enqueued.
+  vgt::HostRangePopulator fresh_out(sdf_host, nvox * sizeof(float));
   const ScopedHostPin pin_in(input_host, nvox * sizeof(InT));
-  const ScopedHostPin pin_out(sdf_host, nvox * sizeof(float));
+  std::unique_ptr<ScopedHostPin> pin_out;
+  const auto lock_output = [&]() {
+    fresh_out.Wait();
+    if (!pin_out) pin_out.reset(new ScopedHostPin(sdf_host, nvox * sizeof(float)));
+  };
   std::lock_guard<std::mutex> lock(ctx->mutex);
   hipError_t err = Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, nvox * sizeof(InT));
   if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float) + 256);  // (+ extrema)
@@ -708,7 +802,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   if (CanPipelineFromHost<InT>(ctx, p))
   {
     if (!ctx->minmax_out) return Fail(VGT_HIP_ERR_RUNTIME, "context has no extrema buffer");
-    result = SdfFromHostPipelined<InT>(ctx, input_host, in_dev, p, sdf_dev, sdf_host);
+    result = SdfFromHostPipelined<InT>(ctx, input_host, in_dev, p, sdf_dev, sdf_host, lock_output);
     float mm[2] = {0.0f, 0.0f};
     if (result == VGT_HIP_OK)
     {
@@ -770,6 +864,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   if (result == VGT_HIP_OK)
   {
     float mm[2] = {0.0f, 0.0f};
+    lock_output();  // (upload and kernels are on their way)
     err = hipMemcpyAsync(sdf_host, sdf_dev, nvox * sizeof(float), hipMemcpyDeviceToHost, s);
     if (err == hipSuccess)
       err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, s);
@@ -1744,13 +1839,26 @@ int vgt_hip_sdf_batch_from_occupancy_f32(vgt_hip_ctx* ctx, const float* const* o
   for (int64_t first = 0; first < batch; first += group)
   {
     const int64_t count = batch - first < group ? batch - first : group;
-    // (the inputs are page-locked for the group's uploads -- they hold data, their pages exist; small arrays are left alone)
+    // Inputs of 32 MiB and more are page-locked for the group's uploads (they hold data, their pages exist); smaller
+    // ones -- for which locking and unlocking costs several times the copy -- cross through the context's ring.
     std::vector<std::unique_ptr<ScopedHostPin>> pins;
-    for (int64_t b = 0; b < count; b++) pins.emplace_back(new ScopedHostPin(occupancy_host[first + b], n * sizeof(float)));
-    for (int64_t b = 0; b < count; b++)
-      VGT_TRY_HIP(hipMemcpyAsync(in_dev + static_cast<size_t>(b) * n, occupancy_host[first + b], n * sizeof(float),
-                                 hipMemcpyHostToDevice, s),
-                  "copy occupancy to device");
+    if (n * sizeof(float) >= (size_t{32} << 20))
+    {
+      for (int64_t b = 0; b < count; b++) pins.emplace_back(new ScopedHostPin(occupancy_host[first + b], n * sizeof(float)));
+      for (int64_t b = 0; b < count; b++)
+        VGT_TRY_HIP(hipMemcpyAsync(in_dev + static_cast<size_t>(b) * n, occupancy_host[first + b], n * sizeof(float),
+                                   hipMemcpyHostToDevice, s),
+                    "copy occupancy to device");
+    }
+    else
+    {
+      std::vector<HostArrayCopy> uploads;
+      for (int64_t b = 0; b < count; b++)
+        uploads.push_back(HostArrayCopy{in_dev + static_cast<size_t>(b) * n, const_cast<float*>(occupancy_host[first + b])});
+      const hipError_t moved = UploadFromHostArrays(ctx, uploads, n * sizeof(float), s);
+      if (moved != hipSuccess) (void)hipStreamSynchronize(s);
+      VGT_TRY_HIP(moved, "copy occupancy to device");
+    }
     vgt::SdfParams p{nx, ny, nz, resolution, unknown_is_filled ? 1 : 0, add_virtual_border ? 1 : 0};
     if (ctx->variant == vgt::EdtVariant::kDefault)
     {
@@ -1874,15 +1982,39 @@ static int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_obj
                                  ctx->minmax_out, nullptr);
 }
 
+// A field of the context's stream into a host array (usually one the caller has just allocated) + the extrema.  The
+// kernels that produce it are enqueued, not finished: preparing the array overlaps them.  Large arrays are faulted in
+// by a few threads and page-locked for one DMA; medium ones cross through the context's page-locked ring
+// (DownloadToHostArrays: locking fresh pages costs more than the copy); small ones take the runtime's pageable path.
 static int CopySdfToHost(vgt_hip_ctx* ctx, const float* sdf_dev, int64_t n, float* sdf_host, float* out_min,
                   float* out_max)
 {
   float mm[2] = {0.0f, 0.0f};
-  hipError_t err = hipMemcpyAsync(sdf_host, sdf_dev, static_cast<size_t>(n) * sizeof(float),
-                                  hipMemcpyDeviceToHost, ctx->stream);
-  if (err == hipSuccess)
+  const size_t bytes = static_cast<size_t>(n) * sizeof(float);
+  hipError_t err = hipSuccess;
+  if (bytes >= (size_t{32} << 20))
+  {
+    vgt::HostRangePopulator fresh(sdf_host, bytes);
+    fresh.Wait();
+    const ScopedHostPin pin(sdf_host, bytes);
+    err = hipMemcpyAsync(sdf_host, sdf_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t sync = hipStreamSynchronize(ctx->stream);  // (before the array is unlocked, whatever happened)
+    if (err == hipSuccess) err = sync;
+  }
+  else if (bytes >= (size_t{1} << 20))
+  {
     err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream);
-  if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err == hipSuccess)
+      err = DownloadToHostArrays(ctx, {HostArrayCopy{sdf_dev, sdf_host}}, bytes, ctx->stream);  // (synchronises)
+    if (err != hipSuccess) (void)hipStreamSynchronize(ctx->stream);  // (`mm` is on this stack)
+  }
+  else
+  {
+    err = hipMemcpyAsync(sdf_host, sdf_dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(mm, ctx->minmax_out, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+  }
   if (err != hipSuccess) return FailHip("copy SDF to host", err);
   if (out_min) *out_min = mm[0];
   if (out_max) *out_max = mm[1];

@@ -23,6 +23,7 @@
 #include "../../include/vgt_hip.h"
 
 #include "vgt_internal.hpp"
+#include "host_pages.hpp"
 
 #include <rccl/rccl.h>  // types and prototypes only: the library itself is loaded on first use (below)
 
@@ -384,7 +385,13 @@ extern "C" int vgt_hipx_sdf_multi(const int* devices, int num_devices, const flo
   // uploads run (joined before the first download is enqueued)
   // (the thread writes the call state itself: whichever way this function returns, the joiner below joins the thread
   // before the state's destructor looks at the flag and unlocks the pages)
+  // (an array the caller has just allocated has no pages yet: they are faulted in by several threads first -- page-locking
+  // fresh memory does it on one, 0.3 s for 4 GiB; host_pages.hpp)
   std::thread pin_out([&st, sdf_host, total_bytes] {
+    {
+      vgt::HostRangePopulator fresh(sdf_host, total_bytes);
+      fresh.Wait();
+    }
     st.registered_out = hipHostRegister(sdf_host, total_bytes, hipHostRegisterPortable) == hipSuccess;
   });
   struct Joiner
