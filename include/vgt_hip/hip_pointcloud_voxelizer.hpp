@@ -161,7 +161,7 @@ public:
 private:
   void Upload(const void* cells, int cell_bytes, int object_id_offset, int hip_device);
   SignedDistanceField EmptyField(const SignedDistanceFieldGenerationParameters& parameters) const;
-  ::vgt_hip_ctx* ctx_ = nullptr;
+  ::vgt_hip_ctx* ctx_ = nullptr;  // the process's context of the device (not owned)
   ::vgt_hip_cells* cells_ = nullptr;
   DenseGrid shape_;  // origin / frame / sizes of the map, for the fields handed back
 };

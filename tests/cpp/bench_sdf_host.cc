@@ -132,7 +132,7 @@ int main(int argc, char** argv)
     }
   }
   // one field of a tagged map: 256^3 (64 MiB out) and 128^3 (8 MiB out)
-  Clock tagged_large, tagged_medium;
+  Clock tagged_large, tagged_medium, tagged_one_shot;
   for (const int64_t n : {int64_t{256}, int64_t{128}})
   {
     TaggedObjectOccupancyMap tagged(Isometry3::Identity(), "bench", 0.02, n, n, n, TaggedObjectOccupancyCell());
@@ -142,6 +142,15 @@ int main(int argc, char** argv)
           for (int64_t z = 0; z < n / 10; z++)
             tagged.SetIndex((id * 37) % (n - n / 10) + x, (id * 53) % (n - n / 10) + y, (id * 71) % (n - n / 10) + z,
                             TaggedObjectOccupancyCell{1.0f, id});
+    if (n == 128)
+      for (int r = 0; r < reps * 4; r++)
+      {
+        // the reference's one-shot interface: upload, extract, drop
+        const double t0 = Now();
+        const SignedDistanceField sdf = DeviceTaggedObjectMap(tagged).ExtractSignedDistanceField({}, params);
+        tagged_one_shot.Add(Now() - t0);
+        checksum += sdf.maximum;
+      }
     const DeviceTaggedObjectMap device_map(tagged);
     Clock& clock = n == 256 ? tagged_large : tagged_medium;
     for (int r = 0; r < reps * 4; r++)
@@ -149,6 +158,21 @@ int main(int argc, char** argv)
       const double t0 = Now();
       const SignedDistanceField sdf = device_map.ExtractSignedDistanceField({}, params);
       clock.Add(Now() - t0);
+      checksum += sdf.maximum;
+    }
+  }
+  // a component map (uploaded, extracted and dropped per call, as the reference's interface has it)
+  Clock component;
+  {
+    OccupancyComponentMap map(Isometry3::Identity(), "bench", 0.02, 128, 128, 128, OccupancyComponentCell());
+    for (int64_t x = 40; x < 60; x++)
+      for (int64_t y = 30; y < 90; y++)
+        for (int64_t z = 50; z < 70; z++) map.SetIndex(x, y, z, OccupancyComponentCell{1.0f, 1u});
+    for (int r = 0; r < reps * 4; r++)
+    {
+      const double t0 = Now();
+      const SignedDistanceField sdf = ExtractSignedDistanceField(map, params);
+      component.Add(Now() - t0);
       checksum += sdf.maximum;
     }
   }
@@ -175,6 +199,8 @@ int main(int argc, char** argv)
   objects.Print("MakeAllObjectSDFs, 32 objects in 128^3", false);
   tagged_large.Print("tagged map 256^3, one field", false);
   tagged_medium.Print("tagged map 128^3, one field", false);
+  tagged_one_shot.Print("tagged map 128^3, uploaded per call", false);
+  component.Print("component map 128^3", false);
   if (slabs.n > 0) slabs.Print("one large map over two slabs of device 0", false);
   std::printf("\"checksum\": %.6g}\n", checksum);
   return 0;

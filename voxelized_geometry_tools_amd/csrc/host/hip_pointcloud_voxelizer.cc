@@ -491,9 +491,7 @@ SignedDistanceField ExtractSignedDistanceField(
     const OccupancyComponentMap& map, const SignedDistanceFieldGenerationParameters& parameters)
 {
   if (!map.IsInitialized()) throw std::invalid_argument("Grid must be initialized");
-  vgt_hip_ctx* ctx = nullptr;
-  if (vgt_hip_create(parameters.hip_device, -1, &ctx) != VGT_HIP_OK)
-    throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
+  vgt_hip_ctx* ctx = SharedSdfContext(parameters.hip_device);  // (the process's context of that device: no set-up per call)
   vgt_hip_cells* cells = nullptr;
   // the component does not enter the SDF (occupancy_component_map.hpp:276-296): no object id
   int rc = vgt_hip_cells_create(ctx, map.GetImmutableRawData().data(), map.NumXVoxels(), map.NumYVoxels(),
@@ -509,7 +507,6 @@ SignedDistanceField ExtractSignedDistanceField(
                            &sdf.minimum, &sdf.maximum);
   const std::string msg = (rc == VGT_HIP_OK) ? std::string() : std::string(vgt_hip_last_error());
   vgt_hip_cells_destroy(cells);
-  vgt_hip_destroy(ctx);
   if (rc != VGT_HIP_OK) ThrowForCode(rc, msg);
   sdf.locked = true;
   return sdf;
@@ -535,14 +532,15 @@ DeviceTaggedObjectMap::DeviceTaggedObjectMap(const TaggedObjectOccupancyComponen
 
 void DeviceTaggedObjectMap::Upload(const void* cells, int cell_bytes, int object_id_offset, int hip_device)
 {
-  if (vgt_hip_create(hip_device, -1, &ctx_) != VGT_HIP_OK)
-    throw std::runtime_error(std::string("HIP SDF backend is not available: ") + vgt_hip_last_error());
+  // The process's context of that device (SharedSdfContext), not one per map: creating a context -- streams, events, its
+  // buffers -- costs 14 ms, ten times the extraction of a 128^3 map, and the reference's interface constructs a map's
+  // device side per call.  Calls on the maps of one device queue behind each other on its stream.
+  ctx_ = SharedSdfContext(hip_device);
   const int rc = vgt_hip_cells_create(ctx_, cells, shape_.NumXVoxels(), shape_.NumYVoxels(),
                                       shape_.NumZVoxels(), cell_bytes, object_id_offset, &cells_);
   if (rc != VGT_HIP_OK)
   {
     const std::string msg = vgt_hip_last_error();
-    vgt_hip_destroy(ctx_);
     ctx_ = nullptr;
     ThrowForCode(rc, msg);
   }
@@ -550,8 +548,7 @@ void DeviceTaggedObjectMap::Upload(const void* cells, int cell_bytes, int object
 
 DeviceTaggedObjectMap::~DeviceTaggedObjectMap()
 {
-  vgt_hip_cells_destroy(cells_);
-  vgt_hip_destroy(ctx_);
+  vgt_hip_cells_destroy(cells_);  // (the context is the process's, it stays)
 }
 
 SignedDistanceField DeviceTaggedObjectMap::EmptyField(
