@@ -280,6 +280,26 @@ def raycast_section():
     return out
 
 
+def cpp_host_layer():
+    """The SDF entry points of the C++ host layer as a caller of the reference's interface sees them -- a map in host
+    memory in, a NEW SignedDistanceField out per call (tests/cpp/bench_sdf_host, a child process): the 1024^3 map, a
+    40^3 map, 64 maps of 64^3 as one batch, MakeAllObjectSDFs, single tagged / component maps, the two-slab entry point."""
+    import subprocess
+    binary = os.path.join(ROOT, "tests", "cpp", "bench_sdf_host")
+    if not os.path.exists(binary):
+        return {"error": "tests/cpp/bench_sdf_host not built (make -C tests/cpp bench_sdf_host)"}
+    try:
+        run = subprocess.run([binary, "1024", "3", "slabs"], capture_output=True, text=True, timeout=300)
+        if run.returncode != 0:
+            return {"error": (run.stdout + run.stderr)[-400:]}
+        out = json.loads(run.stdout.strip().splitlines()[-1])
+        out["note"] = ("ms per blocking call, result grids freshly allocated by every call (best / mean over the calls; "
+                       "first = the process's first call with context set-up and first page-locking of the input)")
+        return out
+    except Exception as exc:
+        return {"error": repr(exc)}
+
+
 def multi_host_path(torch, shape, res):
     """vgt_hipx_sdf_multi (one process, host arrays in and out, one Z slab per listed device) with ALL EIGHT slabs on
     this one GPU: the data movement of the 8-GPU call -- rows of nz / 8 floats at a pitch of nz (512 B at nz = 1024) in
@@ -722,6 +742,8 @@ def main():
                         line["multi_host_path"]["vs_pcie_lower_bound"] = round(line["multi_host_path"]["call_ms"] / bound, 3)
                 except Exception as exc:
                     line["multi_host_path"] = {"error": repr(exc)}
+            if headline:
+                line["cpp_host_layer"] = cpp_host_layer()
         if not args.no_cpu_baseline and not dist_on:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         else:
