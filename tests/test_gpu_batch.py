@@ -106,6 +106,34 @@ def test_batch_is_cut_into_launches_when_large(ctx):
         assert (float(lo[b]), float(hi[b])) == (slo, shi)
 
 
+@pytest.mark.parametrize("shape", [(160, 128, 144), (208, 208, 208)], ids=["12MB-two-ring-slots", "36MB-page-locked"])
+def test_host_copy_paths_by_array_size(ctx, shape):
+    """The host entry points move the caller's arrays by size: below 32 MiB through the context's ring of page-locked 8 MiB
+    slots (one slot, several slots per array, both directions), from 32 MiB page-locked in place with a fresh output
+    faulted in by helper threads first.  Every path bit-equal to the plain single call."""
+    grids = [np.ascontiguousarray(synthetic.make_occupancy(shape, kind, seed=9 + k))
+             for k, kind in enumerate(["spheres", "salt", "unknown_mix"])]
+    fields, lo, hi = ctx.sdf_batch_from_occupancy(grids, 0.02)
+    singles = [ctx.sdf_from_occupancy(g, 0.02) for g in grids]
+    for b, (single, slo, shi) in enumerate(singles):
+        assert bits_equal(fields[b], single), b
+        assert (float(lo[b]), float(hi[b])) == (slo, shi), b
+    # one field of a tagged map into a fresh array (ring / faulted in + page-locked), and its objects as a batch
+    rec = np.zeros(shape, dtype=capi.TAGGED_OBJECT_CELL)
+    rec["occupancy"] = grids[0]
+    rec["object_id"][grids[0] > 0.5] = 7
+    rec["object_id"][: shape[0] // 2][grids[0][: shape[0] // 2] > 0.5] = 3
+    cells = ctx.cells(rec, shape)
+    got, glo, ghi = cells.sdf(0.02)
+    assert bits_equal(got, singles[0][0]) and (glo, ghi) == singles[0][1:]
+    batched = cells.all_object_sdfs(0.02)
+    one_by_one = cells.separate_object_sdfs_one_by_one(0.02, cells.object_ids())
+    assert sorted(batched) == [3, 7]
+    for oid in batched:
+        assert bits_equal(batched[oid][0], one_by_one[oid][0]) and batched[oid][1:] == one_by_one[oid][1:], oid
+    cells.close()
+
+
 def test_all_object_sdfs_as_one_batch(ctx, oracle):
     """A 32-object 128^3 tagged map: the batched MakeAllObjectSDFs against 32 vgt_hip_cells_sdf calls and the oracle."""
     rng = np.random.default_rng(5)
