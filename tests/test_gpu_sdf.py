@@ -155,6 +155,25 @@ def test_degenerate_grids(ctx, oracle):
     assert np.all(np.isneginf(got)) and np.isneginf(lo) and np.isneginf(hi)
 
 
+@pytest.mark.parametrize("shape", [(40, 40, 40), (50, 50, 50), (64, 64, 64), (70, 64, 64)],
+                         ids=["256KB-kernels-on-the-ring", "500KB-kernels-on-the-ring", "1MB-ring-and-DMA", "1.1MB-page-locked"])
+def test_small_maps_back_to_back_with_changing_content(ctx, oracle, shape):
+    """The host entry point moves small maps through ONE page-locked ring that every call reuses (up to 512 KiB the
+    kernels read the map from it and write the field to it directly): calls of one shape with different content, one
+    right behind the other, must each see their own map and return their own field -- nothing cached from the call
+    before on either side of the link."""
+    rng = np.random.default_rng(11)
+    maps = [np.ascontiguousarray((rng.random(shape) < p).astype(np.float32)) for p in (0.002, 0.3, 0.0005, 0.9, 0.05, 0.5)]
+    maps.append(np.zeros(shape, np.float32))
+    maps.append(np.ones(shape, np.float32))
+    want = [oracle.sdf_from_occupancy(m, 0.02) for m in maps]
+    for rnd in range(3):
+        for k in ([0, 1, 2, 3, 4, 5, 6, 7], [7, 3, 3, 0, 6, 1, 5, 2], [4, 4, 6, 7, 0, 2, 1, 3])[rnd]:
+            got, lo, hi = ctx.sdf_from_occupancy(maps[k], 0.02)
+            assert bits_equal(got, want[k][0]), (shape, rnd, k)
+            assert (lo, hi) == want[k][1:], (shape, rnd, k)
+
+
 def test_variants_agree_on_synthetic_distributions(ctx, vctx, oracle):
     shape = (72, 96, 160)
     for dist in ("spheres", "salt", "unknown_mix"):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small maps (the reference's own sizes, example/tutorial.cpp: 40^3): ms per blocking call through the host-pointer entry
-point and per device-resident extraction.  Usage: python tools/bench_small_maps.py"""
+point and per device-resident extraction.  Usage: python tools/bench_small_maps.py [edge ...]"""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ def main():
     out = {}
     with capi.Context(0) as ctx:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        for edge in (16, 40, 64):
+        for edge in ([int(a) for a in sys.argv[1:]] or (16, 40, 64)):
             shape = (edge,) * 3
             occ = np.ascontiguousarray(synthetic.occupancy_spheres(shape, seed=42))
             out_host = np.empty_like(occ)

@@ -788,7 +788,7 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
   };
   std::lock_guard<std::mutex> lock(ctx->mutex);
   hipError_t err = Reserve(&ctx->sdf_in, &ctx->sdf_in_bytes, nvox * sizeof(InT));
-  if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float) + 256);  // (+ extrema)
+  if (err == hipSuccess) err = Reserve(&ctx->sdf_out, &ctx->sdf_out_bytes, nvox * sizeof(float));
   if (err == hipSuccess) err = Reserve(&ctx->sdf_ws, &ctx->sdf_ws_bytes, ws_bytes);
   if (err != hipSuccess)
   {
@@ -822,38 +822,33 @@ int SdfFromHost(vgt_hip_ctx* ctx, const InT* input_host, const vgt::SdfParams& p
     }
     return result;
   }
-  // Small maps (the sizes of the reference's own examples and tests; up to 512 KiB -- at 1 MiB page-locking the arrays wins):
-  // the map goes through the context's page-locked ring in both directions -- one plain memcpy into it, one DMA each way,
-  // the extrema riding behind the field in the SAME download -- instead of two pageable copies, which the runtime stages
-  // itself at several times the cost, and a third copy for two floats.
+  // Small maps (the sizes of the reference's own examples and tests; up to 512 KiB) never cross the link as copies: the map
+  // is copied into a page-locked slot of the context's ring and the kernels work ON the ring -- pass 1 reads the map from
+  // host memory, the X pass writes the field to it, the extrema behind the field -- so a call is one memcpy in, five
+  // dispatches, one wait, one memcpy out.  No DMA dispatch in either direction, no pageable copy that the runtime would
+  // stage itself, no third copy for two floats: 40^3 0.115 ms per blocking call in round 5, 0.078 - 0.085 with a DMA each
+  // way between the ring and the device buffers, 0.060 - 0.072 now; 16^3 0.066 / 0.048 / 0.037
+  // (profiles/r6/experiments.md).  A kernel reads host memory slowly, so not beyond 512 KiB (1 MiB: 0.37 ms against
+  // 0.13 - 0.36 with page-locked arrays, which is what larger maps get below).
   const size_t in_bytes = nvox * sizeof(InT), out_bytes = nvox * sizeof(float);
   if (in_bytes <= (size_t{1} << 19) && out_bytes + 2 * sizeof(float) <= kStagingSlotBytes && EnsureStaging(ctx) == hipSuccess)
   {
     char* const up = static_cast<char*>(ctx->host_staging);
     char* const down = up + kStagingSlotBytes;
     std::memcpy(up, input_host, in_bytes);
-    err = hipMemcpyAsync(in_dev, up, in_bytes, hipMemcpyHostToDevice, s);
-    if (err != hipSuccess)
-      result = FailHip("copy occupancy to device", err);
-    else  // (extrema behind the field: ctx->sdf_out has room, see Reserve above)
-      result = RunSdfPipeline<InT>(ctx, in_dev, p, sdf_dev, ctx->sdf_ws, ctx->sdf_ws_bytes, sdf_dev + nvox, nullptr);
+    float* const field = reinterpret_cast<float*>(down);
+    result = RunSdfPipeline<InT>(ctx, reinterpret_cast<const InT*>(up), p, field, ctx->sdf_ws, ctx->sdf_ws_bytes,
+                                 field + nvox, nullptr);
+    err = hipStreamSynchronize(s);  // (whatever happened: the ring is reused by the next call)
+    if (result == VGT_HIP_OK && err != hipSuccess) result = FailHip("small-map SDF extraction", err);
     if (result == VGT_HIP_OK)
     {
-      err = hipMemcpyAsync(down, sdf_dev, out_bytes + 2 * sizeof(float), hipMemcpyDeviceToHost, s);
-      if (err == hipSuccess) err = hipStreamSynchronize(s);
-      if (err != hipSuccess)
-        result = FailHip("copy SDF to host", err);
-      else
-      {
-        std::memcpy(sdf_host, down, out_bytes);
-        float mm[2];
-        std::memcpy(mm, down + out_bytes, sizeof(mm));
-        if (out_min) *out_min = mm[0];
-        if (out_max) *out_max = mm[1];
-      }
+      std::memcpy(sdf_host, down, out_bytes);
+      float mm[2];
+      std::memcpy(mm, down + out_bytes, sizeof(mm));
+      if (out_min) *out_min = mm[0];
+      if (out_max) *out_max = mm[1];
     }
-    else
-      (void)hipStreamSynchronize(s);
     return result;
   }
   err = hipMemcpyAsync(in_dev, input_host, nvox * sizeof(InT), hipMemcpyHostToDevice, s);
