@@ -161,6 +161,31 @@ int main(int argc, char** argv)
       checksum += sdf.maximum;
     }
   }
+  // a tagged map of the reference's own test sizes: one field from the resident map, and the one-shot form
+  Clock tagged_small, tagged_small_one_shot;
+  {
+    TaggedObjectOccupancyMap tagged(Isometry3::Identity(), "bench", 0.25, 40, 40, 40, TaggedObjectOccupancyCell());
+    for (uint32_t id = 1; id <= 4; id++)
+      for (int64_t x = 0; x < 6; x++)
+        for (int64_t y = 0; y < 6; y++)
+          for (int64_t z = 0; z < 6; z++)
+            tagged.SetIndex((id * 7) % 34 + x, (id * 11) % 34 + y, (id * 13) % 34 + z, TaggedObjectOccupancyCell{1.0f, id});
+    for (int r = 0; r < 200; r++)
+    {
+      const double t0 = Now();
+      const SignedDistanceField sdf = DeviceTaggedObjectMap(tagged).ExtractSignedDistanceField({}, params);
+      tagged_small_one_shot.Add(Now() - t0);
+      checksum += sdf.maximum;
+    }
+    const DeviceTaggedObjectMap device_map(tagged);
+    for (int r = 0; r < 200; r++)
+    {
+      const double t0 = Now();
+      const SignedDistanceField sdf = device_map.ExtractSignedDistanceField({}, params);
+      tagged_small.Add(Now() - t0);
+      checksum += sdf.maximum;
+    }
+  }
   // a component map (uploaded, extracted and dropped per call, as the reference's interface has it)
   Clock component;
   {
@@ -200,6 +225,8 @@ int main(int argc, char** argv)
   tagged_large.Print("tagged map 256^3, one field", false);
   tagged_medium.Print("tagged map 128^3, one field", false);
   tagged_one_shot.Print("tagged map 128^3, uploaded per call", false);
+  tagged_small.Print("tagged map 40^3, one field", false);
+  tagged_small_one_shot.Print("tagged map 40^3, uploaded per call", false);
   component.Print("component map 128^3", false);
   if (slabs.n > 0) slabs.Print("one large map over two slabs of device 0", false);
   std::printf("\"checksum\": %.6g}\n", checksum);

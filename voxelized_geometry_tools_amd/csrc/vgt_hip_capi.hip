@@ -1958,7 +1958,7 @@ static int CheckCells(const vgt_hip_ctx* ctx, const vgt_hip_cells* cells)
 // mask (mode, objects) -> signed distance field in `sdf_dev`, extrema in ctx->minmax_out.
 // Caller holds the context mutex.
 static int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_objects, const vgt::SdfParams& p,
-                float* sdf_dev)
+                float* sdf_dev, float* minmax_dev = nullptr)  // (extrema: the context's two floats unless told otherwise)
 {
   const int64_t n = c->nx * c->ny * c->nz;
   VGT_TRY_HIP(vgt::LaunchCellMask(c->records, n, c->cell_bytes, c->object_id_offset, mode, c->objects,
@@ -1974,7 +1974,7 @@ static int RunCellsSdf(vgt_hip_ctx* ctx, vgt_hip_cells* c, int mode, int num_obj
     VGT_TRY_HIP(Reserve(&c->workspace, &c->workspace_bytes, need), "allocate SDF workspace");
   }
   return RunSdfPipeline<uint8_t>(ctx, c->mask, mask_params, sdf_dev, c->workspace, c->workspace_bytes,
-                                 ctx->minmax_out, nullptr);
+                                 minmax_dev ? minmax_dev : ctx->minmax_out, nullptr);
 }
 
 // A field of the context's stream into a host array (usually one the caller has just allocated) + the extrema.  The
@@ -2187,6 +2187,21 @@ int vgt_hip_cells_sdf(vgt_hip_ctx* ctx, vgt_hip_cells* cells, const uint32_t* ob
   }
   const vgt::SdfParams p{cells->nx, cells->ny, cells->nz, resolution, unknown_is_filled ? 1 : 0,
                          add_virtual_border ? 1 : 0};
+  const size_t n = static_cast<size_t>(cells->nx * cells->ny * cells->nz);
+  if (n * sizeof(float) <= (size_t{1} << 19) && EnsureStaging(ctx) == hipSuccess)
+  {
+    // a small field: the X pass writes it, and the extrema behind it, straight into the context's page-locked ring
+    // (as SdfFromHost does for small maps: no download, one wait, one memcpy)
+    float* const field = reinterpret_cast<float*>(static_cast<char*>(ctx->host_staging) + kStagingSlotBytes);
+    rc = RunCellsSdf(ctx, cells, objects.empty() ? 0 : 1, static_cast<int>(objects.size()), p, field, field + n);
+    const hipError_t err = hipStreamSynchronize(ctx->stream);
+    if (rc == VGT_HIP_OK && err != hipSuccess) rc = FailHip("small tagged-map SDF extraction", err);
+    if (rc != VGT_HIP_OK) return rc;
+    std::memcpy(sdf_host, field, n * sizeof(float));
+    if (out_min) *out_min = field[n];
+    if (out_max) *out_max = field[n + 1];
+    return VGT_HIP_OK;
+  }
   rc = RunCellsSdf(ctx, cells, objects.empty() ? 0 : 1, static_cast<int>(objects.size()), p, cells->sdf);
   if (rc != VGT_HIP_OK)
   {
