@@ -500,102 +500,57 @@ hipError_t EnsureStaging(vgt_hip_ctx* ctx)
   }
   return err;
 }
-hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& fields, size_t bytes, hipStream_t s)
+// One trip of the ring: a slot's worth of bytes that is either part of ONE array (arrays larger than a slot) or SEVERAL
+// whole arrays whose device sides lie one behind the other (small arrays: one DMA and one hand-shake per slot instead of
+// one per array -- 64 maps of 64^3 are 8 trips, not 64).
+struct RingPiece
 {
-  if (fields.empty() || bytes == 0) return hipSuccess;
+  size_t first, count;  // arrays [first, first + count)
+  size_t offset;        // into the array (count == 1)
+  size_t bytes;         // of the whole piece
+};
+std::vector<RingPiece> RingPieces(const std::vector<HostArrayCopy>& arrays, size_t bytes)
+{
+  std::vector<RingPiece> pieces;
+  if (bytes >= kStagingSlotBytes)
   {
-    const hipError_t err = EnsureStaging(ctx);
-    if (err != hipSuccess) return err;
+    for (size_t a = 0; a < arrays.size(); a++)
+      for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
+        pieces.push_back(RingPiece{a, 1, off, std::min(kStagingSlotBytes, bytes - off)});
+    return pieces;
   }
-  while (static_cast<int>(ctx->staging_events.size()) < kStagingSlots)
+  const size_t per_slot = kStagingSlotBytes / bytes;
+  for (size_t a = 0; a < arrays.size();)
   {
-    hipEvent_t e = nullptr;
-    const hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    if (err != hipSuccess) return err;
-    ctx->staging_events.push_back(e);
+    size_t count = 1;
+    while (count < per_slot && a + count < arrays.size() &&
+           static_cast<const char*>(arrays[a + count].device) == static_cast<const char*>(arrays[a].device) + count * bytes)
+      count++;
+    pieces.push_back(RingPiece{a, count, 0, count * bytes});
+    a += count;
   }
-  // the pieces, in order: (field, offset, bytes), each at most one slot
-  struct Piece
+  return pieces;
+}
+// bytes [begin, end) of a piece between its slot and the caller's arrays
+void CopyPieceRange(const std::vector<HostArrayCopy>& arrays, size_t bytes, const RingPiece& p, char* slot, size_t begin,
+                    size_t end, bool to_host)
+{
+  while (begin < end)
   {
-    size_t field, offset, bytes;
-  };
-  std::vector<Piece> pieces;
-  for (size_t f = 0; f < fields.size(); f++)
-    for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
-      pieces.push_back(Piece{f, off, std::min(kStagingSlotBytes, bytes - off)});
-  const int workers = static_cast<int>(std::max(1u, std::min(16u, std::thread::hardware_concurrency() / 2)));
-#ifdef __linux__
-  // (fresh arrays of several MiB: ask for huge pages where the kernel gives them on request -- 2 MiB per fault instead of
-  // 4 KiB; a hint, any answer is fine)
-  if (bytes >= (size_t{4} << 20))
-    for (const HostArrayCopy& f : fields)
-    {
-      const uintptr_t begin = (reinterpret_cast<uintptr_t>(f.host) + 4095) & ~uintptr_t{4095};
-      const uintptr_t end = (reinterpret_cast<uintptr_t>(f.host) + bytes) & ~uintptr_t{4095};
-      if (end > begin) (void)madvise(reinterpret_cast<void*>(begin), end - begin, MADV_HUGEPAGE);
-    }
-#endif
-  // arrived[i]: the copy of piece i into its slot has been ENQUEUED (its event recorded); copied[i]: workers done with it
-  std::vector<std::atomic<int>> arrived(pieces.size()), copied(pieces.size());
-  for (auto& a : arrived) a.store(0);
-  for (auto& c : copied) c.store(0);
-  std::atomic<int> failed{0};
-  char* const staging = static_cast<char*>(ctx->host_staging);
-  const int device = ctx->device;
-  std::vector<std::thread> pool;
-  for (int w = 0; w < workers; w++)
-    pool.emplace_back([&, w]() {
-      (void)hipSetDevice(device);
-      for (size_t i = 0; i < pieces.size(); i++)
-      {
-        while (arrived[i].load(std::memory_order_acquire) == 0)
-        {
-          if (failed.load()) return;
-          std::this_thread::yield();
-        }
-        const int slot = static_cast<int>(i % kStagingSlots);
-        if (hipEventSynchronize(ctx->staging_events[static_cast<size_t>(slot)]) != hipSuccess)
-        {
-          failed.store(1);
-          return;
-        }
-        const Piece& p = pieces[i];
-        // (slices on page boundaries of the destination's offset: two workers never fault the same page)
-        const size_t pages = (p.bytes + 4095) / 4096;
-        const size_t begin = std::min(p.bytes, pages * static_cast<size_t>(w) / workers * 4096);
-        const size_t end = std::min(p.bytes, pages * static_cast<size_t>(w + 1) / workers * 4096);
-        if (end > begin)
-          std::memcpy(static_cast<char*>(fields[p.field].host) + p.offset + begin,
-                      staging + static_cast<size_t>(slot) * kStagingSlotBytes + begin, end - begin);
-        copied[i].fetch_add(1, std::memory_order_release);
-      }
-    });
-  hipError_t err = hipSuccess;
-  for (size_t i = 0; i < pieces.size() && err == hipSuccess; i++)
-  {
-    const int slot = static_cast<int>(i % kStagingSlots);
-    if (i >= static_cast<size_t>(kStagingSlots))
-      while (copied[i - kStagingSlots].load(std::memory_order_acquire) < workers && !failed.load()) std::this_thread::yield();
-    if (failed.load()) break;
-    const Piece& p = pieces[i];
-    err = hipMemcpyAsync(staging + static_cast<size_t>(slot) * kStagingSlotBytes,
-                         static_cast<const char*>(fields[p.field].device) + p.offset, p.bytes, hipMemcpyDeviceToHost, s);
-    if (err == hipSuccess) err = hipEventRecord(ctx->staging_events[static_cast<size_t>(slot)], s);
-    if (err == hipSuccess) arrived[i].store(1, std::memory_order_release);
+    const size_t k = p.count == 1 ? 0 : begin / bytes;              // array of the piece
+    const size_t in_array = p.count == 1 ? p.offset + begin : begin - k * bytes;
+    const size_t array_end = p.count == 1 ? end : std::min(end, (k + 1) * bytes);
+    char* const host = static_cast<char*>(arrays[p.first + k].host) + in_array;
+    if (to_host)
+      std::memcpy(host, slot + begin, array_end - begin);
+    else
+      std::memcpy(slot + begin, host, array_end - begin);
+    begin = array_end;
   }
-  if (err != hipSuccess) failed.store(1);
-  for (auto& th : pool) th.join();
-  const hipError_t sync = hipStreamSynchronize(s);
-  if (err == hipSuccess) err = sync;
-  if (err == hipSuccess && failed.load()) err = hipErrorUnknown;
-  return err;
 }
 
-// Many host arrays that hold data into device buffers: the twin of DownloadToHostArrays.  Page-locking a 1 MiB array for
-// one copy costs ~0.15 ms (register + unregister) where the copy itself takes 0.02 -- 64 maps of 64^3 spent 10 ms
-// there.  The workers copy slices of each piece into a slot of the ring, the calling thread sends full slots on.
-// At return every copy is ENQUEUED on `s` (the ring is only reused by work enqueued on `s` later).
-hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& arrays, size_t bytes, hipStream_t s)
+// direction: true = device -> host arrays (the fields of a batch), false = host arrays -> device (its inputs)
+hipError_t MoveThroughRing(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& arrays, size_t bytes, hipStream_t s, bool to_host)
 {
   if (arrays.empty() || bytes == 0) return hipSuccess;
   {
@@ -609,19 +564,25 @@ hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCop
     if (err != hipSuccess) return err;
     ctx->staging_events.push_back(e);
   }
-  struct Piece
-  {
-    size_t array, offset, bytes;
-  };
-  std::vector<Piece> pieces;
-  for (size_t a = 0; a < arrays.size(); a++)
-    for (size_t off = 0; off < bytes; off += kStagingSlotBytes)
-      pieces.push_back(Piece{a, off, std::min(kStagingSlotBytes, bytes - off)});
-  const int workers = static_cast<int>(std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2)));
-  // filled[i]: workers done writing piece i into its slot; sent[i]: its copy to the device is enqueued and its event recorded
-  std::vector<std::atomic<int>> filled(pieces.size()), sent(pieces.size());
-  for (auto& f : filled) f.store(0);
-  for (auto& d : sent) d.store(0);
+  const std::vector<RingPiece> pieces = RingPieces(arrays, bytes);
+  const unsigned cap = to_host ? 16u : 8u;
+  const int workers = static_cast<int>(std::max(1u, std::min(cap, std::thread::hardware_concurrency() / 2)));
+#ifdef __linux__
+  // (fresh arrays of several MiB: ask for huge pages where the kernel gives them on request -- 2 MiB per fault instead of
+  // 4 KiB; a hint, any answer is fine)
+  if (to_host && bytes >= (size_t{4} << 20))
+    for (const HostArrayCopy& f : arrays)
+    {
+      const uintptr_t begin = (reinterpret_cast<uintptr_t>(f.host) + 4095) & ~uintptr_t{4095};
+      const uintptr_t end = (reinterpret_cast<uintptr_t>(f.host) + bytes) & ~uintptr_t{4095};
+      if (end > begin) (void)madvise(reinterpret_cast<void*>(begin), end - begin, MADV_HUGEPAGE);
+    }
+#endif
+  // Download: dma[i] = the copy of piece i into its slot is ENQUEUED (its event recorded); host[i] = workers done with it.
+  // Upload: host[i] = workers have filled the slot; dma[i] = its copy to the device is enqueued (event recorded).
+  std::vector<std::atomic<int>> dma(pieces.size()), host(pieces.size());
+  for (auto& a : dma) a.store(0);
+  for (auto& c : host) c.store(0);
   std::atomic<int> failed{0};
   char* const staging = static_cast<char*>(ctx->host_staging);
   const int device = ctx->device;
@@ -632,10 +593,12 @@ hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCop
       for (size_t i = 0; i < pieces.size(); i++)
       {
         const int slot = static_cast<int>(i % kStagingSlots);
-        if (i >= static_cast<size_t>(kStagingSlots))
+        // the DMA this piece's slot has to wait for: its own (download) or the one that emptied the slot (upload)
+        const bool wait_for_dma = to_host || i >= static_cast<size_t>(kStagingSlots);
+        if (wait_for_dma)
         {
-          // the slot's previous content must have left for the device
-          while (sent[i - kStagingSlots].load(std::memory_order_acquire) == 0)
+          const size_t which = to_host ? i : i - kStagingSlots;
+          while (dma[which].load(std::memory_order_acquire) == 0)
           {
             if (failed.load()) return;
             std::this_thread::yield();
@@ -646,32 +609,55 @@ hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCop
             return;
           }
         }
-        const Piece& p = pieces[i];
+        const RingPiece& p = pieces[i];
+        // (slices on page boundaries: two workers never fault the same page of a fresh array)
         const size_t pages = (p.bytes + 4095) / 4096;
         const size_t begin = std::min(p.bytes, pages * static_cast<size_t>(w) / workers * 4096);
         const size_t end = std::min(p.bytes, pages * static_cast<size_t>(w + 1) / workers * 4096);
-        if (end > begin)
-          std::memcpy(staging + static_cast<size_t>(slot) * kStagingSlotBytes + begin,
-                      static_cast<const char*>(arrays[p.array].host) + p.offset + begin, end - begin);
-        filled[i].fetch_add(1, std::memory_order_release);
+        if (end > begin) CopyPieceRange(arrays, bytes, p, staging + static_cast<size_t>(slot) * kStagingSlotBytes, begin, end, to_host);
+        host[i].fetch_add(1, std::memory_order_release);
       }
     });
   hipError_t err = hipSuccess;
   for (size_t i = 0; i < pieces.size() && err == hipSuccess; i++)
   {
     const int slot = static_cast<int>(i % kStagingSlots);
-    while (filled[i].load(std::memory_order_acquire) < workers && !failed.load()) std::this_thread::yield();
+    // the host side this DMA has to wait for: the workers that emptied the slot (download) or filled it (upload)
+    if (to_host ? i >= static_cast<size_t>(kStagingSlots) : true)
+    {
+      const size_t which = to_host ? i - kStagingSlots : i;
+      while (host[which].load(std::memory_order_acquire) < workers && !failed.load()) std::this_thread::yield();
+    }
     if (failed.load()) break;
-    const Piece& p = pieces[i];
-    err = hipMemcpyAsync(static_cast<char*>(const_cast<void*>(arrays[p.array].device)) + p.offset,
-                         staging + static_cast<size_t>(slot) * kStagingSlotBytes, p.bytes, hipMemcpyHostToDevice, s);
+    const RingPiece& p = pieces[i];
+    char* const in_slot = staging + static_cast<size_t>(slot) * kStagingSlotBytes;
+    char* const on_device = static_cast<char*>(const_cast<void*>(arrays[p.first].device)) + p.offset;
+    err = to_host ? hipMemcpyAsync(in_slot, on_device, p.bytes, hipMemcpyDeviceToHost, s)
+                  : hipMemcpyAsync(on_device, in_slot, p.bytes, hipMemcpyHostToDevice, s);
     if (err == hipSuccess) err = hipEventRecord(ctx->staging_events[static_cast<size_t>(slot)], s);
-    if (err == hipSuccess) sent[i].store(1, std::memory_order_release);
+    if (err == hipSuccess) dma[i].store(1, std::memory_order_release);
   }
   if (err != hipSuccess) failed.store(1);
   for (auto& th : pool) th.join();
+  if (to_host)
+  {
+    const hipError_t sync = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = sync;
+  }
   if (err == hipSuccess && failed.load()) err = hipErrorUnknown;
   return err;
+}
+// Many device fields into many host arrays (synchronises `s`) / many host arrays that hold data into device buffers (at
+// return every copy is ENQUEUED on `s`; the ring is only reused by work enqueued on `s` later).  Page-locking a 1 MiB
+// array for one copy costs ~0.15 ms (register + unregister) where the copy itself takes 0.02 -- 64 maps of 64^3 spent
+// 10 ms there.
+hipError_t DownloadToHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& fields, size_t bytes, hipStream_t s)
+{
+  return MoveThroughRing(ctx, fields, bytes, s, true);
+}
+hipError_t UploadFromHostArrays(vgt_hip_ctx* ctx, const std::vector<HostArrayCopy>& arrays, size_t bytes, hipStream_t s)
+{
+  return MoveThroughRing(ctx, arrays, bytes, s, false);
 }
 
 // The largest group of a batch that one launch can take: CheckBatch's limits (2^20 grids, 2^28 lines, 32-bit item counts)
