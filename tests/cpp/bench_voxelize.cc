@@ -6,11 +6,13 @@
 // raycast, filter, download -- for 1, 2 and 8 clouds dispatched in parallel as the reference does.  Prints one JSON
 // line.  The clouds hand their points over as one strided FLOAT32 buffer (PointCloud2 layout) and, for
 // comparison, through the per-point virtual copy of the plain PointCloudWrapper interface.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <limits>
 #include <random>
+#include <string>
 
 #include "../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
 
@@ -91,7 +93,41 @@ double TimeOnce(const HipPointCloudVoxelizer& voxelizer, const OccupancyMap& env
 }
 }  // namespace
 
-int main()
+// `bench_voxelize small`: the sizes of the reference's own voxelization test and examples -- a 32^3 / 64^3 grid, one cloud
+// of 10 000 points -- per blocking VoxelizePointClouds call (by reference into a kept map, by value).
+int SmallScenes(const HipPointCloudVoxelizer& voxelizer)
+{
+  std::printf("{");
+  bool first = true;
+  for (const int edge : {32, 64})
+  {
+    OccupancyMap env = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 5.12 / edge, 5.12, 5.12, 5.12, 0.0f);
+    for (int64_t x = 0; x < env.NumXVoxels(); x++)
+      for (int64_t y = 0; y < env.NumYVoxels(); y++) env.SetIndex(x, y, 0, 1.0f);
+    const std::vector<PointCloudWrapperSharedPtr> clouds = {std::make_shared<BufferCloud>(10000, 7, true)};
+    OccupancyMap kept = env;
+    double best_ref = 1e30, best_val = 1e30, sum_ref = 0.0, sum_val = 0.0;
+    const int reps = 200;
+    for (int rep = 0; rep < reps + 5; rep++)
+    {
+      double r = 0, f = 0;
+      const double a = TimeOnceInto(voxelizer, env, clouds, kept, &r, &f);
+      const double b = TimeOnce(voxelizer, env, clouds, &r, &f);
+      if (rep < 5) continue;
+      best_ref = std::min(best_ref, a);
+      best_val = std::min(best_val, b);
+      sum_ref += a;
+      sum_val += b;
+    }
+    std::printf("%s\"%d^3, 10000 points\": {\"by_reference_ms\": {\"best\": %.4f, \"mean\": %.4f}, \"by_value_ms\": {\"best\": %.4f, "
+                "\"mean\": %.4f}}", first ? "" : ", ", edge, best_ref * 1e3, sum_ref / reps * 1e3, best_val * 1e3, sum_val / reps * 1e3);
+    first = false;
+  }
+  std::printf("}\n");
+  return 0;
+}
+
+int main(int argc, char** argv)
 {
   try
   {
@@ -105,6 +141,7 @@ int main()
     options["DISPATCH_PARALLELIZE"] = 1;
     options["DISPATCH_NUM_THREADS"] = 8;
     const HipPointCloudVoxelizer voxelizer(options);
+    if (argc > 1 && std::string(argv[1]) == "small") return SmallScenes(voxelizer);
     OccupancyMap env = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.02, 5.12, 5.12, 5.12, 0.0f);
     for (int64_t x = 0; x < env.NumXVoxels(); x++)
       for (int64_t y = 0; y < env.NumYVoxels(); y++) env.SetIndex(x, y, 0, 1.0f);

@@ -3,11 +3,14 @@
 // No gtest in this image: a tiny EXPECT macro set; exit code = number of failures.
 //   test_hip_host            all tests (needs a HIP device)
 //   test_hip_host --no-device  only the "backend unavailable" behaviour (CPU box)
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <limits>
+#include <thread>
+#include <vector>
 
 #include "../../include/vgt_hip/hip_pointcloud_voxelizer.hpp"
 #include "../../oracle/vgt_oracle.h"  // the checker of the CPU-exact mode (test infrastructure: oracle/ never ships)
@@ -659,6 +662,61 @@ static void HostGridStorageTests()
   { OccupancyMap tiny = OccupancyMap::FromGridSizes(Isometry3::Identity(), "world", 0.25, 1.0, 2.0, 3.0, 0.0f); (void)tiny; }
 }
 
+// Several host threads on the process's ONE context per device (every map type shares it since round 6): extractions of
+// all four map types, small (kernels on the page-locked ring), medium (ring transfers) and batched, at the same time.
+// Every field must equal the one the same call returned on a quiet context.
+static void ConcurrentCallersTests()
+{
+  const SignedDistanceFieldGenerationParameters params;
+  std::vector<FourMaps> scenes;
+  for (const double res : {0.25, 0.125, 0.0625})  // 16^3 ... 64^3 cells for 4 x 4 x 4 m
+  {
+    scenes.emplace_back(Isometry3::Identity(), res, 4.0, 4.0, 4.0, 0.0f);
+    const int n = static_cast<int>(scenes.back().occupancy.NumXVoxels());
+    scenes.back().FillBox(n / 4, n / 2, n / 8, n / 3, n / 5, n - 2);
+    scenes.back().FillBox(0, 2, n - 3, n, 1, 3);
+  }
+  OccupancyMap medium = OccupancyMap::FromGridSizes(Isometry3::Identity(), "test_frame", 0.03125, 4.0, 4.0, 4.0, 0.0f);  // 128^3
+  FillBox(medium, 20, 50, 60, 100, 5, 120);
+  std::vector<std::vector<SignedDistanceField>> quiet;
+  for (const FourMaps& scene : scenes) quiet.push_back(scene.Fields());
+  const SignedDistanceField quiet_medium = ExtractSignedDistanceField(medium, params);
+  std::vector<const OccupancyMap*> batch;
+  for (int i = 0; i < 6; i++) batch.push_back(&scenes[2].occupancy);
+  std::atomic<int> mismatches{0};
+  const auto same = [](const SignedDistanceField& a, const SignedDistanceField& b) {
+    return a.grid.GetImmutableRawData().size() == b.grid.GetImmutableRawData().size() && a.minimum == b.minimum &&
+           a.maximum == b.maximum &&
+           std::memcmp(a.grid.GetImmutableRawData().data(), b.grid.GetImmutableRawData().data(),
+                       a.grid.GetImmutableRawData().size() * sizeof(float)) == 0;
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < 6; t++)
+    pool.emplace_back([&, t]() {
+      try
+      {
+        for (int round = 0; round < 12; round++)
+        {
+          const size_t k = static_cast<size_t>((t + round) % 3);
+          const std::vector<SignedDistanceField> fields = scenes[k].Fields();
+          for (size_t f = 0; f < fields.size(); f++)
+            if (!same(fields[f], quiet[k][f])) mismatches++;
+          if ((t + round) % 4 == 0 && !same(ExtractSignedDistanceField(medium, params), quiet_medium)) mismatches++;
+          if ((t + round) % 5 == 0)
+            for (const SignedDistanceField& field : ExtractSignedDistanceFields(batch, params))
+              if (!same(field, quiet[2][0])) mismatches++;
+        }
+      }
+      catch (const std::exception& ex)
+      {
+        std::printf("concurrent caller threw: %s\n", ex.what());
+        mismatches++;
+      }
+    });
+  for (auto& th : pool) th.join();
+  EXPECT_EQ(mismatches.load(), 0);
+}
+
 int main(int argc, char** argv)
 {
   const bool no_device = (argc > 1 && std::strcmp(argv[1], "--no-device") == 0);
@@ -671,6 +729,7 @@ int main(int argc, char** argv)
     SdfConsumerTests();
     TaggedObjectSdfTests();
     BatchedSdfTests();
+    ConcurrentCallersTests();
     PointCloudVoxelizationTests(1);
     PointCloudVoxelizationTests(4);
   }
