@@ -973,13 +973,25 @@ int UploadAndRun(vgt_hip_ctx* ctx, const void* host, size_t bytes, size_t scratc
       }
       if (lane.pinned_bytes >= bytes)
       {
-        std::memcpy(lane.pinned, host, bytes);  // (the previous use of the buffer was waited for at the end of its call)
-        source = lane.pinned;
+        // (the previous use of the buffer was waited for at the end of its call)  Piece by piece, so that the DMA of one
+        // piece runs while the host copies the next: a 12 MB cloud is 0.4 ms of memcpy and 0.2 ms of DMA -- 0.45 ms this
+        // way instead of 0.6.
+        constexpr size_t kPiece = size_t{2} << 20;
+        for (size_t off = 0; off < bytes; off += kPiece)
+        {
+          const size_t piece = std::min(kPiece, bytes - off);
+          std::memcpy(static_cast<char*>(lane.pinned) + off, static_cast<const char*>(host) + off, piece);
+          VGT_TRY_HIP(hipMemcpyAsync(static_cast<char*>(lane.stage) + off, static_cast<char*>(lane.pinned) + off, piece,
+                                     hipMemcpyHostToDevice, lane.stream),
+                      "Failed to copy points to the device");
+        }
+        source = nullptr;  // (uploaded)
       }
     }
   }
-  VGT_TRY_HIP(hipMemcpyAsync(lane.stage, source, bytes, hipMemcpyHostToDevice, lane.stream),
-              "Failed to copy points to the device");
+  if (source)
+    VGT_TRY_HIP(hipMemcpyAsync(lane.stage, source, bytes, hipMemcpyHostToDevice, lane.stream),
+                "Failed to copy points to the device");
   VGT_TRY_HIP(launch(lane.stage, static_cast<char*>(lane.stage) + scratch_at, lane.stream),
               "Failed to dispatch raycast kernel");
   VGT_TRY_HIP(hipStreamSynchronize(lane.stream), "raycast");
